@@ -1,0 +1,263 @@
+// GroupNorm(+Swish) forward / backward and the small row / column reductions.
+//
+// Replaces the reference's nn.GroupNorm(32, C, eps=1e-5) -> Swish pairs
+// (model/unet.py:207-218, :254, :180-182).  All kernels are HBM-bound:
+//   fwd : one workgroup per (view, group); the whole group (<= 32768 floats) is held in
+//         registers, so x is read ONCE and y written once (two-pass mean / variance in
+//         registers -> no E[x^2]-E[x]^2 cancellation).
+//   bwd : per-(view,channel) row sums (one wave per row), then a streaming dx pass.
+// Layout: NCHW fp32, a group is cpg*H*W contiguous floats.
+#include "common.h"
+
+namespace {
+
+template <int NV, int NT>
+__global__ __launch_bounds__(NT) void gn_fwd_kernel(const float* __restrict__ x,
+                                                    const float* __restrict__ gamma,
+                                                    const float* __restrict__ beta,
+                                                    float* __restrict__ y, float* __restrict__ mean_out,
+                                                    float* __restrict__ rstd_out, int C, int HW, int cpg,
+                                                    float eps, int silu) {
+    __shared__ float red[NT / 64];
+    const int G = C / cpg;
+    const int sg = blockIdx.x;
+    const int s = sg / G, g = sg - s * G;
+    const size_t base = ((size_t)s * C + (size_t)g * cpg) * HW;
+    const int n = cpg * HW, n4 = n >> 2;
+    const float4* x4 = reinterpret_cast<const float4*>(x + base);
+    float4* y4 = reinterpret_cast<float4*>(y + base);
+
+    float4 v[NV];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int idx = threadIdx.x + i * NT;
+        if (idx < n4) {
+            v[i] = x4[idx];
+            sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        } else {
+            v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    const float mean = block_sum<NT>(sum, red) / (float)n;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int idx = threadIdx.x + i * NT;
+        if (idx < n4) {
+            const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+            sq += (a * a + b * b) + (c * c + d * d);
+        }
+    }
+    const float var = block_sum<NT>(sq, red) / (float)n;
+    const float rstd = 1.0f / sqrtf(var + eps);
+    if (threadIdx.x == 0) {
+        mean_out[sg] = mean;
+        rstd_out[sg] = rstd;
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int idx = threadIdx.x + i * NT;
+        if (idx < n4) {
+            const int c = g * cpg + (idx * 4) / HW;
+            const float ga = gamma[c] * rstd;
+            const float be = beta[c] - mean * ga;
+            float4 o;
+            o.x = v[i].x * ga + be;
+            o.y = v[i].y * ga + be;
+            o.z = v[i].z * ga + be;
+            o.w = v[i].w * ga + be;
+            if (silu) {
+                o.x = silu_f(o.x);
+                o.y = silu_f(o.y);
+                o.z = silu_f(o.z);
+                o.w = silu_f(o.w);
+            }
+            y4[idx] = o;
+        }
+    }
+}
+
+__device__ __forceinline__ float dsilu_mul(float z, float dy) {
+    const float sg = 1.0f / (1.0f + expf(-z));
+    return dy * (sg * (1.0f + z * (1.0f - sg)));
+}
+
+// One wave per (view, channel) row: a = sum(dz), b = sum(dz * xhat).
+__global__ __launch_bounds__(256) void gn_bwd_rows_kernel(const float* __restrict__ x,
+                                                          const float* __restrict__ dy,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta,
+                                                          const float* __restrict__ mean,
+                                                          const float* __restrict__ rstd,
+                                                          float* __restrict__ dbeta_part,
+                                                          float* __restrict__ dgamma_part, int rows, int C,
+                                                          int HW, int cpg, int silu) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const int s = row / C, c = row - s * C;
+    const int sg = s * (C / cpg) + c / cpg;
+    const float mu = mean[sg], r = rstd[sg], ga = gamma[c], be = beta[c];
+    const float4* x4 = reinterpret_cast<const float4*>(x + (size_t)row * HW);
+    const float4* d4 = reinterpret_cast<const float4*>(dy + (size_t)row * HW);
+    float a = 0.f, b = 0.f;
+    for (int i = lane; i < (HW >> 2); i += 64) {
+        const float4 xv = x4[i], dv = d4[i];
+        const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+        const float ds[4] = {dv.x, dv.y, dv.z, dv.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float xh = (xs[j] - mu) * r;
+            const float dz = silu ? dsilu_mul(xh * ga + be, ds[j]) : ds[j];
+            a += dz;
+            b += dz * xh;
+        }
+    }
+    a = wave_sum(a);
+    b = wave_sum(b);
+    if (lane == 0) {
+        dbeta_part[row] = a;
+        dgamma_part[row] = b;
+    }
+}
+
+// dx = rstd * (dz*gamma - (s1 + xhat*s2)/n),  s1 = sum_c gamma_c a[s][c], s2 = sum_c gamma_c b[s][c].
+__global__ __launch_bounds__(256) void gn_bwd_dx_kernel(const float* __restrict__ x,
+                                                        const float* __restrict__ dy,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta,
+                                                        const float* __restrict__ mean,
+                                                        const float* __restrict__ rstd,
+                                                        const float* __restrict__ dbeta_part,
+                                                        const float* __restrict__ dgamma_part,
+                                                        float* __restrict__ dx, int C, int HW, int cpg,
+                                                        int silu) {
+    const int G = C / cpg;
+    const int sg = blockIdx.x;
+    const int s = sg / G, g = sg - s * G;
+    float s1 = 0.f, s2 = 0.f;
+    for (int j = 0; j < cpg; ++j) {
+        const int c = g * cpg + j;
+        const float ga = gamma[c];
+        s1 += ga * dbeta_part[s * C + c];
+        s2 += ga * dgamma_part[s * C + c];
+    }
+    const int n = cpg * HW, n4 = n >> 2;
+    const float inv_n = 1.0f / (float)n;
+    s1 *= inv_n;
+    s2 *= inv_n;
+    const float mu = mean[sg], r = rstd[sg];
+    const size_t base = ((size_t)s * C + (size_t)g * cpg) * HW;
+    const float4* x4 = reinterpret_cast<const float4*>(x + base);
+    const float4* d4 = reinterpret_cast<const float4*>(dy + base);
+    float4* o4 = reinterpret_cast<float4*>(dx + base);
+    for (int i = blockIdx.y * 256 + threadIdx.x; i < n4; i += gridDim.y * 256) {
+        const int c = g * cpg + (i * 4) / HW;
+        const float ga = gamma[c], be = beta[c];
+        const float4 xv = x4[i], dv = d4[i];
+        const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+        const float ds[4] = {dv.x, dv.y, dv.z, dv.w};
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float xh = (xs[j] - mu) * r;
+            const float dz = silu ? dsilu_mul(xh * ga + be, ds[j]) : ds[j];
+            o[j] = r * (dz * ga - (s1 + xh * s2));
+        }
+        o4[i] = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// out[row] = sum_j x[row][j]   (one wave per row; row length multiple of 4)
+__global__ __launch_bounds__(256) void rowsum_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                     int rows, int len) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float4* x4 = reinterpret_cast<const float4*>(x + (size_t)row * len);
+    float a = 0.f;
+    for (int i = lane; i < (len >> 2); i += 64) {
+        const float4 v = x4[i];
+        a += (v.x + v.y) + (v.z + v.w);
+    }
+    a = wave_sum(a);
+    if (lane == 0) out[row] = a;
+}
+
+// out[c] = sum_s part[s][c]   (deterministic, fixed order)
+__global__ void colsum_kernel(const float* __restrict__ part, float* __restrict__ out, int S, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float a = 0.f;
+    for (int s = 0; s < S; ++s) a += part[(size_t)s * C + c];
+    out[c] = a;
+}
+
+template <int NV, int NT>
+int launch_gn_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                  int S, int C, int HW, int cpg, float eps, int silu, hipStream_t st) {
+    hipLaunchKernelGGL((gn_fwd_kernel<NV, NT>), dim3(S * (C / cpg)), dim3(NT), 0, st, x, gamma, beta, y, mean,
+                       rstd, C, HW, cpg, eps, silu);
+    VF_RETURN_LAST_ERROR();
+}
+
+}  // namespace
+
+extern "C" {
+
+int vf_gn_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, int S,
+              int C, int HW, int groups, float eps, int silu, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (S <= 0) return 0;
+    if (C % groups != 0 || (HW & 3)) return (int)hipErrorInvalidValue;
+    const int cpg = C / groups;
+    const long n4 = (long)cpg * HW / 4;
+#define VF_GN(NV, NT) return launch_gn_fwd<NV, NT>(x, gamma, beta, y, mean, rstd, S, C, HW, cpg, eps, silu, st)
+    if (n4 <= 64) VF_GN(1, 64);
+    if (n4 <= 256) VF_GN(1, 256);
+    if (n4 <= 512) VF_GN(2, 256);
+    if (n4 <= 1024) VF_GN(4, 256);
+    if (n4 <= 2048) VF_GN(8, 256);
+    if (n4 <= 3072) VF_GN(12, 256);
+    if (n4 <= 4096) VF_GN(16, 256);
+    if (n4 <= 6144) VF_GN(12, 512);
+    if (n4 <= 8192) VF_GN(16, 512);
+    if (n4 <= 16384) VF_GN(16, 1024);
+    if (n4 <= 32768) VF_GN(32, 1024);
+#undef VF_GN
+    return (int)hipErrorInvalidValue;
+}
+
+int vf_gn_bwd(const float* x, const float* gamma, const float* beta, const float* mean, const float* rstd,
+              const float* dy, float* dx, float* dgamma_part, float* dbeta_part, int S, int C, int HW,
+              int groups, int silu, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (S <= 0) return 0;
+    if (C % groups != 0 || (HW & 3)) return (int)hipErrorInvalidValue;
+    const int cpg = C / groups;
+    const int rows = S * C;
+    hipLaunchKernelGGL(gn_bwd_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, x, dy, gamma, beta, mean, rstd,
+                       dbeta_part, dgamma_part, rows, C, HW, cpg, silu);
+    const int n4 = cpg * HW / 4;
+    int chunks = (n4 + 1023) / 1024;  // >= 4 float4 per thread
+    if (chunks < 1) chunks = 1;
+    hipLaunchKernelGGL(gn_bwd_dx_kernel, dim3(S * groups, chunks), dim3(256), 0, st, x, dy, gamma, beta, mean,
+                       rstd, dbeta_part, dgamma_part, dx, C, HW, cpg, silu);
+    VF_RETURN_LAST_ERROR();
+}
+
+int vf_rowsum(const float* x, float* out, int rows, int len, void* stream) {
+    if (rows <= 0) return 0;
+    if (len & 3) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(rowsum_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, out, rows, len);
+    VF_RETURN_LAST_ERROR();
+}
+
+int vf_colsum(const float* part, float* out, int S, int C, void* stream) {
+    if (C <= 0) return 0;
+    hipLaunchKernelGGL(colsum_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, part, out, S, C);
+    VF_RETURN_LAST_ERROR();
+}
+
+}  // extern "C"

@@ -1,0 +1,170 @@
+"""MI355X-native UNet denoiser: host-side mirror of the reference `UNet` interface.
+
+Same constructor keywords, same `forward(x, angle, time)` and the same `state_dict` keys /
+shapes / registration order as /root/reference/model/unet.py:8-138, so reference checkpoints
+load unchanged.  The torch.nn layer objects below are PARAMETER HOLDERS only (they give the
+reference's names and default initialisation); their own `forward` is never called.  All
+arithmetic is dispatched to the hand-written gfx950 kernels through `view_fusion_amd.ops`
+(C-ABI in include/vf_hip.h).  There is no CPU / eager fallback: without the HIP library or
+with CPU tensors the forward raises.
+
+Dataflow per residual block (reference unet.py:221-245):
+    a1 = swish(GN(x)) ............ vf_gn_fwd (one read, one write)
+    h  = conv3x3(a1) + b + Linear(t)[s,c] ........ vf_conv_fwd (epilogue: bias + per-view bias)
+    a2 = swish(GN(h))
+    y  = conv3x3(a2) + b + (x | conv1x1(x)) ...... vf_conv_fwd (epilogue: bias + residual)
+"""
+import torch
+from torch import nn
+
+
+class _Named(nn.Module):
+    """Container that registers children under explicit (reference) names."""
+
+    def __init__(self, **children):
+        super().__init__()
+        for name, mod in children.items():
+            self.add_module(name, mod)
+
+    def __getitem__(self, name):
+        return self._modules[name]
+
+
+def _norm_act_conv(cin, cout, groups):
+    # reference Block: Sequential(GroupNorm, Swish, Identity|Dropout, Conv2d) -> slots "0" and "3"
+    return _Named(block=_Named(**{"0": nn.GroupNorm(groups, cin), "3": nn.Conv2d(cin, cout, 3, padding=1)}))
+
+
+class _ResBlock(nn.Module):
+    def __init__(self, cin, cout, emb_dim, groups):
+        super().__init__()
+        self.noise_func = _Named(noise_func=_Named(**{"0": nn.Linear(emb_dim, cout)}))
+        self.block1 = _norm_act_conv(cin, cout, groups)
+        self.block2 = _norm_act_conv(cout, cout, groups)
+        self.res_conv = nn.Conv2d(cin, cout, 1) if cin != cout else nn.Identity()
+        self.groups = groups
+
+    def forward(self, x, emb):
+        from . import ops
+        b1, b2 = self.block1["block"], self.block2["block"]
+        lin = self.noise_func["noise_func"]["0"]
+        e = ops.linear(emb, lin.weight, lin.bias)                                   # (S,Cout)
+        a = ops.group_norm(x, b1["0"].weight, b1["0"].bias, self.groups, silu=True)
+        h = ops.conv2d(a, b1["3"], view_bias=e)
+        a = ops.group_norm(h, b2["0"].weight, b2["0"].bias, self.groups, silu=True)
+        skip = x if isinstance(self.res_conv, nn.Identity) else ops.conv2d(x, self.res_conv)
+        return ops.conv2d(a, b2["3"], residual=skip)
+
+
+class _SelfAttention(nn.Module):
+    def __init__(self, ch, groups):
+        super().__init__()
+        self.norm = nn.GroupNorm(groups, ch)
+        self.qkv = nn.Conv2d(ch, ch * 3, 1, bias=False)
+        self.out = nn.Conv2d(ch, ch, 1)
+        self.groups = groups
+
+    def forward(self, x):
+        from . import ops
+        n = ops.group_norm(x, self.norm.weight, self.norm.bias, self.groups, silu=False)
+        qkv = ops.conv2d(n, self.qkv)                                               # (S,3C,H,W)
+        o = ops.attention(qkv)                                                      # (S,C,H,W)
+        return ops.conv2d(o, self.out, residual=x)
+
+
+class _ResAttnBlock(nn.Module):
+    def __init__(self, cin, cout, emb_dim, groups, with_attn):
+        super().__init__()
+        self.with_attn = with_attn
+        self.res_block = _ResBlock(cin, cout, emb_dim, groups)
+        if with_attn:
+            self.attn = _SelfAttention(cout, groups)
+
+    def forward(self, x, emb):
+        x = self.res_block(x, emb)
+        return self.attn(x) if self.with_attn else x
+
+
+class _Resample(nn.Module):
+    def __init__(self, ch, up):
+        super().__init__()
+        self.up = up
+        self.conv = nn.Conv2d(ch, ch, 3, padding=1) if up else nn.Conv2d(ch, ch, 3, 2, 1)
+
+    def forward(self, x):
+        from . import ops
+        return ops.conv2d(x, self.conv, mode="up2" if self.up else "down2")
+
+
+class UNet(nn.Module):
+    def __init__(self, in_channel=6, out_channel=3, inner_channel=32, norm_groups=32,
+                 channel_mults=(1, 2, 4, 8, 8), attn_res=(8,), res_blocks=3, dropout=0,
+                 with_noise_level_emb=True, image_size=128):
+        super().__init__()
+        if dropout != 0:
+            raise NotImplementedError("dropout != 0 is never used by the reference configs")
+        if not with_noise_level_emb:
+            raise NotImplementedError("with_noise_level_emb=False is never used by the reference configs")
+        self.inner_channel = inner_channel
+        self.noise_level_mlp = _Named(**{"0": nn.Linear(inner_channel, inner_channel * 4),
+                                         "2": nn.Linear(inner_channel * 4, inner_channel)})
+        emb = inner_channel
+        ch = inner_channel
+        skips = [ch]
+        res = image_size
+        downs = [nn.Conv2d(in_channel, inner_channel, 3, padding=1)]
+        last = len(channel_mults) - 1
+        for lvl, mult in enumerate(channel_mults):
+            width = inner_channel * mult
+            for _ in range(res_blocks):
+                downs.append(_ResAttnBlock(ch, width, emb, norm_groups, res in attn_res))
+                ch = width
+                skips.append(ch)
+            if lvl != last:
+                downs.append(_Resample(ch, up=False))
+                skips.append(ch)
+                res //= 2
+        self.downs = nn.ModuleList(downs)
+        self.mid = nn.ModuleList([_ResAttnBlock(ch, ch, emb, norm_groups, True),
+                                  _ResAttnBlock(ch, ch, emb, norm_groups, False)])
+        ups = []
+        for lvl in reversed(range(len(channel_mults))):
+            width = inner_channel * channel_mults[lvl]
+            for _ in range(res_blocks + 1):
+                ups.append(_ResAttnBlock(ch + skips.pop(), width, emb, norm_groups, res in attn_res))
+                ch = width
+            if lvl > 0:
+                ups.append(_Resample(ch, up=True))
+                res *= 2
+        self.ups = nn.ModuleList(ups)
+        self.final_conv = _norm_act_conv(ch, out_channel if out_channel is not None else in_channel,
+                                         norm_groups)
+        self.norm_groups = norm_groups
+
+    def forward(self, x, angle, time):
+        """x (S,Cin,H,W), angle (S,1), time = noise level (S,1)  ->  (S,Cout,H,W)."""
+        from . import ops
+        mlp = self.noise_level_mlp
+        pe = ops.sincos_embedding(time, angle, self.inner_channel)                  # (S,inner)
+        emb = ops.linear(pe, mlp["0"].weight, mlp["0"].bias)
+        emb = ops.linear(ops.swish(emb), mlp["2"].weight, mlp["2"].bias)            # (S,inner)
+
+        feats = []
+        for layer in self.downs:
+            if isinstance(layer, _ResAttnBlock):
+                x = layer(x, emb)
+            elif isinstance(layer, _Resample):
+                x = layer(x)
+            else:
+                x = ops.conv2d(x, layer)
+            feats.append(x)
+        for layer in self.mid:
+            x = layer(x, emb)
+        for layer in self.ups:
+            if isinstance(layer, _ResAttnBlock):
+                x = layer(ops.concat_channels(x, feats.pop()), emb)
+            else:
+                x = layer(x)
+        fc = self.final_conv["block"]
+        a = ops.group_norm(x, fc["0"].weight, fc["0"].bias, self.norm_groups, silu=True)
+        return ops.conv2d(a, fc["3"])
