@@ -1,0 +1,81 @@
+/* vf_hip.h -- C ABI of libvf_hip.so, the MI355X (gfx950) kernels of the ViewFusion hot path.
+ *
+ * The reference (bronemos/view-fusion) has no FFI: its hot path is `model/unet.py` +
+ * `model/view_fusion.py` calling stock torch ops.  Each entry point below replaces the torch
+ * op(s) cited next to it.  Conventions:
+ *   - raw DEVICE pointers to contiguous fp32 NCHW tensors, explicit sizes, explicit stream
+ *     (`hipStream_t` passed as void*); no torch types;
+ *   - every call only ENQUEUES work: no allocation, no synchronisation, no retained
+ *     pointers, re-entrant, HIP-graph capturable; workspaces are passed in by the caller;
+ *   - return value is a hipError_t as int (0 = success; hipErrorInvalidValue for an
+ *     unsupported shape -- there is no fallback path).
+ */
+#ifndef VF_HIP_H
+#define VF_HIP_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- GroupNorm (+Swish) : nn.GroupNorm(32,C,eps) -> Swish, unet.py:211-212,254,180-182 ---- */
+int vf_gn_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean /*[S*G]*/,
+              float* rstd /*[S*G]*/, int S, int C, int HW, int groups, float eps, int silu, void* stream);
+/* dgamma_part/dbeta_part: [S][C] per-view partials; reduce over S with vf_colsum. */
+int vf_gn_bwd(const float* x, const float* gamma, const float* beta, const float* mean, const float* rstd,
+              const float* dy, float* dx, float* dgamma_part, float* dbeta_part, int S, int C, int HW, int groups,
+              int silu, void* stream);
+int vf_rowsum(const float* x, float* out /*[rows]*/, int rows, int len, void* stream);
+int vf_colsum(const float* part /*[S][C]*/, float* out /*[C]*/, int S, int C, void* stream);
+
+/* ---- convolution : nn.Conv2d 3x3 / 1x1, nn.Upsample+conv, stride-2 conv,
+ *      unet.py:42,189,198,214,238,255,256 (+ FeatureWiseAffine add :160-177, residual add :245,277) ---- */
+int vf_conv_pack_sizes(int Cout, int Cin, int KS, long* fwd_floats, long* bwd_floats);
+int vf_conv_pack_weights(const float* w_oihw, float* w_fwd, float* w_bwd /*or NULL*/, int Cout, int Cin, int KS,
+                         void* stream);
+/* mode 0 stride-1 | 1 stride-2 (x is 2Hx2W) | 2 nearest-x2 upsampled x (x is H/2xW/2) |
+ * 3 zero-dilated x (dgrad of mode 1).  H,W = OUTPUT size, square power of two in [8,128]. */
+int vf_conv_fwd(const float* x, const float* w_packed, const float* bias /*[Cout]|NULL*/,
+                const float* view_bias /*[S][Cout]|NULL*/, const float* residual /*like y|NULL*/, float* y, int S,
+                int Cin, int Cout, int H, int W, int KS, int mode, void* stream);
+long vf_conv_wgrad_ws_floats(int S, int Cin, int Cout, int H, int W, int KS);
+int vf_conv_wgrad(const float* x, const float* dy, float* dw_oihw, float* ws, long ws_floats, int S, int Cin,
+                  int Cout, int H, int W, int KS, int mode, void* stream);
+int vf_sumpool2(const float* x, float* y, long n_out, int Wo, void* stream);
+
+/* ---- batched GEMM + softmax : torch.einsum / torch.softmax / nn.Linear,
+ *      unet.py:267-274 (attention), :29-31,165 (linears) ---- */
+int vf_bgemm(const float* A, const float* B, float* C, const float* bias /*[N]|NULL*/, int batch, int M, int N,
+             int K, long sAb, long sAm, long sAk, long sBb, long sBk, long sBn, long sCb, long sCm, long sCn,
+             float alpha, float beta, void* stream);
+int vf_softmax_fwd(const float* x, float* y, int rows, int cols, void* stream);
+int vf_softmax_bwd(const float* y, const float* dy, float* dx, int rows, int cols, void* stream);
+
+/* ---- small elementwise : PositionalEncoding unet.py:142-157, Swish :180-182, torch.cat :134 ---- */
+int vf_sincos_embed(const float* level /*[S]*/, const float* angle /*[S]*/, float* out /*[S][dim]*/, int S, int dim,
+                    void* stream);
+int vf_swish_fwd(const float* x, float* y, long n, void* stream);
+int vf_swish_bwd(const float* x, const float* dy, float* dx, long n, void* stream);
+int vf_concat_channels(float* a, float* b, float* out, int S, long na, long nb, int split, void* stream);
+
+/* ---- ViewFusion : view_fusion.py:162-164 (q_sample), :244-263/:95-115 (stack), :265-298/:116-150
+ *      (compose, mean ablation, MSE), :70-84,152-177 (posterior + p_sample), :314-317 (extract) ---- */
+int vf_gather_level(const float* gammas, const long long* t, const float* u /*[B]|NULL*/, float* level, int B,
+                    void* stream);
+int vf_stack_views(const float* y_cond, const float* y_t, const float* noise /*|NULL*/, const float* level,
+                   const float* angle, const int* off /*[B+1]*/, float* x, float* level_s, float* angle_s, int B,
+                   int Nmax, int HW, int S, int copy_cond, void* stream);
+int vf_compose_fwd(const float* unet_out, const int* off, const float* target /*|NULL*/, float* noise_hat,
+                   float* weights /*[B][maxV][3][HW]|NULL*/, float* loss_part /*[B*64]*/, float* loss, int B,
+                   int Cout, int HW, int maxV, int weighting, void* stream);
+int vf_compose_mse_bwd(const float* unet_out, const int* off, const float* target, const float* noise_hat,
+                       const float* gloss, float* dout, int B, int Cout, int HW, int weighting, void* stream);
+int vf_p_sample_tail(const float* unet_out, const int* off, const float* y_t, const float* z /*|NULL*/,
+                     const long long* t, const float* sqrt_recip_gammas, const float* sqrt_recipm1_gammas,
+                     const float* posterior_log_variance, const float* posterior_mean_coef1,
+                     const float* posterior_mean_coef2, float* y_next /*|NULL*/, float* mean_out /*|NULL*/,
+                     float* weights /*|NULL*/, int B, int Cout, int HW, int maxV, int weighting, int clip,
+                     void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VF_HIP_H */

@@ -1,0 +1,146 @@
+"""End-to-end parity on a real MI355X: the HIP UNet / ViewFusion against the golden vectors made
+from the real reference (tests/golden) and against the CPU oracle on the same inputs.
+
+Stated fp32 tolerances: UNet forward atol 5e-5 / rtol 1e-4; loss rel 1e-5;
+gradient digests l2 rel 1e-4 (+ per-element floor 3e-5 for analytically-zero gradients).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, SMALL, TINY
+
+pytestmark = pytest.mark.gpu
+SCHED_TRAIN = dict(schedule="linear", num_timesteps=2000, linear_start=1e-6, linear_end=1e-2)
+SCHED_TEST = dict(schedule="linear", num_timesteps=1000, linear_start=1e-4, linear_end=0.09)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+def make_unet(hp, dev):
+    from view_fusion_amd import UNet
+    from view_fusion_amd.utils import deterministic_fill_
+    net = UNet(**hp)
+    deterministic_fill_(net.state_dict())
+    return net.to(dev)
+
+
+def make_vf(hp, sched, dev, weighting=True):
+    from view_fusion_amd import ViewFusion
+    vf = ViewFusion(make_unet(hp, dev), {"train": sched}, weighting, weighting)
+    vf.set_new_noise_schedule(device=dev, phase="train")
+    return vf
+
+
+def check_grads(g, named_params, prefix="g."):
+    from view_fusion_amd.utils import tensor_digest
+    for k, p in named_params:
+        ref = g[f"{prefix}{k}.stat"]
+        d = tensor_digest(p.grad)
+        assert abs(d["l2"] - ref[1]) <= 1e-4 * ref[1] + 3e-5 * p.numel() ** 0.5, k
+        np.testing.assert_allclose(d["samples"], g[f"{prefix}{k}.samples"], rtol=2e-3,
+                                   atol=2e-5 * ref[2] + 3e-5, err_msg=k)
+
+
+def T(a, dev):
+    return torch.tensor(a).to(dev)
+
+
+def test_unet_tiny_forward_backward_vs_reference(dev):
+    g = load("unet_tiny.npz")
+    net = make_unet(TINY, dev)
+    x = T(g["x"], dev).requires_grad_(True)
+    y = net(x, T(g["angle"], dev), T(g["level"], dev))
+    np.testing.assert_allclose(y.detach().cpu().numpy(), g["y"], rtol=1e-4, atol=5e-5)
+    (y * T(g["gy"], dev)).sum().backward()
+    np.testing.assert_allclose(x.grad.cpu().numpy(), g["gx"], rtol=1e-3, atol=1e-5)
+    check_grads(g, net.named_parameters())
+
+
+def test_unet_small_forward_vs_reference(dev):
+    g = load("unet_small.npz")
+    net = make_unet(SMALL, dev)
+    with torch.no_grad():
+        y = net(T(g["x"], dev), T(g["angle"], dev), T(g["level"], dev))
+    np.testing.assert_allclose(y.cpu().numpy(), g["y"], rtol=1e-4, atol=5e-5)
+
+
+@pytest.mark.parametrize("tag", ["uniform_w", "ragged_w", "ragged_mean"])
+def test_train_forward_loss_and_grads_vs_reference(dev, tag):
+    g = load(f"train_{tag}.npz")
+    vf = make_vf(TINY, SCHED_TRAIN, dev, bool(g["weighting"]))
+    loss = vf(y_cond=T(g["y_cond"], dev), view_count=torch.tensor(g["view_count"]), angle=T(g["angle"], dev),
+              y_0=T(g["y_0"], dev), noise=T(g["noise"], dev), t=T(g["t"], dev), u=T(g["u"], dev))
+    assert abs(loss.item() - float(g["loss"])) <= 1e-5 * abs(float(g["loss"]))
+    loss.backward()
+    check_grads(g, vf.denoise_fn.named_parameters())
+
+
+@pytest.mark.parametrize("tag,weighting", [("w", True), ("mean", False)])
+def test_generate_chain_vs_reference(dev, tag, weighting):
+    g = load(f"sample_generate_{tag}.npz")
+    vf = make_vf(TINY, dict(schedule="linear", num_timesteps=10, linear_start=1e-4, linear_end=0.09), dev, weighting)
+    y, ret, logit_arr, weight_arr, samples = vf.generate(
+        T(g["y_cond"], dev), torch.tensor(g["view_count"]), T(g["angle"], dev), y_t=T(g["y_T"], dev),
+        z_seq=T(g["z_seq"], dev))
+    np.testing.assert_allclose(y.cpu().numpy(), g["y"], rtol=1e-4, atol=5e-5)
+    np.testing.assert_allclose(ret.cpu().numpy(), g["ret"], rtol=1e-4, atol=5e-5)
+    np.testing.assert_allclose(samples.cpu().numpy(), g["samples"], rtol=1e-4, atol=5e-5)
+    if weighting:
+        np.testing.assert_allclose(logit_arr.cpu().numpy(), g["logit_arr"], rtol=1e-4, atol=5e-5)
+        np.testing.assert_allclose(weight_arr.cpu().numpy(), g["weight_arr"], rtol=1e-4, atol=1e-5)
+    else:
+        assert logit_arr == [None] * 10 and weight_arr == [None] * 10
+
+
+def test_p_mean_variance_vs_reference(dev):
+    g = load("sample_pmv.npz")
+    vf = make_vf(TINY, SCHED_TEST, dev, True)
+    with torch.no_grad():
+        mean, logvar, logits, w = vf.p_mean_variance(T(g["y_t"], dev), T(g["y_cond"], dev),
+                                                     torch.tensor(g["view_count"]), T(g["angle"], dev),
+                                                     T(g["t"], dev), clip_denoised=True)
+    np.testing.assert_allclose(mean.cpu().numpy(), g["mean"], rtol=1e-4, atol=5e-5)
+    np.testing.assert_array_equal(logvar.cpu().numpy(), g["logvar"])
+    np.testing.assert_allclose(logits.cpu().numpy(), g["logits"], rtol=1e-4, atol=5e-5)
+    np.testing.assert_allclose(w.cpu().numpy(), g["weights"], rtol=1e-4, atol=1e-5)
+
+
+def test_small_train_step_vs_oracle(dev):
+    """Full-size network (33.9 M params), B=2 N=2: loss and gradient digests vs the CPU oracle."""
+    from oracle import unet_ref, view_fusion_ref as vfr
+    from view_fusion_amd.utils import tensor_digest
+    vf = make_vf(SMALL, SCHED_TRAIN, dev, True)
+    g = torch.Generator().manual_seed(0)
+    B, N = 2, 2
+    y_0, y_cond = torch.rand(B, 3, 64, 64, generator=g), torch.rand(B, N, 3, 64, 64, generator=g)
+    angle = 2 * np.pi / 24 * torch.randint(0, 24, (B, 1), generator=g).float()
+    noise, t, u = torch.randn(B, 3, 64, 64, generator=g), torch.tensor([1500, 3]), torch.rand(B, 1, generator=g)
+    vc = torch.tensor([2, 1])
+    loss = vf(y_cond=y_cond.to(dev), view_count=vc, angle=angle.to(dev), y_0=y_0.to(dev), noise=noise.to(dev),
+              t=t.to(dev), u=u.to(dev))
+    loss.backward()
+    sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in vf.denoise_fn.state_dict().items()}
+    sched = vfr.schedule_buffers(vfr.beta_schedule(**SCHED_TRAIN))
+    fn = lambda x, a, l: unet_ref.unet_forward(sd, SMALL, x, a, l)
+    lref = vfr.train_loss(fn, sched, y_cond, vc, angle, y_0, t, u, noise, True)
+    lref.backward()
+    assert abs(loss.item() - lref.item()) <= 1e-5 * abs(lref.item())
+    worst = 0.0
+    for k, p in vf.denoise_fn.named_parameters():
+        a, b = p.grad.detach().cpu().double(), sd[k].grad.double()
+        err = float((a - b).norm() / b.norm().clamp_min(1e-12))
+        if float(b.norm()) > 1e-4:
+            worst = max(worst, err)
+    assert worst < 1e-4, worst

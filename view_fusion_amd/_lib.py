@@ -1,0 +1,73 @@
+"""ctypes binding of libvf_hip.so (C ABI declared in include/vf_hip.h).
+
+There is NO fallback: if the library is missing or a call returns a non-zero hipError_t the
+caller gets an exception.  The library must be loaded after `import torch` so that it binds to
+the HIP runtime torch already loaded (same SONAME libamdhip64.so.7) -- one runtime, shared
+streams and allocations.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (loads libamdhip64 first)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libvf_hip.so")
+
+_P, _I, _L, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
+
+# name -> argtypes (restype is int unless listed in _RESTYPE)
+SIGNATURES = {
+    "vf_gn_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P],
+    "vf_gn_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "vf_rowsum": [_P, _P, _I, _I, _P],
+    "vf_colsum": [_P, _P, _I, _I, _P],
+    "vf_conv_pack_sizes": [_I, _I, _I, ctypes.POINTER(_L), ctypes.POINTER(_L)],
+    "vf_conv_pack_weights": [_P, _P, _P, _I, _I, _I, _P],
+    "vf_conv_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "vf_conv_wgrad_ws_floats": [_I, _I, _I, _I, _I, _I],
+    "vf_conv_wgrad": [_P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _P],
+    "vf_sumpool2": [_P, _P, _L, _I, _P],
+    "vf_bgemm": [_P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _L, _L, _L, _L, _L, _F, _F, _P],
+    "vf_softmax_fwd": [_P, _P, _I, _I, _P],
+    "vf_softmax_bwd": [_P, _P, _P, _I, _I, _P],
+    "vf_sincos_embed": [_P, _P, _P, _I, _I, _P],
+    "vf_swish_fwd": [_P, _P, _L, _P],
+    "vf_swish_bwd": [_P, _P, _P, _L, _P],
+    "vf_concat_channels": [_P, _P, _P, _I, _L, _L, _I, _P],
+    "vf_gather_level": [_P, _P, _P, _P, _I, _P],
+    "vf_stack_views": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "vf_compose_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "vf_compose_mse_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "vf_p_sample_tail": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+}
+_RESTYPE = {"vf_conv_wgrad_ws_floats": _L}
+
+_lib = None
+
+
+class VFHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and return the ctypes library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise VFHipError(
+                f"{LIB_PATH} not found: build it with `python -m view_fusion_amd.build` "
+                "(there is no CPU / eager fallback for the ViewFusion hot path)")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, args in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.argtypes = args
+            fn.restype = _RESTYPE.get(name, _I)
+        _lib = lib
+    return _lib
+
+
+def call(name, *args):
+    """Invoke an int-returning launcher; non-zero hipError_t -> exception."""
+    rc = getattr(load(), name)(*args)
+    if rc != 0:
+        raise VFHipError(f"{name} failed with hipError_t {rc}")

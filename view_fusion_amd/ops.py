@@ -1,0 +1,438 @@
+"""Operators of the ViewFusion hot path: torch.autograd glue over the HIP C ABI.
+
+Every function here enqueues hand-written gfx950 kernels (include/vf_hip.h) on torch's
+current HIP stream.  PyTorch supplies device memory, streams and the autograd tape only.
+CPU tensors are rejected -- there is no eager fallback.
+"""
+import ctypes
+import math
+
+import torch
+
+from . import _lib
+
+_MODES = {"same": 0, "down2": 1, "up2": 2}
+
+
+def _ptr(t, offset_elems=0):
+    if t is None:
+        return None
+    return ctypes.c_void_p(t.data_ptr() + 4 * offset_elems)
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _check(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise _lib.VFHipError("view_fusion_amd ops need CUDA/HIP tensors (no CPU fallback)")
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise _lib.VFHipError(f"expected contiguous float32, got {t.dtype} contiguous={t.is_contiguous()}")
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ---------------------------------------------------------------------------------------------
+# workspace shared by all wgrad launches on a device (stream ordered, grown on demand)
+_ws = {}
+
+
+def _workspace(device, nfloats):
+    buf = _ws.get(device)
+    if buf is None or buf.numel() < nfloats:
+        buf = torch.empty(int(nfloats), device=device, dtype=torch.float32)
+        _ws[device] = buf
+    return buf
+
+
+# ---------------------------------------------------------------------------------------------
+class _GroupNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, groups, silu):
+        _check(x, gamma, beta)
+        S, C, H, W = x.shape
+        y = torch.empty_like(x)
+        mean = torch.empty(S * groups, device=x.device, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        _lib.call("vf_gn_fwd", _ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(mean), _ptr(rstd), S, C, H * W,
+                  groups, 1e-5, int(silu), _stream())
+        ctx.save_for_backward(x, gamma, beta, mean, rstd)
+        ctx.groups, ctx.silu = groups, int(silu)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, mean, rstd = ctx.saved_tensors
+        dy = _c(dy)
+        S, C, H, W = x.shape
+        dx = torch.empty_like(x)
+        parts = torch.empty(2, S, C, device=x.device, dtype=torch.float32)
+        _lib.call("vf_gn_bwd", _ptr(x), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd), _ptr(dy), _ptr(dx),
+                  _ptr(parts[0]), _ptr(parts[1]), S, C, H * W, ctx.groups, ctx.silu, _stream())
+        dgb = torch.empty(2, C, device=x.device, dtype=torch.float32)
+        _lib.call("vf_colsum", _ptr(parts[0]), _ptr(dgb[0]), S, C, _stream())
+        _lib.call("vf_colsum", _ptr(parts[1]), _ptr(dgb[1]), S, C, _stream())
+        return dx, dgb[0], dgb[1], None, None
+
+
+def group_norm(x, weight, bias, groups, silu):
+    """GroupNorm(groups, C, eps=1e-5) [+ x*sigmoid(x)] on (S,C,H,W)."""
+    return _GroupNormFn.apply(x, weight, bias, groups, silu)
+
+
+# ---------------------------------------------------------------------------------------------
+def _packed(layer):
+    """Packed forward / dgrad weights of a conv layer, re-packed when the weight changes."""
+    w = layer.weight
+    cache = getattr(layer, "_vf_pack", None)
+    key = (w._version, w.data_ptr(), w.device)
+    if cache is not None and cache[0] == key:
+        return cache[1], cache[2]
+    Cout, Cin, KS, _ = w.shape
+    nf, nb = ctypes.c_long(), ctypes.c_long()
+    _lib.call("vf_conv_pack_sizes", Cout, Cin, KS, ctypes.byref(nf), ctypes.byref(nb))
+    if cache is not None and cache[1].numel() == nf.value and cache[1].device == w.device:
+        wf, wb = cache[1], cache[2]
+    else:
+        wf = torch.empty(nf.value, device=w.device, dtype=torch.float32)
+        wb = torch.empty(nb.value, device=w.device, dtype=torch.float32)
+    wd = w.detach()
+    _check(wd)
+    _lib.call("vf_conv_pack_weights", _ptr(wd), _ptr(wf), _ptr(wb), Cout, Cin, KS, _stream())
+    object.__setattr__(layer, "_vf_pack", (key, wf, wb))
+    return wf, wb
+
+
+class _Conv2dFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, view_bias, residual, layer, mode):
+        _check(x, bias, view_bias, residual)
+        wf, wb = _packed(layer)
+        S, Cin, Hi, Wi = x.shape
+        Cout, _, KS, _ = weight.shape
+        m = _MODES[mode]
+        H, W = (Hi // 2, Wi // 2) if m == 1 else ((Hi * 2, Wi * 2) if m == 2 else (Hi, Wi))
+        y = torch.empty(S, Cout, H, W, device=x.device, dtype=torch.float32)
+        _lib.call("vf_conv_fwd", _ptr(x), _ptr(wf), _ptr(bias), _ptr(view_bias), _ptr(residual), _ptr(y), S, Cin,
+                  Cout, H, W, KS, m, _stream())
+        ctx.save_for_backward(x)
+        ctx.wb, ctx.m, ctx.KS, ctx.Cout = wb, m, KS, Cout
+        ctx.has = (bias is not None, view_bias is not None, residual is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = _c(dy)
+        S, Cin, Hi, Wi = x.shape
+        _, Cout, H, W = dy.shape
+        KS, m = ctx.KS, ctx.m
+        st = _stream()
+        dx = dw = db = dvb = dres = None
+        if ctx.needs_input_grad[0]:
+            if m == 0:
+                dx = torch.empty_like(x)
+                _lib.call("vf_conv_fwd", _ptr(dy), _ptr(ctx.wb), None, None, None, _ptr(dx), S, Cout, Cin, H, W,
+                          KS, 0, st)
+            elif m == 1:      # stride-2 conv: transposed conv = conv over the zero-dilated dy
+                dx = torch.empty_like(x)
+                _lib.call("vf_conv_fwd", _ptr(dy), _ptr(ctx.wb), None, None, None, _ptr(dx), S, Cout, Cin, Hi, Wi,
+                          KS, 3, st)
+            else:             # upsample + conv: dgrad at the upsampled size, then 2x2 sum-pool
+                dup = torch.empty(S, Cin, H, W, device=x.device, dtype=torch.float32)
+                _lib.call("vf_conv_fwd", _ptr(dy), _ptr(ctx.wb), None, None, None, _ptr(dup), S, Cout, Cin, H, W,
+                          KS, 0, st)
+                dx = torch.empty_like(x)
+                _lib.call("vf_sumpool2", _ptr(dup), _ptr(dx), dx.numel(), Wi, st)
+        if ctx.needs_input_grad[1]:
+            need = _lib.load().vf_conv_wgrad_ws_floats(S, Cin, Cout, H, W, KS)
+            ws = _workspace(x.device, need)
+            dw = torch.empty(Cout, Cin, KS, KS, device=x.device, dtype=torch.float32)
+            _lib.call("vf_conv_wgrad", _ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), ws.numel(), S, Cin, Cout, H, W, KS, m,
+                      st)
+        hb, hv, hr = ctx.has
+        if (hb and ctx.needs_input_grad[2]) or (hv and ctx.needs_input_grad[3]):
+            rs = torch.empty(S, Cout, device=x.device, dtype=torch.float32)
+            _lib.call("vf_rowsum", _ptr(dy), _ptr(rs), S * Cout, H * W, st)
+            if hv and ctx.needs_input_grad[3]:
+                dvb = rs
+            if hb and ctx.needs_input_grad[2]:
+                db = torch.empty(Cout, device=x.device, dtype=torch.float32)
+                _lib.call("vf_colsum", _ptr(rs), _ptr(db), S, Cout, st)
+        if hr and ctx.needs_input_grad[4]:
+            dres = dy
+        return dx, dw, db, dvb, dres, None, None
+
+
+def conv2d(x, layer, view_bias=None, residual=None, mode="same"):
+    """3x3 (pad 1) or 1x1 convolution with the parameters of `layer` (an nn.Conv2d holder).
+
+    mode "same": stride 1; "down2": stride 2; "up2": nearest x2 upsample fused into the load.
+    Epilogue adds bias[c] + view_bias[s,c] + residual.
+    """
+    return _Conv2dFn.apply(x, layer.weight, layer.bias, view_bias, residual, layer, mode)
+
+
+# ---------------------------------------------------------------------------------------------
+def _bgemm(A, B, C, bias, batch, M, N, K, sA, sB, sC, alpha=1.0, beta=0.0, offA=0, offB=0, offC=0):
+    _lib.call("vf_bgemm", _ptr(A, offA), _ptr(B, offB), _ptr(C, offC), _ptr(bias), batch, M, N, K, sA[0], sA[1],
+              sA[2], sB[0], sB[1], sB[2], sC[0], sC[1], sC[2], alpha, beta, _stream())
+
+
+class _LinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b):
+        _check(x, w, b)
+        S, I = x.shape
+        O = w.shape[0]
+        y = torch.empty(S, O, device=x.device, dtype=torch.float32)
+        _bgemm(x, w, y, b, 1, S, O, I, (0, I, 1), (0, 1, I), (0, O, 1))
+        ctx.save_for_backward(x, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = _c(dy)
+        S, I = x.shape
+        O = w.shape[0]
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            _bgemm(dy, w, dx, None, 1, S, I, O, (0, O, 1), (0, I, 1), (0, I, 1))
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(w)
+            _bgemm(dy, x, dw, None, 1, O, I, S, (0, 1, O), (0, I, 1), (0, I, 1))
+        if ctx.needs_input_grad[2]:
+            db = torch.empty(O, device=x.device, dtype=torch.float32)
+            _lib.call("vf_colsum", _ptr(dy), _ptr(db), S, O, _stream())
+        return dx, dw, db
+
+
+def linear(x, weight, bias):
+    """(S,I) @ weight(O,I)^T + bias -> (S,O)."""
+    return _LinearFn.apply(x, weight, bias)
+
+
+class _SwishFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _check(x)
+        y = torch.empty_like(x)
+        _lib.call("vf_swish_fwd", _ptr(x), _ptr(y), x.numel(), _stream())
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = _c(dy)
+        dx = torch.empty_like(x)
+        _lib.call("vf_swish_bwd", _ptr(x), _ptr(dy), _ptr(dx), x.numel(), _stream())
+        return dx
+
+
+def swish(x):
+    return _SwishFn.apply(x)
+
+
+def sincos_embedding(level, angle, dim):
+    """(S,1),(S,1) -> (S,dim): [sin|cos](level*f) ++ [sin|cos](angle*f), dim/4 frequencies."""
+    level = _c(level.detach().reshape(-1).float())
+    angle = _c(angle.detach().reshape(-1).float())
+    _check(level, angle)
+    S = level.numel()
+    out = torch.empty(S, dim, device=level.device, dtype=torch.float32)
+    _lib.call("vf_sincos_embed", _ptr(level), _ptr(angle), _ptr(out), S, dim, _stream())
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+class _AttentionFn(torch.autograd.Function):
+    """softmax(Q^T K / sqrt(C)) applied to V for single-head spatial attention; qkv (S,3C,H,W)."""
+
+    @staticmethod
+    def forward(ctx, qkv):
+        _check(qkv)
+        S, C3, H, W = qkv.shape
+        C, L = C3 // 3, H * W
+        alpha = 1.0 / math.sqrt(C)
+        P = torch.empty(S, L, L, device=qkv.device, dtype=torch.float32)
+        _bgemm(qkv, qkv, P, None, S, L, L, C, (C3 * L, 1, L), (C3 * L, L, 1), (L * L, L, 1), alpha,
+               offA=0, offB=C * L)
+        _lib.call("vf_softmax_fwd", _ptr(P), _ptr(P), S * L, L, _stream())
+        out = torch.empty(S, C, H, W, device=qkv.device, dtype=torch.float32)
+        _bgemm(qkv, P, out, None, S, C, L, L, (C3 * L, L, 1), (L * L, 1, L), (C * L, L, 1), offA=2 * C * L)
+        ctx.save_for_backward(qkv, P)
+        return out
+
+    @staticmethod
+    def backward(ctx, dO):
+        qkv, P = ctx.saved_tensors
+        dO = _c(dO)
+        S, C3, H, W = qkv.shape
+        C, L = C3 // 3, H * W
+        alpha = 1.0 / math.sqrt(C)
+        dqkv = torch.empty_like(qkv)
+        dS = torch.empty_like(P)
+        # dP[i][j] = sum_c dO[c][i] v[c][j]
+        _bgemm(dO, qkv, dS, None, S, L, L, C, (C * L, 1, L), (C3 * L, L, 1), (L * L, L, 1), offB=2 * C * L)
+        # dV[c][j] = sum_i dO[c][i] P[i][j]
+        _bgemm(dO, P, dqkv, None, S, C, L, L, (C * L, L, 1), (L * L, L, 1), (C3 * L, L, 1), offC=2 * C * L)
+        _lib.call("vf_softmax_bwd", _ptr(P), _ptr(dS), _ptr(dS), S * L, L, _stream())
+        # dQ[c][i] = alpha sum_j k[c][j] dS[i][j]
+        _bgemm(qkv, dS, dqkv, None, S, C, L, L, (C3 * L, L, 1), (L * L, 1, L), (C3 * L, L, 1), alpha,
+               offA=C * L, offC=0)
+        # dK[c][j] = alpha sum_i q[c][i] dS[i][j]
+        _bgemm(qkv, dS, dqkv, None, S, C, L, L, (C3 * L, L, 1), (L * L, L, 1), (C3 * L, L, 1), alpha,
+               offA=0, offC=C * L)
+        return dqkv
+
+
+def attention(qkv):
+    return _AttentionFn.apply(qkv)
+
+
+class _ConcatFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        _check(a, b)
+        S, Ca, H, W = a.shape
+        Cb = b.shape[1]
+        out = torch.empty(S, Ca + Cb, H, W, device=a.device, dtype=torch.float32)
+        _lib.call("vf_concat_channels", _ptr(a), _ptr(b), _ptr(out), S, Ca * H * W, Cb * H * W, 0, _stream())
+        ctx.shapes = (a.shape, b.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dout = _c(dout)
+        sa, sb = ctx.shapes
+        da = torch.empty(sa, device=dout.device, dtype=torch.float32)
+        db = torch.empty(sb, device=dout.device, dtype=torch.float32)
+        _lib.call("vf_concat_channels", _ptr(da), _ptr(db), _ptr(dout), sa[0], da[0].numel(), db[0].numel(), 1,
+                  _stream())
+        return da, db
+
+
+def concat_channels(a, b):
+    return _ConcatFn.apply(a, b)
+
+
+# ---------------------------------------------------------------------------------------------
+# ViewFusion glue
+def view_offsets(view_count, device):
+    """view_count (list / CPU tensor / device tensor) -> (off int32 [B+1] on device, S, maxV).
+
+    A CPU-side view_count (what the reference's training loop produces, experiment.py:277-279)
+    needs no device sync; a device tensor costs one D2H copy, like the reference's .tolist().
+    """
+    if torch.is_tensor(view_count):
+        vc = view_count.detach().cpu().tolist()
+    else:
+        vc = [int(v) for v in view_count]
+    off = [0]
+    for v in vc:
+        if v < 1:
+            raise ValueError("every sample needs at least one conditioning view")
+        off.append(off[-1] + int(v))
+    t = torch.tensor(off, dtype=torch.int32)
+    if device.type == "cuda":
+        t = t.pin_memory().to(device, non_blocking=True)
+    return t, off[-1], max(vc)
+
+
+def gather_level(gammas, t, u=None):
+    """level[b] = gammas[t[b]]  or the training draw (g[t]-g[t-1])*u + g[t-1]."""
+    _check(gammas, u)
+    t = _c(t.to(torch.int64))
+    B = t.numel()
+    level = torch.empty(B, device=gammas.device, dtype=torch.float32)
+    _lib.call("vf_gather_level", _ptr(gammas), ctypes.c_void_p(t.data_ptr()), _ptr(u), _ptr(level), B, _stream())
+    return level
+
+
+def stack_views(y_cond, y_t, noise, level, angle, off, S, x=None, copy_cond=True):
+    """Ragged stacking (+ optional q_sample): -> x (S,6,H,W), level_s (S,1), angle_s (S,1)."""
+    y_cond, y_t = _c(y_cond), _c(y_t)
+    angle = _c(angle.reshape(-1).float())
+    _check(y_cond, y_t, noise, level, angle)
+    B, Nmax, _, H, W = y_cond.shape
+    if x is None:
+        x = torch.empty(S, 6, H, W, device=y_cond.device, dtype=torch.float32)
+    ls = torch.empty(S, 1, device=y_cond.device, dtype=torch.float32)
+    as_ = torch.empty(S, 1, device=y_cond.device, dtype=torch.float32)
+    _lib.call("vf_stack_views", _ptr(y_cond), _ptr(y_t), _ptr(noise), _ptr(level), _ptr(angle),
+              ctypes.c_void_p(off.data_ptr()), _ptr(x), _ptr(ls), _ptr(as_), B, Nmax, H * W, S, int(copy_cond),
+              _stream())
+    return x, ls, as_
+
+
+class _ComposeLossFn(torch.autograd.Function):
+    """MSE(target, compose(unet_out)) fused: softmax over each sample's views (or mean)."""
+
+    @staticmethod
+    def forward(ctx, out, target, off, B, weighting):
+        _check(out, target)
+        S, Cout, H, W = out.shape
+        nh = torch.empty(B, 3, H, W, device=out.device, dtype=torch.float32)
+        part = torch.empty(B * 64 + 1, device=out.device, dtype=torch.float32)
+        loss = part[B * 64:]
+        _lib.call("vf_compose_fwd", _ptr(out), ctypes.c_void_p(off.data_ptr()), _ptr(target), _ptr(nh), None,
+                  _ptr(part), _ptr(loss), B, Cout, H * W, 0, int(weighting), _stream())
+        ctx.save_for_backward(out, target, nh, off)
+        ctx.B, ctx.weighting = B, int(weighting)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, gloss):
+        out, target, nh, off = ctx.saved_tensors
+        S, Cout, H, W = out.shape
+        gloss = _c(gloss.reshape(1).float())
+        dout = torch.empty_like(out)
+        _lib.call("vf_compose_mse_bwd", _ptr(out), ctypes.c_void_p(off.data_ptr()), _ptr(target), _ptr(nh),
+                  _ptr(gloss), _ptr(dout), ctx.B, Cout, H * W, ctx.weighting, _stream())
+        return dout, None, None, None, None
+
+
+def compose_mse_loss(unet_out, target_noise, off, B, weighting):
+    return _ComposeLossFn.apply(unet_out, _c(target_noise), off, B, weighting)
+
+
+def compose(unet_out, off, B, max_views, weighting, want_weights=True):
+    """Inference compose: -> noise (B,3,H,W), weights (B,maxV,3,H,W) | None."""
+    _check(unet_out)
+    S, Cout, H, W = unet_out.shape
+    nh = torch.empty(B, 3, H, W, device=unet_out.device, dtype=torch.float32)
+    wts = None
+    if weighting and want_weights:
+        wts = torch.empty(B, max_views, 3, H, W, device=unet_out.device, dtype=torch.float32)
+    _lib.call("vf_compose_fwd", _ptr(unet_out), ctypes.c_void_p(off.data_ptr()), None, _ptr(nh), _ptr(wts), None,
+              None, B, Cout, H * W, max_views, int(weighting), _stream())
+    return nh, wts
+
+
+def p_sample_tail(unet_out, off, y_t, z, t, sched, B, max_views, weighting, clip=True, want_weights=True,
+                  want_mean=False):
+    """Fused compose -> y0_hat -> clamp -> posterior mean -> + z*sigma.
+    Returns (y_next, mean | None, weights | None)."""
+    _check(unet_out, y_t, z)
+    S, Cout, H, W = unet_out.shape
+    t = _c(t.to(torch.int64))
+    y_next = torch.empty_like(y_t)
+    mean = torch.empty_like(y_t) if want_mean else None
+    wts = None
+    if weighting and want_weights:
+        wts = torch.empty(B, max_views, 3, H, W, device=y_t.device, dtype=torch.float32)
+    _lib.call("vf_p_sample_tail", _ptr(unet_out), ctypes.c_void_p(off.data_ptr()), _ptr(y_t), _ptr(z),
+              ctypes.c_void_p(t.data_ptr()), _ptr(sched["sqrt_recip_gammas"]), _ptr(sched["sqrt_recipm1_gammas"]),
+              _ptr(sched["posterior_log_variance_clipped"]), _ptr(sched["posterior_mean_coef1"]),
+              _ptr(sched["posterior_mean_coef2"]), _ptr(y_next), _ptr(mean), _ptr(wts), B, Cout, H * W, max_views,
+              int(weighting), int(clip), _stream())
+    return y_next, mean, wts

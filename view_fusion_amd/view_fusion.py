@@ -1,0 +1,147 @@
+"""MI355X-native ViewFusion: host-side mirror of the reference `ViewFusion` module.
+
+Same constructor, `set_new_noise_schedule`, `forward(y_cond, view_count, angle, y_0=None,
+noise=None, generate=False)`, `generate`, `p_sample`, `p_mean_variance`, `q_sample`,
+`predict_start_from_noise`, `q_posterior` and the same six persistent schedule buffers as
+/root/reference/model/view_fusion.py:12-300 -- so `state_dict()` is interchangeable.
+
+What differs is underneath: the ragged view stacking + q_sample, the softmax-over-views
+compose + MSE (and its backward) and the reverse-step tail are single fused HIP kernels driven
+by a device prefix-sum of `view_count`; nothing on the path calls `.tolist()` / `.item()` when
+`view_count` is handed over as a CPU tensor or list (as the reference's training loop does).
+
+Extras (default None = reference behaviour): `forward(..., t=, u=)` and
+`generate(..., z_seq=)` inject the random draws so that runs can be compared bit-for-bit
+against the CPU oracle; `sample()` is an alias of `generate()`.
+"""
+import torch
+from torch import nn
+
+from . import schedule as _schedule
+
+
+class ViewFusion(nn.Module):
+    def __init__(self, denoise_fn, beta_schedule, weighting_train=True, weighting_inference=True, **kwargs):
+        super().__init__(**kwargs)
+        self.denoise_fn = denoise_fn
+        self.beta_schedule = beta_schedule
+        self.weighting_train = weighting_train
+        self.weighting_inference = weighting_inference
+
+    # -- schedule ---------------------------------------------------------------------------
+    def set_new_noise_schedule(self, device=torch.device("cuda"), phase="train"):
+        betas = _schedule.make_beta_schedule(**self.beta_schedule[phase])
+        self.num_timesteps = int(betas.shape[0])
+        for name, val in _schedule.schedule_tensors(betas, device).items():
+            if name in self._buffers:
+                self._buffers[name] = val
+            else:
+                self.register_buffer(name, val)
+
+    def _sched(self):
+        return {k: getattr(self, k) for k in _schedule.BUFFER_NAMES}
+
+    @staticmethod
+    def _at(table, t, ndim=4):
+        return table.gather(-1, t).reshape(t.shape[0], *((1,) * (ndim - 1)))
+
+    # -- small API-compat helpers (not on the fused hot path) ---------------------------------
+    def predict_start_from_noise(self, y_t, t, noise):
+        return self._at(self.sqrt_recip_gammas, t) * y_t - self._at(self.sqrt_recipm1_gammas, t) * noise
+
+    def q_posterior(self, y_0_hat, y_t, t):
+        mean = self._at(self.posterior_mean_coef1, t) * y_0_hat + self._at(self.posterior_mean_coef2, t) * y_t
+        return mean, self._at(self.posterior_log_variance_clipped, t)
+
+    def q_sample(self, y_0, sample_gammas, noise=None):
+        if noise is None:
+            noise = torch.randn_like(y_0)
+        return sample_gammas.sqrt() * y_0 + (1 - sample_gammas).sqrt() * noise
+
+    # -- reverse process ---------------------------------------------------------------------
+    def _denoise(self, y_t, y_cond, angle, t, off, S, x=None, copy_cond=True):
+        from . import ops
+        level = ops.gather_level(self.gammas, t)
+        x, level_s, angle_s = ops.stack_views(y_cond, y_t, None, level, angle, off, S, x=x, copy_cond=copy_cond)
+        return x, self.denoise_fn(x, angle_s, level_s)
+
+    def p_mean_variance(self, y_t, y_cond, view_count, angle, t, clip_denoised: bool):
+        from . import ops
+        off, S, max_v = ops.view_offsets(view_count, y_t.device)
+        _, out = self._denoise(y_t, y_cond, angle, t, off, S)
+        w_on = bool(self.weighting_inference)
+        _, mean, weights = ops.p_sample_tail(out, off, y_t, None, t, self._sched(), y_t.shape[0], max_v, w_on,
+                                             clip=clip_denoised, want_mean=True)
+        logits = out[:, 3:, ...] if w_on else None
+        return mean, self._at(self.posterior_log_variance_clipped, t), logits, weights
+
+    @torch.no_grad()
+    def p_sample(self, y_t, y_cond, view_count, angle, t, clip_denoised=True, z=None):
+        from . import ops
+        off, S, max_v = ops.view_offsets(view_count, y_t.device)
+        _, out = self._denoise(y_t, y_cond, angle, t, off, S)
+        if z is None:
+            z = torch.randn_like(y_t) if bool((t > 0).any()) else None
+        elif not bool((t > 0).any()):
+            z = None
+        w_on = bool(self.weighting_inference)
+        y, _, weights = ops.p_sample_tail(out, off, y_t, z, t, self._sched(), y_t.shape[0], max_v, w_on,
+                                          clip=clip_denoised)
+        return y, (out[:, 3:, ...] if w_on else None), weights
+
+    @torch.no_grad()
+    def generate(self, y_cond, view_count, angle, y_t=None, sample_num=8, z_seq=None):
+        from . import ops
+        b = y_cond.shape[0]
+        assert self.num_timesteps > sample_num, "num_timesteps must greater than sample_num"
+        every = self.num_timesteps // sample_num
+        if y_t is None:
+            y_t = torch.randn_like(y_cond[:, :1, :3, ...]).squeeze(dim=1)
+        y_t = y_t.contiguous()
+        off, S, max_v = ops.view_offsets(view_count, y_t.device)
+        w_on = bool(self.weighting_inference)
+        sched = self._sched()
+        ret, logit_arr, weight_arr = [y_t], [], []
+        x = None
+        for i in reversed(range(self.num_timesteps)):
+            t = torch.full((b,), i, device=y_t.device, dtype=torch.long)
+            stash = i % every == 0
+            # the conditioning half of the stacked input never changes: copy it once
+            x, out = self._denoise(y_t, y_cond, angle, t, off, S, x=x, copy_cond=x is None)
+            z = None
+            if i > 0:
+                z = z_seq[i] if z_seq is not None else torch.randn_like(y_t)
+            y_t, _, weights = ops.p_sample_tail(out, off, y_t, z, t, sched, b, max_v, w_on,
+                                                want_weights=stash)
+            if stash:
+                ret.append(y_t)
+                logit_arr.append(out[:, 3:, ...].clone() if w_on else None)
+                weight_arr.append(weights)
+        ret = torch.stack(ret, dim=1)
+        samples = ret[:, -1, ...]
+        if w_on:
+            logit_arr = torch.stack(logit_arr, dim=1)
+            weight_arr = torch.stack(weight_arr, dim=1)
+        return y_t, ret, logit_arr, weight_arr, samples
+
+    sample = generate
+
+    # -- training ---------------------------------------------------------------------------
+    def forward(self, y_cond, view_count, angle, y_0=None, noise=None, generate=False, t=None, u=None):
+        if generate:                      # generate() wrapped in forward for DDP, as in the reference
+            return self.generate(y_cond, view_count, angle)
+        from . import ops
+        b = y_0.shape[0]
+        dev = y_0.device
+        # same draw order as the reference: t, u, noise
+        if t is None:
+            t = torch.randint(1, self.num_timesteps, (b,), device=dev).long()
+        if u is None:
+            u = torch.rand((b, 1), device=dev)
+        if noise is None:
+            noise = torch.randn_like(y_0)
+        level = ops.gather_level(self.gammas, t, u.reshape(-1).contiguous())
+        off, S, _ = ops.view_offsets(view_count, dev)
+        x, level_s, angle_s = ops.stack_views(y_cond, y_0.contiguous(), noise.contiguous(), level, angle, off, S)
+        out = self.denoise_fn(x, angle_s, level_s)
+        return ops.compose_mse_loss(out, noise, off, b, bool(self.weighting_train))
