@@ -1,0 +1,99 @@
+"""Synthetic-data training / sampling harness for the ViewFusion hot path.
+
+Mirrors the reference's iteration semantics (experiment.py:90-120 model/optimizer/DDP setup,
+:265-293 the step: set LR -> zero_grad -> model(...) -> backward -> Adam.step) without its
+dataset, wandb and checkpoint plumbing.  One process per GPU; gradients are all-reduced by
+DistributedDataParallel over RCCL (backend "nccl" on ROCm).
+"""
+import math
+import os
+
+import torch
+import torch.distributed as dist
+from torch.nn.parallel import DistributedDataParallel
+
+from .unet import UNet
+from .view_fusion import ViewFusion
+
+SMALL_UNET = dict(in_channel=6, out_channel=6, inner_channel=64, norm_groups=32, channel_mults=(1, 2, 3, 5),
+                  attn_res=(16,), res_blocks=3, image_size=64)          # configs/small-v100.yaml:19-30
+BETA_SCHEDULE = {
+    "train": dict(schedule="linear", num_timesteps=2000, linear_start=1e-6, linear_end=1e-2),
+    "test": dict(schedule="linear", num_timesteps=1000, linear_start=1e-4, linear_end=0.09),
+}                                                                        # configs/small-v100.yaml:9-18
+
+
+class LrScheduler:
+    """Linear warm-up to `peak_lr` over `peak_it`, then peak * decay_rate**(dt/decay_it)
+    (reference utils/schedulers.py, constants from experiment.py:112-117)."""
+
+    def __init__(self, peak_lr=1e-4, peak_it=2500, decay_rate=0.16, decay_it=4000000):
+        self.peak_lr, self.peak_it, self.decay_rate, self.decay_it = peak_lr, peak_it, decay_rate, decay_it
+
+    def get_cur_lr(self, it):
+        if it < self.peak_it:
+            return self.peak_lr * (it / self.peak_it)
+        return self.peak_lr * self.decay_rate ** ((it - self.peak_it) / self.decay_it)
+
+
+def init_distributed():
+    """(rank, local_rank, world).  torchrun env -> RCCL process group; else single process."""
+    if "WORLD_SIZE" not in os.environ or int(os.environ["WORLD_SIZE"]) <= 1:
+        return 0, 0, 1
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        dist.init_process_group(backend="gloo")
+    return dist.get_rank(), local_rank, dist.get_world_size()
+
+
+def synthetic_batch(B, N, hw, device, seed=0, ragged=False):
+    """NMR-shaped random batch (data/nmr_dataset.py:10-52): images in [0,1], angle = 2pi/24*k."""
+    g = torch.Generator().manual_seed(seed)
+    y_0 = torch.rand(B, 3, hw, hw, generator=g)
+    y_cond = torch.rand(B, N, 3, hw, hw, generator=g)
+    angle = 2 * math.pi / 24 * torch.randint(0, 24, (B, 1), generator=g).float()
+    view_count = torch.randint(1, N + 1, (B,), generator=g) if ragged else torch.full((B,), N)
+    return dict(y_0=y_0.to(device), y_cond=y_cond.to(device), angle=angle.to(device), view_count=view_count)
+
+
+def build_model(unet_params=None, beta_schedule=None, device="cuda", phase="train", weighting=True, seed=0):
+    torch.manual_seed(seed)
+    net = UNet(**(unet_params or SMALL_UNET))
+    vf = ViewFusion(net, beta_schedule or BETA_SCHEDULE, weighting, weighting).to(device)
+    vf.set_new_noise_schedule(device=torch.device(device), phase=phase)
+    return vf
+
+
+class Trainer:
+    def __init__(self, model, world=1, local_rank=0, lr_warmup=2500, decay_it=4000000, bucket_cap_mb=32):
+        self.module = model
+        self.model = model
+        if world > 1:
+            kw = dict(broadcast_buffers=False, gradient_as_bucket_view=True, bucket_cap_mb=bucket_cap_mb)
+            if next(model.parameters()).is_cuda:
+                kw.update(device_ids=[local_rank], output_device=local_rank)
+            self.model = DistributedDataParallel(model, **kw)
+        self.sched = LrScheduler(peak_lr=1e-4, peak_it=lr_warmup, decay_it=decay_it, decay_rate=0.16)
+        params = list(model.parameters())
+        try:
+            self.opt = torch.optim.Adam(params, lr=self.sched.get_cur_lr(0), fused=params[0].is_cuda)
+        except (RuntimeError, TypeError):
+            self.opt = torch.optim.Adam(params, lr=self.sched.get_cur_lr(0))
+        self.it = -1
+
+    def step(self, batch, **extra):
+        """One reference iteration; returns the (device) loss tensor, no host sync."""
+        self.it += 1
+        lr = self.sched.get_cur_lr(self.it)
+        for gparam in self.opt.param_groups:
+            gparam["lr"] = lr
+        self.model.train()
+        self.opt.zero_grad()
+        loss = self.model(y_0=batch["y_0"], y_cond=batch["y_cond"], view_count=batch["view_count"],
+                          angle=batch["angle"], **extra)
+        loss.backward()
+        self.opt.step()
+        return loss
