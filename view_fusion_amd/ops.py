@@ -38,6 +38,23 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+# Optional per-launch timing of the contraction kernels (bench.py roofline leg).  When
+# KERNEL_LOG is a list, every conv launch is bracketed by HIP events recorded on the stream the
+# kernel is launched on, and (kind, algorithmic flops, start, end) is appended.
+KERNEL_LOG = None
+
+
+def _launch(kind, flops, name, *args):
+    if KERNEL_LOG is None:
+        _lib.call(name, *args)
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    _lib.call(name, *args)
+    e1.record()
+    KERNEL_LOG.append((kind, flops, e0, e1))
+
+
 # ---------------------------------------------------------------------------------------------
 # workspace shared by all wgrad launches on a device (stream ordered, grown on demand)
 _ws = {}
@@ -119,8 +136,10 @@ class _Conv2dFn(torch.autograd.Function):
         m = _MODES[mode]
         H, W = (Hi // 2, Wi // 2) if m == 1 else ((Hi * 2, Wi * 2) if m == 2 else (Hi, Wi))
         y = torch.empty(S, Cout, H, W, device=x.device, dtype=torch.float32)
-        _lib.call("vf_conv_fwd", _ptr(x), _ptr(wf), _ptr(bias), _ptr(view_bias), _ptr(residual), _ptr(y), S, Cin,
-                  Cout, H, W, KS, m, _stream())
+        flops = 2.0 * S * Cout * Cin * KS * KS * H * W
+        _launch("conv_fwd", flops, "vf_conv_fwd", _ptr(x), _ptr(wf), _ptr(bias), _ptr(view_bias), _ptr(residual),
+                _ptr(y), S, Cin, Cout, H, W, KS, m, _stream())
+        ctx.flops = flops
         ctx.save_for_backward(x)
         ctx.wb, ctx.m, ctx.KS, ctx.Cout = wb, m, KS, Cout
         ctx.has = (bias is not None, view_bias is not None, residual is not None)
@@ -138,24 +157,24 @@ class _Conv2dFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if m == 0:
                 dx = torch.empty_like(x)
-                _lib.call("vf_conv_fwd", _ptr(dy), _ptr(ctx.wb), None, None, None, _ptr(dx), S, Cout, Cin, H, W,
-                          KS, 0, st)
+                _launch("conv_dgrad", ctx.flops, "vf_conv_fwd", _ptr(dy), _ptr(ctx.wb), None, None, None, _ptr(dx),
+                        S, Cout, Cin, H, W, KS, 0, st)
             elif m == 1:      # stride-2 conv: transposed conv = conv over the zero-dilated dy
                 dx = torch.empty_like(x)
-                _lib.call("vf_conv_fwd", _ptr(dy), _ptr(ctx.wb), None, None, None, _ptr(dx), S, Cout, Cin, Hi, Wi,
-                          KS, 3, st)
+                _launch("conv_dgrad", ctx.flops, "vf_conv_fwd", _ptr(dy), _ptr(ctx.wb), None, None, None, _ptr(dx),
+                        S, Cout, Cin, Hi, Wi, KS, 3, st)
             else:             # upsample + conv: dgrad at the upsampled size, then 2x2 sum-pool
                 dup = torch.empty(S, Cin, H, W, device=x.device, dtype=torch.float32)
-                _lib.call("vf_conv_fwd", _ptr(dy), _ptr(ctx.wb), None, None, None, _ptr(dup), S, Cout, Cin, H, W,
-                          KS, 0, st)
+                _launch("conv_dgrad", ctx.flops, "vf_conv_fwd", _ptr(dy), _ptr(ctx.wb), None, None, None, _ptr(dup),
+                        S, Cout, Cin, H, W, KS, 0, st)
                 dx = torch.empty_like(x)
                 _lib.call("vf_sumpool2", _ptr(dup), _ptr(dx), dx.numel(), Wi, st)
         if ctx.needs_input_grad[1]:
             need = _lib.load().vf_conv_wgrad_ws_floats(S, Cin, Cout, H, W, KS)
             ws = _workspace(x.device, need)
             dw = torch.empty(Cout, Cin, KS, KS, device=x.device, dtype=torch.float32)
-            _lib.call("vf_conv_wgrad", _ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), ws.numel(), S, Cin, Cout, H, W, KS, m,
-                      st)
+            _launch("conv_wgrad", ctx.flops, "vf_conv_wgrad", _ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), ws.numel(), S,
+                    Cin, Cout, H, W, KS, m, st)
         hb, hv, hr = ctx.has
         if (hb and ctx.needs_input_grad[2]) or (hv and ctx.needs_input_grad[3]):
             rs = torch.empty(S, Cout, device=x.device, dtype=torch.float32)
