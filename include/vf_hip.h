@@ -24,7 +24,8 @@ int vf_gn_bwd(const float* x, const float* gamma, const float* beta, const float
               const float* dy, float* dx, float* dgamma_part, float* dbeta_part, int S, int C, int HW, int groups,
               int silu, void* stream);
 int vf_rowsum(const float* x, float* out /*[rows]*/, int rows, int len, void* stream);
-int vf_colsum(const float* part /*[S][C]*/, float* out /*[C]*/, int S, int C, void* stream);
+int vf_colsum(const float* part /*[batch][S][C]*/, float* out /*[batch][C]*/, int batch, int S, int C,
+              void* stream);
 
 /* ---- convolution : nn.Conv2d 3x3 / 1x1, nn.Upsample+conv, stride-2 conv,
  *      unet.py:42,189,198,214,238,255,256 (+ FeatureWiseAffine add :160-177, residual add :245,277) ---- */

@@ -1,0 +1,74 @@
+"""World-size-2 CPU (gloo) test of the data-parallel harness: the Trainer's DDP wrapping,
+per-rank shards and the gradient all-reduce (mean) give the same update as one process on the
+concatenated batch.  The HIP model cannot run on CPU (no fallback by design), so a small
+stand-in module with the ViewFusion.forward signature takes its place; what is under test is
+the harness (view_fusion_amd.train), which is device-agnostic.  RCCL itself only runs on the
+GPU box (bench.py --gpus N)."""
+import os
+import socket
+import sys
+
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class StandIn(torch.nn.Module):
+    """Same call signature as ViewFusion.forward; loss = per-sample MSE of a tiny conv net."""
+
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(0)
+        self.net = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.Tanh(),
+                                       torch.nn.Conv2d(8, 3, 3, padding=1))
+
+    def forward(self, y_cond, view_count, angle, y_0=None, noise=None, generate=False):
+        pred = self.net(y_cond.mean(dim=1)) * angle.reshape(-1, 1, 1, 1).cos()
+        return torch.nn.functional.mse_loss(pred, y_0)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
+                      WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    from view_fusion_amd import train
+    r, lr, w = train.init_distributed()
+    assert (r, w) == (rank, world)
+    tr = train.Trainer(StandIn(), world=w, local_rank=lr, lr_warmup=1)
+    tr.it = 0                                   # lr(1) = peak
+    batch = train.synthetic_batch(4, 3, 8, "cpu", seed=rank)
+    tr.step(batch)
+    out[rank] = [p.detach().clone() for p in tr.module.parameters()]
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_gloo_matches_single_process_on_the_global_batch():
+    sys.path.insert(0, ROOT)
+    from view_fusion_amd import train
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    # replicas stay in lock-step
+    for a, b in zip(out[0], out[1]):
+        assert torch.equal(a, b)
+    # single process on the concatenation of the two shards
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        os.environ.pop(k, None)
+    tr = train.Trainer(StandIn(), world=1, lr_warmup=1)
+    tr.it = 0
+    shards = [train.synthetic_batch(4, 3, 8, "cpu", seed=r) for r in range(world)]
+    batch = {k: torch.cat([s[k] for s in shards]) for k in shards[0]}
+    tr.step(batch)
+    for a, b in zip(out[0], tr.module.parameters()):
+        assert torch.allclose(a, b.detach(), rtol=1e-5, atol=1e-7)

@@ -25,6 +25,7 @@ namespace {
 
 constexpr int TPIX = 128;  // output pixels per workgroup tile
 constexpr int TCO = 64;    // output channels per workgroup tile
+constexpr int WGRAD_TARGET_WGS = 512;  // split-K slices are sized for ~2 workgroups per CU
 
 template <int KS, int LOGW, int MODE>
 struct Geo {
@@ -218,7 +219,7 @@ struct WgradArgs {
 };
 
 template <int KS, int LOGW, int MODE>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
     using G = Geo<KS, LOGW, MODE>;
     constexpr int NT = KS * KS;
     constexpr int TCI = 32;
@@ -228,8 +229,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     constexpr int ND4 = TCO * (TPIX / 4);
     constexpr int OHW = G::HW;
 
-    __shared__ float dyl[TCO * DYS];
-    __shared__ float xl[TCI * PSO];
+    constexpr int LDSF = TCO * DYS + TCI * PSO;
+    __shared__ float lds[LDSF];                   // one array: dY tile | input patch | k-half reduce
+    float* const dyl = lds;
+    float* const xl = lds + TCO * DYS;
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int cw = wid & 1, kq = wid >> 1;
@@ -287,7 +290,28 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
         }
     }
 
-    const int slab = blockIdx.z * 2 + kq;
+    // the two pixel halves (kq) of each co-half are summed through LDS, in passes of NTP taps
+    constexpr int NTP = NT > 1 ? (NT + 1) / 2 : 1;
+    static_assert(2 * NTP * 16 * 64 <= LDSF, "k-half reduce buffer does not fit");
+#pragma unroll
+    for (int t0 = 0; t0 < NT; t0 += NTP) {
+        __syncthreads();
+        if (kq == 1) {
+#pragma unroll
+            for (int t = t0; t < (t0 + NTP < NT ? t0 + NTP : NT); ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) lds[((cw * NTP + (t - t0)) * 16 + r) * 64 + lane] = acc[t][r];
+        }
+        __syncthreads();
+        if (kq == 0) {
+#pragma unroll
+            for (int t = t0; t < (t0 + NTP < NT ? t0 + NTP : NT); ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] += lds[((cw * NTP + (t - t0)) * 16 + r) * 64 + lane];
+        }
+    }
+    if (kq != 0) return;
+    const int slab = blockIdx.z;
 #pragma unroll
     for (int tap = 0; tap < NT; ++tap) {
 #pragma unroll
@@ -360,16 +384,16 @@ int launch_wgrad(WgradArgs a, float* dw, size_t ws_floats, hipStream_t st) {
     a.ntiles = G::IM > 1 ? (a.S + G::IM - 1) / G::IM : a.S * G::TPI;
     const int nco = a.CoutP / TCO, nci = a.CinQ / 32;
     const size_t slab_floats = (size_t)NT * a.CoutP * a.CinQ;
-    int z = (1024 + nco * nci - 1) / (nco * nci);
+    int z = (WGRAD_TARGET_WGS + nco * nci - 1) / (nco * nci);
     if (z > a.ntiles) z = a.ntiles;
-    const size_t zmax = ws_floats / (2 * slab_floats);
+    const size_t zmax = ws_floats / slab_floats;
     if (zmax < 1) return (int)hipErrorInvalidValue;
     if ((size_t)z > zmax) z = (int)zmax;
     a.tiles_per_slice = (a.ntiles + z - 1) / z;
     z = (a.ntiles + a.tiles_per_slice - 1) / a.tiles_per_slice;
     hipLaunchKernelGGL((conv_wgrad_kernel<KS, LOGW, MODE>), dim3(nco, nci, z), dim3(256), 0, st, a);
     const int total = NT * a.Cout * a.Cin;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, a.ws, dw, 2 * z, NT,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, a.ws, dw, z, NT,
                        a.Cout, a.Cin, a.CoutP, a.CinQ);
     VF_RETURN_LAST_ERROR();
 }
@@ -435,15 +459,15 @@ int vf_conv_fwd(const float* x, const float* w_packed, const float* bias, const 
 }
 
 // Workspace floats needed by vf_conv_wgrad for the preferred split (a smaller workspace is
-// accepted down to 2 slabs and just reduces the split-K factor).
+// accepted down to 1 slab and just reduces the split-K factor).
 long vf_conv_wgrad_ws_floats(int S, int Cin, int Cout, int H, int W, int KS) {
     const long slab = (long)KS * KS * round_up(Cout, TCO) * round_up(Cin, 32);
     const int nco = round_up(Cout, TCO) / TCO, nci = round_up(Cin, 32) / 32;
-    long z = (1024 + nco * nci - 1) / (nco * nci);
+    long z = (WGRAD_TARGET_WGS + nco * nci - 1) / (nco * nci);
     long ntiles = ((long)S * H * W + TPIX - 1) / TPIX;
     if (z > ntiles) z = ntiles;
     if (z < 1) z = 1;
-    return 2 * z * slab;
+    return z * slab;
 }
 
 // dw[Cout][Cin][KS][KS] = sum_{s,p} dy[s][co][p] * x_as_seen_by_the_conv[s][ci][p (+) tap]

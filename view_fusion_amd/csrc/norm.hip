@@ -185,13 +185,20 @@ __global__ __launch_bounds__(256) void rowsum_kernel(const float* __restrict__ x
     if (lane == 0) out[row] = a;
 }
 
-// out[c] = sum_s part[s][c]   (deterministic, fixed order)
-__global__ void colsum_kernel(const float* __restrict__ part, float* __restrict__ out, int S, int C) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// out[b][c] = sum_s part[b][s][c]   (deterministic: fixed 4-way row split + fixed tree)
+// block = 64 columns x 4 row groups; grid (ceil(C/64), batch)
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                     int S, int C) {
+    __shared__ float red[4][64];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
+    const float* p = part + (size_t)blockIdx.y * S * C;
     float a = 0.f;
-    for (int s = 0; s < S; ++s) a += part[(size_t)s * C + c];
-    out[c] = a;
+    if (c < C)
+        for (int s = ry; s < S; s += 4) a += p[(size_t)s * C + c];
+    red[ry][cx] = a;
+    __syncthreads();
+    if (ry == 0 && c < C) out[(size_t)blockIdx.y * C + c] = (red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]);
 }
 
 template <int NV, int NT>
@@ -254,9 +261,10 @@ int vf_rowsum(const float* x, float* out, int rows, int len, void* stream) {
     VF_RETURN_LAST_ERROR();
 }
 
-int vf_colsum(const float* part, float* out, int S, int C, void* stream) {
-    if (C <= 0) return 0;
-    hipLaunchKernelGGL(colsum_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, part, out, S, C);
+int vf_colsum(const float* part, float* out, int batch, int S, int C, void* stream) {
+    if (C <= 0 || batch <= 0) return 0;
+    hipLaunchKernelGGL(colsum_kernel, dim3((C + 63) / 64, batch), dim3(256), 0, (hipStream_t)stream, part, out, S,
+                       C);
     VF_RETURN_LAST_ERROR();
 }
 

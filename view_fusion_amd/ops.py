@@ -93,8 +93,7 @@ class _GroupNormFn(torch.autograd.Function):
         _lib.call("vf_gn_bwd", _ptr(x), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd), _ptr(dy), _ptr(dx),
                   _ptr(parts[0]), _ptr(parts[1]), S, C, H * W, ctx.groups, ctx.silu, _stream())
         dgb = torch.empty(2, C, device=x.device, dtype=torch.float32)
-        _lib.call("vf_colsum", _ptr(parts[0]), _ptr(dgb[0]), S, C, _stream())
-        _lib.call("vf_colsum", _ptr(parts[1]), _ptr(dgb[1]), S, C, _stream())
+        _lib.call("vf_colsum", _ptr(parts), _ptr(dgb), 2, S, C, _stream())
         return dx, dgb[0], dgb[1], None, None
 
 
@@ -183,7 +182,7 @@ class _Conv2dFn(torch.autograd.Function):
                 dvb = rs
             if hb and ctx.needs_input_grad[2]:
                 db = torch.empty(Cout, device=x.device, dtype=torch.float32)
-                _lib.call("vf_colsum", _ptr(rs), _ptr(db), S, Cout, st)
+                _lib.call("vf_colsum", _ptr(rs), _ptr(db), 1, S, Cout, st)
         if hr and ctx.needs_input_grad[4]:
             dres = dy
         return dx, dw, db, dvb, dres, None, None
@@ -230,7 +229,7 @@ class _LinearFn(torch.autograd.Function):
             _bgemm(dy, x, dw, None, 1, O, I, S, (0, 1, O), (0, I, 1), (0, I, 1))
         if ctx.needs_input_grad[2]:
             db = torch.empty(O, device=x.device, dtype=torch.float32)
-            _lib.call("vf_colsum", _ptr(dy), _ptr(db), S, O, _stream())
+            _lib.call("vf_colsum", _ptr(dy), _ptr(db), 1, S, O, _stream())
         return dx, dw, db
 
 
