@@ -75,7 +75,7 @@ def roofline(trainer, batch, steps=2):
     torch.cuda.synchronize()
     log, ops.KERNEL_LOG = ops.KERNEL_LOG, None
     agg = {}
-    for kind, flops, e0, e1 in log:
+    for kind, flops, e0, e1, _tag in log:
         a = agg.setdefault(kind, [0.0, 0.0, 0])
         a[0] += flops
         a[1] += e0.elapsed_time(e1) * 1e-3

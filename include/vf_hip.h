@@ -47,6 +47,9 @@ int vf_sumpool2(const float* x, float* y, long n_out, int Wo, void* stream);
 int vf_bgemm(const float* A, const float* B, float* C, const float* bias /*[N]|NULL*/, int batch, int M, int N,
              int K, long sAb, long sAm, long sAk, long sBb, long sBk, long sBn, long sCb, long sCm, long sCn,
              float alpha, float beta, void* stream);
+/* fused attention forward (unet.py:258-277 core): qkv [S][3C][L] -> out [S][C][L]; optionally
+ * P [S][L][L] (softmax probabilities, saved for backward).  L in {64,256}, C % 32 == 0. */
+int vf_attention_fwd(const float* qkv, float* out, float* P /*|NULL*/, int S, int C, int L, void* stream);
 int vf_softmax_fwd(const float* x, float* y, int rows, int cols, void* stream);
 int vf_softmax_bwd(const float* y, const float* dy, float* dx, int rows, int cols, void* stream);
 

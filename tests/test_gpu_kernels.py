@@ -151,6 +151,20 @@ def test_attention_fwd_bwd(dev, C, H):
     assert rel(qg.grad, qc.grad) < 5e-5
 
 
+@pytest.mark.parametrize("C,H", [(192, 16), (320, 8), (32, 32)])
+def test_attention_inference_path(dev, C, H):
+    """no-grad call: fused kernel without the probability write (L=64/256) / generic path (L=1024)."""
+    from view_fusion_amd import ops
+    S, L = 2, H * H
+    qkv = rnd(S, 3 * C, H, H, seed=3) * 2
+    q, k, v = qkv.reshape(S, 3, C, L).unbind(1)
+    p = torch.softmax(torch.bmm(q.transpose(1, 2), k) / math.sqrt(C), -1)
+    oc = torch.bmm(v, p.transpose(1, 2)).reshape(S, C, H, H)
+    with torch.no_grad():
+        og = ops.attention(qkv.to(dev))
+    assert rel(og, oc) < 2e-5
+
+
 def test_concat(dev):
     from view_fusion_amd import ops
     a, b = rnd(3, 64, 8, 8, seed=1), rnd(3, 32, 8, 8, seed=2)

@@ -11,7 +11,7 @@
 
 namespace {
 
-constexpr int BM = 64, BN = 64, BK = 16, LDT = 65;
+constexpr int BM = 64, BN = 64, BK = 32, LDT = 65;
 
 struct GemmArgs {
     const float* A;
@@ -37,16 +37,16 @@ __global__ __launch_bounds__(256) void bgemm_kernel(GemmArgs g) {
     for (int k0 = 0; k0 < g.K; k0 += BK) {
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 8; ++i) {
             int m, k;
             if (a_m_fast) { m = tid & 63; k = (tid >> 6) + 4 * i; }
-            else          { k = tid & 15; m = (tid >> 4) + 16 * i; }
+            else          { k = tid & 31; m = (tid >> 5) + 8 * i; }
             float v = 0.f;
             if (m0 + m < g.M && k0 + k < g.K) v = A[(long)(m0 + m) * g.sAm + (long)(k0 + k) * g.sAk];
             Al[k * LDT + m] = v;
             int n, kb;
             if (b_n_fast) { n = tid & 63; kb = (tid >> 6) + 4 * i; }
-            else          { kb = tid & 15; n = (tid >> 4) + 16 * i; }
+            else          { kb = tid & 31; n = (tid >> 5) + 8 * i; }
             float u = 0.f;
             if (n0 + n < g.N && k0 + kb < g.K) u = B[(long)(k0 + kb) * g.sBk + (long)(n0 + n) * g.sBn];
             Bl[kb * LDT + n] = u;

@@ -44,7 +44,7 @@ def _c(t):
 KERNEL_LOG = None
 
 
-def _launch(kind, flops, name, *args):
+def _launch(kind, flops, name, *args, tag=None):
     if KERNEL_LOG is None:
         _lib.call(name, *args)
         return
@@ -52,7 +52,7 @@ def _launch(kind, flops, name, *args):
     e0.record()
     _lib.call(name, *args)
     e1.record()
-    KERNEL_LOG.append((kind, flops, e0, e1))
+    KERNEL_LOG.append((kind, flops, e0, e1, tag))
 
 
 # ---------------------------------------------------------------------------------------------
@@ -103,12 +103,17 @@ def group_norm(x, weight, bias, groups, silu):
 
 
 # ---------------------------------------------------------------------------------------------
-def _packed(layer):
-    """Packed forward / dgrad weights of a conv layer, re-packed when the weight changes."""
+def _packed(layer, force):
+    """Packed forward / dgrad weights of a conv layer.
+
+    Inference: cached, keyed on the parameter's version counter (load_state_dict / copy_ bump it).
+    Training (`force`): re-packed on every forward -- fused optimizers (torch._fused_adam_) update
+    parameters WITHOUT bumping `_version`, so the counter cannot be trusted across steps.
+    """
     w = layer.weight
     cache = getattr(layer, "_vf_pack", None)
     key = (w._version, w.data_ptr(), w.device)
-    if cache is not None and cache[0] == key:
+    if not force and cache is not None and cache[0] == key:
         return cache[1], cache[2]
     Cout, Cin, KS, _ = w.shape
     nf, nb = ctypes.c_long(), ctypes.c_long()
@@ -129,7 +134,7 @@ class _Conv2dFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, view_bias, residual, layer, mode):
         _check(x, bias, view_bias, residual)
-        wf, wb = _packed(layer)
+        wf, wb = _packed(layer, force=ctx.needs_input_grad[1])
         S, Cin, Hi, Wi = x.shape
         Cout, _, KS, _ = weight.shape
         m = _MODES[mode]
@@ -137,8 +142,8 @@ class _Conv2dFn(torch.autograd.Function):
         y = torch.empty(S, Cout, H, W, device=x.device, dtype=torch.float32)
         flops = 2.0 * S * Cout * Cin * KS * KS * H * W
         _launch("conv_fwd", flops, "vf_conv_fwd", _ptr(x), _ptr(wf), _ptr(bias), _ptr(view_bias), _ptr(residual),
-                _ptr(y), S, Cin, Cout, H, W, KS, m, _stream())
-        ctx.flops = flops
+                _ptr(y), S, Cin, Cout, H, W, KS, m, _stream(), tag=(Cin, Cout, H, KS, m))
+        ctx.flops, ctx.tag = flops, (Cin, Cout, H, KS, m)
         ctx.save_for_backward(x)
         ctx.wb, ctx.m, ctx.KS, ctx.Cout = wb, m, KS, Cout
         ctx.has = (bias is not None, view_bias is not None, residual is not None)
@@ -157,15 +162,15 @@ class _Conv2dFn(torch.autograd.Function):
             if m == 0:
                 dx = torch.empty_like(x)
                 _launch("conv_dgrad", ctx.flops, "vf_conv_fwd", _ptr(dy), _ptr(ctx.wb), None, None, None, _ptr(dx),
-                        S, Cout, Cin, H, W, KS, 0, st)
+                        S, Cout, Cin, H, W, KS, 0, st, tag=ctx.tag)
             elif m == 1:      # stride-2 conv: transposed conv = conv over the zero-dilated dy
                 dx = torch.empty_like(x)
                 _launch("conv_dgrad", ctx.flops, "vf_conv_fwd", _ptr(dy), _ptr(ctx.wb), None, None, None, _ptr(dx),
-                        S, Cout, Cin, Hi, Wi, KS, 3, st)
+                        S, Cout, Cin, Hi, Wi, KS, 3, st, tag=ctx.tag)
             else:             # upsample + conv: dgrad at the upsampled size, then 2x2 sum-pool
                 dup = torch.empty(S, Cin, H, W, device=x.device, dtype=torch.float32)
                 _launch("conv_dgrad", ctx.flops, "vf_conv_fwd", _ptr(dy), _ptr(ctx.wb), None, None, None, _ptr(dup),
-                        S, Cout, Cin, H, W, KS, 0, st)
+                        S, Cout, Cin, H, W, KS, 0, st, tag=ctx.tag)
                 dx = torch.empty_like(x)
                 _lib.call("vf_sumpool2", _ptr(dup), _ptr(dx), dx.numel(), Wi, st)
         if ctx.needs_input_grad[1]:
@@ -173,7 +178,7 @@ class _Conv2dFn(torch.autograd.Function):
             ws = _workspace(x.device, need)
             dw = torch.empty(Cout, Cin, KS, KS, device=x.device, dtype=torch.float32)
             _launch("conv_wgrad", ctx.flops, "vf_conv_wgrad", _ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), ws.numel(), S,
-                    Cin, Cout, H, W, KS, m, st)
+                    Cin, Cout, H, W, KS, m, st, tag=ctx.tag)
         hb, hv, hr = ctx.has
         if (hb and ctx.needs_input_grad[2]) or (hv and ctx.needs_input_grad[3]):
             rs = torch.empty(S, Cout, device=x.device, dtype=torch.float32)
@@ -281,12 +286,17 @@ class _AttentionFn(torch.autograd.Function):
         S, C3, H, W = qkv.shape
         C, L = C3 // 3, H * W
         alpha = 1.0 / math.sqrt(C)
-        P = torch.empty(S, L, L, device=qkv.device, dtype=torch.float32)
-        _bgemm(qkv, qkv, P, None, S, L, L, C, (C3 * L, 1, L), (C3 * L, L, 1), (L * L, L, 1), alpha,
-               offA=0, offB=C * L)
-        _lib.call("vf_softmax_fwd", _ptr(P), _ptr(P), S * L, L, _stream())
+        need_p = ctx.needs_input_grad[0]
         out = torch.empty(S, C, H, W, device=qkv.device, dtype=torch.float32)
-        _bgemm(qkv, P, out, None, S, C, L, L, (C3 * L, L, 1), (L * L, 1, L), (C * L, L, 1), offA=2 * C * L)
+        if L in (64, 256) and C % 32 == 0:        # fused flash-style kernel, scores stay in registers
+            P = torch.empty(S, L, L, device=qkv.device, dtype=torch.float32) if need_p else None
+            _lib.call("vf_attention_fwd", _ptr(qkv), _ptr(out), _ptr(P), S, C, L, _stream())
+        else:                                     # generic sizes: materialised scores
+            P = torch.empty(S, L, L, device=qkv.device, dtype=torch.float32)
+            _bgemm(qkv, qkv, P, None, S, L, L, C, (C3 * L, 1, L), (C3 * L, L, 1), (L * L, L, 1), alpha,
+                   offA=0, offB=C * L)
+            _lib.call("vf_softmax_fwd", _ptr(P), _ptr(P), S * L, L, _stream())
+            _bgemm(qkv, P, out, None, S, C, L, L, (C3 * L, L, 1), (L * L, 1, L), (C * L, L, 1), offA=2 * C * L)
         ctx.save_for_backward(qkv, P)
         return out
 
