@@ -20,14 +20,16 @@
 //
 // Bound: fp32 matrix rate (157.3 TF), not HBM: AI of these layers is 144-960 flop/B.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
-constexpr int TPIX = 128;  // output pixels per workgroup tile
 constexpr int TCO = 64;    // output channels per workgroup tile
 constexpr int WGRAD_TARGET_WGS = 512;  // split-K slices are sized for ~2 workgroups per CU
 
-template <int KS, int LOGW, int MODE>
+// TPIX = output pixels per workgroup tile (64 / 128 / 256): whole image rows, or several whole
+// images when an image has fewer pixels than the tile.
+template <int KS, int LOGW, int MODE, int TPIX = 128>
 struct Geo {
     static constexpr int W = 1 << LOGW;
     static constexpr int H = W;
@@ -56,7 +58,7 @@ struct Geo {
 
 struct ConvArgs {
     const float* x;
-    const float* w;      // packed [tap][CinP][CoutP]
+    const float* w;      // packed [co tile][ci chunk][group][co 64][ci 8]
     const float* bias;   // [Cout] or null
     const float* vbias;  // [S][Cout] or null
     const float* res;    // [S][Cout][H][W] or null
@@ -65,10 +67,9 @@ struct ConvArgs {
 };
 
 // Global -> register load of one float4 of the input patch (zero outside the image / tensor).
-template <int KS, int LOGW, int MODE>
+template <class G, int MODE>
 __device__ __forceinline__ float4 load_patch4(const float* __restrict__ x, int S, int Cin, int s, int ci,
                                               int r0, int pr, int q) {
-    using G = Geo<KS, LOGW, MODE>;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (s >= S || ci >= Cin) return v;
     const size_t plane = ((size_t)s * Cin + ci) * (size_t)(G::SH * G::SW);
@@ -88,17 +89,17 @@ __device__ __forceinline__ float4 load_patch4(const float* __restrict__ x, int S
     return v;
 }
 
-template <int KS, int LOGW, int MODE>
+template <int KS, int LOGW, int MODE, int NPT>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
-    using G = Geo<KS, LOGW, MODE>;
-    constexpr int CK = KS == 3 ? 8 : 32;
-    constexpr int NT = KS * KS;
-    constexpr int NW4 = NT * CK * (TCO / 4);
-    constexpr int NWL = (NW4 + 255) / 256;
+    constexpr int TPIX = 64 * NPT;            // each wave: 32 channels x (32*NPT) pixels
+    using G = Geo<KS, LOGW, MODE, TPIX>;
+    constexpr int CK = KS == 3 ? 8 : 32;      // input channels per K-chunk
+    constexpr int NG = KS == 3 ? 9 : 4;       // 8-channel groups per chunk: 9 taps (3x3) or 4 sub-chunks (1x1)
+    constexpr int WROW = 12;                  // LDS floats per (group, co) row: 8 used, stride 12 -> b128 reads conflict-free
+    constexpr int NW4 = NG * TCO * 2;         // float4 per weight chunk
     constexpr int NX4 = CK * G::IM * G::PH * G::Q;
-    constexpr int NXL = (NX4 + 255) / 256;
 
-    __shared__ __attribute__((aligned(16))) float wl[NT * CK * TCO];
+    __shared__ __attribute__((aligned(16))) float wl[NG * TCO * WROW];
     __shared__ __attribute__((aligned(16))) float xl[CK * G::PS];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -122,10 +123,10 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
     constexpr bool WT = (NW4 % 256) != 0, XT = (NX4 % 256) != 0;
     float4 wreg[NWF > 0 ? NWF : 1], xreg[NXF > 0 ? NXF : 1];
     float4 wtail = make_float4(0.f, 0.f, 0.f, 0.f), xtail = make_float4(0.f, 0.f, 0.f, 0.f);
+    // packed weights: [co tile][chunk][group][co 64][ci 8] -> one contiguous block per (tile, chunk)
+    const float* wsrc = a.w + (size_t)cot * (a.CinP / CK) * (NG * TCO * 8);
     auto load_w = [&](int e, int c0) -> float4 {
-        const int q4 = e & 15, row = e >> 4;                     // row = tap*CK + ci
-        const int tap = row / CK, ci = row - tap * CK;
-        return *reinterpret_cast<const float4*>(a.w + ((size_t)tap * a.CinP + c0 + ci) * a.CoutP + co0 + 4 * q4);
+        return *reinterpret_cast<const float4*>(wsrc + (size_t)(c0 / CK) * (NG * TCO * 8) + 4 * e);
     };
     auto load_x = [&](int e, int c0) -> float4 {
         const int q = e % G::Q;
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
         const int pr = t1 % G::PH;
         const int t2 = t1 / G::PH;
         const int im = t2 % G::IM, ci = t2 / G::IM;
-        return load_patch4<KS, LOGW, MODE>(a.x, a.S, a.Cin, s0 + im, c0 + ci, r0, pr, q);
+        return load_patch4<G, MODE>(a.x, a.S, a.Cin, s0 + im, c0 + ci, r0, pr, q);
     };
     auto store_x = [&](int e, const float4& v) {
         const int q = e % G::Q;
@@ -150,17 +151,28 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
 #define VF_STORE_CHUNK()                                                              \
     {                                                                                 \
         _Pragma("unroll") for (int i = 0; i < NWF; ++i)                                \
-            *reinterpret_cast<float4*>(wl + 4 * (tid + i * 256)) = wreg[i];            \
-        if (WT && tid + NWF * 256 < NW4) *reinterpret_cast<float4*>(wl + 4 * (tid + NWF * 256)) = wtail; \
+            *reinterpret_cast<float4*>(wl + ((tid + i * 256) >> 1) * WROW + 4 * (tid & 1)) = wreg[i]; \
+        if (WT && tid + NWF * 256 < NW4)                                               \
+            *reinterpret_cast<float4*>(wl + ((tid + NWF * 256) >> 1) * WROW + 4 * (tid & 1)) = wtail; \
         _Pragma("unroll") for (int i = 0; i < NXF; ++i) store_x(tid + i * 256, xreg[i]); \
         if (XT && tid + NXF * 256 < NX4) store_x(tid + NXF * 256, xtail);              \
     }
 
-    f32x16 acc0 = {0}, acc1 = {0};
-    const float* wb = wl + lh * TCO + cw * 32 + li;
-    const int p0 = pw * 64 + li, p1 = p0 + 32;
-    const float* xb0 = xl + lh * G::PS + G::pix_off(p0);
-    const float* xb1 = xl + lh * G::PS + G::pix_off(p1);
+    f32x16 acc[NPT];
+    int xo[NPT];
+#pragma unroll
+    for (int nt = 0; nt < NPT; ++nt) {
+        acc[nt] = (f32x16){0};
+        xo[nt] = 4 * lh * G::PS + G::pix_off(pw * 32 * NPT + nt * 32 + li);
+    }
+    // k order inside an 8-channel group: MFMA step s pairs channel s (lane half 0) with channel
+    // 4+s (half 1), so a lane's four A values are contiguous -> one ds_read_b128 per group.
+    const float* wb = wl + (cw * 32 + li) * WROW + 4 * lh;
+    auto frag_a = [&](int g) -> float4 { return *reinterpret_cast<const float4*>(wb + g * TCO * WROW); };
+    auto frag_b = [&](int g, int nt, int s) -> float {
+        const int off = KS == 3 ? (g / 3) * G::PW + (g % 3) + s * G::PS : (8 * g + s) * G::PS;
+        return xl[xo[nt] + off];
+    };
 
     VF_LOAD_CHUNK(0);
     for (int c0 = 0; c0 < a.CinP; c0 += CK) {
@@ -168,16 +180,39 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
         VF_STORE_CHUNK();
         __syncthreads();
         if (c0 + CK < a.CinP) VF_LOAD_CHUNK(c0 + CK);
+        // software pipeline over the groups: fragments of group g+1 are fetched from LDS before
+        // the MFMAs of group g are issued (sched_barrier pins that order)
+        float4 a_cur = frag_a(0);
+        float b_cur[NPT][4];
 #pragma unroll
-        for (int tap = 0; tap < NT; ++tap) {
-            const int toff = (tap / KS) * G::PW + (tap % KS);
+        for (int nt = 0; nt < NPT; ++nt)
 #pragma unroll
-            for (int s = 0; s < CK / 2; ++s) {
-                const float av = wb[(tap * CK + 2 * s) * TCO];
-                const float b0 = xb0[2 * s * G::PS + toff];
-                const float b1 = xb1[2 * s * G::PS + toff];
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, acc1, 0, 0, 0);
+            for (int s = 0; s < 4; ++s) b_cur[nt][s] = frag_b(0, nt, s);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            float4 a_nxt = a_cur;
+            float b_nxt[NPT][4];
+            if (g + 1 < NG) {
+                a_nxt = frag_a(g + 1);
+#pragma unroll
+                for (int nt = 0; nt < NPT; ++nt)
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) b_nxt[nt][s] = frag_b(g + 1, nt, s);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const float av[4] = {a_cur.x, a_cur.y, a_cur.z, a_cur.w};
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int nt = 0; nt < NPT; ++nt)
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], b_cur[nt][s], acc[nt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (g + 1 < NG) {
+                a_cur = a_nxt;
+#pragma unroll
+                for (int nt = 0; nt < NPT; ++nt)
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) b_cur[nt][s] = b_nxt[nt][s];
             }
         }
     }
@@ -185,27 +220,34 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
     // epilogue: lane = pixel (coalesced), register = output channel
 #undef VF_LOAD_CHUNK
 #undef VF_STORE_CHUNK
-    auto epilogue = [&](const f32x16& acc, int nt) {
-        const int p = pw * 64 + nt * 32 + li;
+    // All loads of a 32x32 tile (residual, biases) are issued before any of its stores so that
+    // their latency overlaps instead of forming a load->add->store chain per element.
+#pragma unroll
+    for (int nt = 0; nt < NPT; ++nt) {
+        const int p = pw * 32 * NPT + nt * 32 + li;
         const int s = G::IM > 1 ? s0 + (p >> (2 * LOGW)) : s0;
         const int pix = G::IM > 1 ? (p & (G::HW - 1)) : r0 * G::W + p;
-        if (s < a.S) {
+        if (s >= a.S) continue;
+        const int cob = co0 + cw * 32 + 4 * lh;
+        const size_t ob = ((size_t)s * a.Cout + cob) * G::HW + pix;
+        float add[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = co0 + cw * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (co < a.Cout) {
-                    const size_t o = ((size_t)s * a.Cout + co) * G::HW + pix;
-                    float v = acc[r];
-                    if (a.bias) v += a.bias[co];
-                    if (a.vbias) v += a.vbias[(size_t)s * a.Cout + co];
-                    if (a.res) v += a.res[o];
-                    a.y[o] = v;
-                }
+        for (int r = 0; r < 16; ++r) {
+            const int dco = (r & 3) + 8 * (r >> 2);
+            float v = 0.f;
+            if (cob + dco < a.Cout) {
+                if (a.res) v = a.res[ob + (size_t)dco * G::HW];
+                if (a.bias) v += a.bias[cob + dco];
+                if (a.vbias) v += a.vbias[(size_t)s * a.Cout + cob + dco];
             }
+            add[r] = v;
         }
-    };
-    epilogue(acc0, 0);
-    epilogue(acc1, 1);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int dco = (r & 3) + 8 * (r >> 2);
+            if (cob + dco < a.Cout) a.y[ob + (size_t)dco * G::HW] = acc[nt][r] + add[r];
+        }
+    }
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -220,17 +262,18 @@ struct WgradArgs {
 
 template <int KS, int LOGW, int MODE>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
-    using G = Geo<KS, LOGW, MODE>;
+    constexpr int TPIX = 128;
+    using G = Geo<KS, LOGW, MODE, TPIX>;
     constexpr int NT = KS * KS;
     constexpr int TCI = 32;
-    constexpr int DYS = TPIX + 1;                 // odd row stride: conflict-free column reads
+    constexpr int DYS = TPIX + 4;                 // 4*odd row stride: conflict-free ds_read_b128 down a column
     constexpr int PSO = G::PS | 1;                // odd plane stride
     constexpr int NX4 = TCI * G::IM * G::PH * G::Q;
     constexpr int ND4 = TCO * (TPIX / 4);
     constexpr int OHW = G::HW;
 
     constexpr int LDSF = TCO * DYS + TCI * PSO;
-    __shared__ float lds[LDSF];                   // one array: dY tile | input patch | k-half reduce
+    __shared__ __attribute__((aligned(16))) float lds[LDSF];   // dY tile | input patch | k-half reduce
     float* const dyl = lds;
     float* const xl = lds + TCO * DYS;
 
@@ -247,8 +290,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = (f32x16){0};
 
-    const float* ab = dyl + (cw * 32 + li) * DYS + kq * 64 + lh;
-    const float* bb = xl + li * PSO + G::pix_off(kq * 64 + lh);
+    const float* ab = dyl + (cw * 32 + li) * DYS + kq * 64 + 4 * lh;
+    const float* bb = xl + li * PSO + G::pix_off(kq * 64 + 4 * lh);
 
     for (int tile = t_begin; tile < t_end; ++tile) {
         const int s0 = G::IM > 1 ? tile * G::IM : tile / G::TPI;
@@ -263,8 +306,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (s < a.S && co0 + co < a.Cout)
                 v = *reinterpret_cast<const float4*>(a.dy + ((size_t)s * a.Cout + co0 + co) * OHW + pix);
-            float* d = dyl + co * DYS + p;
-            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            *reinterpret_cast<float4*>(dyl + co * DYS + p) = v;
         }
         // input patch: 32 channels
         for (int e = tid; e < NX4; e += 256) {
@@ -273,19 +315,54 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
             const int pr = t1 % G::PH;
             const int t2 = t1 / G::PH;
             const int im = t2 % G::IM, ci = t2 / G::IM;
-            const float4 v = load_patch4<KS, LOGW, MODE>(a.x, a.S, a.Cin, s0 + im, ci0 + ci, r0, pr, q);
+            const float4 v = load_patch4<G, MODE>(a.x, a.S, a.Cin, s0 + im, ci0 + ci, r0, pr, q);
             float* d = xl + ci * PSO + (im * G::PH + pr) * G::PW + 4 * q + (KS == 1 ? 0 : 4);
             d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
         }
         __syncthreads();
+        // 8 pixel groups of 8 per wave; k order inside a group: MFMA step e pairs pixel e (lane
+        // half 0) with pixel 4+e (half 1) -> the four A values of a lane are one ds_read_b128.
+        // Software pipeline: the B fragments of stage (group, tap row) + 1 are fetched before the
+        // MFMAs of the current stage are issued.
+        constexpr int NSTG = 8 * KS;                       // stages per chunk: (group, kh)
+        auto frag_b = [&](int stg, int kw, int e) -> float {
+            const int grp = stg / KS, kh = stg % KS;
+            const int d = G::pix_off(8 * grp) - G::pix_off(0);
+            return bb[d + (MODE == 1 ? 2 * e : e) + kh * G::PW + kw];
+        };
+        float b_cur[KS][4];
 #pragma unroll
-        for (int s = 0; s < 32; ++s) {
-            const float av = ab[2 * s];
-            const int d = G::pix_off(2 * s) - G::pix_off(0);
+        for (int kw = 0; kw < KS; ++kw)
 #pragma unroll
-            for (int tap = 0; tap < NT; ++tap) {
-                const float bv = bb[d + (tap / KS) * G::PW + (tap % KS)];
-                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[tap], 0, 0, 0);
+            for (int e = 0; e < 4; ++e) b_cur[kw][e] = frag_b(0, kw, e);
+        float4 a4 = *reinterpret_cast<const float4*>(ab);
+#pragma unroll
+        for (int stg = 0; stg < NSTG; ++stg) {
+            float b_nxt[KS][4];
+            float4 a_nxt = a4;
+            if (stg + 1 < NSTG) {
+#pragma unroll
+                for (int kw = 0; kw < KS; ++kw)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) b_nxt[kw][e] = frag_b(stg + 1, kw, e);
+                if ((stg + 1) % KS == 0) a_nxt = *reinterpret_cast<const float4*>(ab + 8 * ((stg + 1) / KS));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int kw = 0; kw < KS; ++kw) {
+                    const int tap = (stg % KS) * KS + kw;
+                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], b_cur[kw][e], acc[tap], 0, 0, 0);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+            if (stg + 1 < NSTG) {
+                a4 = a_nxt;
+#pragma unroll
+                for (int kw = 0; kw < KS; ++kw)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) b_cur[kw][e] = b_nxt[kw][e];
             }
         }
     }
@@ -338,24 +415,37 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restr
     dw[((size_t)co * Cin + ci) * NT + tap] = acc;
 }
 
-// OIHW -> packed forward [tap][CinP][CoutP] and backward (dgrad) [tap'][CoutPk][CinPm] with
-// flipped taps; zero padded.
+// OIHW -> packed forward  [co tile][ci chunk][group][co 64][ci 8]   (M = Cout, K = Cin x taps)
+//      and packed backward [ci tile][co chunk][group][ci 64][co 8]   (dgrad: M = Cin, K = Cout x flipped taps)
+// group = tap for 3x3 (chunk = 8 channels), = 8-channel sub-chunk for 1x1 (chunk = 32 channels).
+// Zero padded to whole tiles / chunks.
 __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wf, float* __restrict__ wb,
-                                    int Cout, int Cin, int NT, int CinPk, int CoutPm, int CoutPk, int CinPm) {
-    const size_t nf = (size_t)NT * CinPk * CoutPm, nb = (size_t)NT * CoutPk * CinPm;
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < nf) {
-        const int co = idx % CoutPm;
-        const size_t t = idx / CoutPm;
-        const int ci = t % CinPk, tap = t / CinPk;
-        wf[idx] = (co < Cout && ci < Cin) ? w[((size_t)co * Cin + ci) * NT + tap] : 0.f;
-    } else if (idx < nf + nb && wb) {
-        const size_t j = idx - nf;
-        const int ci = j % CinPm;
-        const size_t t = j / CinPm;
-        const int co = t % CoutPk, tap = t / CoutPk;
-        wb[j] = (co < Cout && ci < Cin) ? w[((size_t)co * Cin + ci) * NT + (NT - 1 - tap)] : 0.f;
+                                    int Cout, int Cin, int KS, size_t nf, size_t nb) {
+    const int NT = KS * KS, CK = KS == 3 ? 8 : 32, NG = KS == 3 ? 9 : 4;
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool bwd = idx >= nf;
+    if (bwd) {
+        idx -= nf;
+        if (idx >= nb || !wb) return;
     }
+    const int M = bwd ? Cin : Cout, K = bwd ? Cout : Cin;      // M: tile dim, K: chunk dim
+    const int nchunk = (K + CK - 1) / CK;
+    const int k8 = idx & 7;
+    const int m = (idx >> 3) & 63;
+    size_t t = idx >> 9;
+    const int g = t % NG;
+    t /= NG;
+    const int chunk = t % nchunk;
+    const int mt = t / nchunk;
+    const int mm = mt * 64 + m;
+    const int kk = chunk * CK + (KS == 3 ? k8 : g * 8 + k8);
+    const int tap = KS == 3 ? (bwd ? NT - 1 - g : g) : 0;
+    float v = 0.f;
+    if (mm < M && kk < K) {
+        const int co = bwd ? kk : mm, ci = bwd ? mm : kk;
+        v = w[((size_t)co * Cin + ci) * NT + tap];
+    }
+    (bwd ? wb : wf)[idx] = v;
 }
 
 // y[s][c][h][w] = sum of the 2x2 block of x (backward of nearest x2 upsampling)
@@ -368,23 +458,54 @@ __global__ void sumpool2_kernel(const float* __restrict__ x, float* __restrict__
     y[i] = (p[0] + p[1]) + (p[2 * Wo] + p[2 * Wo + 1]);
 }
 
+template <int KS, int LOGW, int MODE, int NPT>
+int conv_blocks(const ConvArgs& a) {
+    using G = Geo<KS, LOGW, MODE, 64 * NPT>;
+    const int ntiles = G::IM > 1 ? (a.S + G::IM - 1) / G::IM : a.S * G::TPI;
+    return ntiles * (a.CoutP / TCO);
+}
+
+template <int KS, int LOGW, int MODE, int NPT>
+int launch_conv_npt(const ConvArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL((conv_mfma_kernel<KS, LOGW, MODE, NPT>), dim3(conv_blocks<KS, LOGW, MODE, NPT>(a)),
+                       dim3(256), 0, st, a);
+    VF_RETURN_LAST_ERROR();
+}
+
+// Tile-size choice (measured, profiles/r01_conv_tile_sweep.txt): 128-pixel tiles (NPT=2) are the
+// fastest wherever they fill the chip; 256-pixel tiles lose occupancy and are never faster; small
+// feature maps (16x16, 8x8 at S=96) fall back to 64-pixel tiles so that the 256 CUs stay filled
+// and load-balanced.
+constexpr int CONV_MIN_WGS = 3 * 256;
+
+inline int npt_override() {
+    static const int v = [] {
+        const char* e = getenv("VF_CONV_NPT");       // tuning aid: force the pixel-tile size
+        return e ? atoi(e) : 0;
+    }();
+    return v;
+}
+
 template <int KS, int LOGW, int MODE>
 int launch_conv(const ConvArgs& a, hipStream_t st) {
-    using G = Geo<KS, LOGW, MODE>;
-    const int ntiles = G::IM > 1 ? (a.S + G::IM - 1) / G::IM : a.S * G::TPI;
-    const int nblk = ntiles * (a.CoutP / TCO);
-    hipLaunchKernelGGL((conv_mfma_kernel<KS, LOGW, MODE>), dim3(nblk), dim3(256), 0, st, a);
-    VF_RETURN_LAST_ERROR();
+    constexpr bool ok1 = LOGW <= 4;                       // 64-pixel tiles
+    if constexpr (ok1) {
+        const int force = npt_override();
+        if (force == 1 || (force == 0 && conv_blocks<KS, LOGW, MODE, 2>(a) < CONV_MIN_WGS))
+            return launch_conv_npt<KS, LOGW, MODE, 1>(a, st);
+    }
+    return launch_conv_npt<KS, LOGW, MODE, 2>(a, st);
 }
 
 template <int KS, int LOGW, int MODE>
 int launch_wgrad(WgradArgs a, float* dw, size_t ws_floats, hipStream_t st) {
-    using G = Geo<KS, LOGW, MODE>;
+    using G = Geo<KS, LOGW, MODE, 128>;
     constexpr int NT = KS * KS;
     a.ntiles = G::IM > 1 ? (a.S + G::IM - 1) / G::IM : a.S * G::TPI;
     const int nco = a.CoutP / TCO, nci = a.CinQ / 32;
     const size_t slab_floats = (size_t)NT * a.CoutP * a.CinQ;
-    int z = (WGRAD_TARGET_WGS + nco * nci - 1) / (nco * nci);
+    int z = WGRAD_TARGET_WGS / (nco * nci);          // never more workgroups than fit at once
+    if (z < 1) z = 1;
     if (z > a.ntiles) z = a.ntiles;
     const size_t zmax = ws_floats / slab_floats;
     if (zmax < 1) return (int)hipErrorInvalidValue;
@@ -422,16 +543,16 @@ int vf_conv_pack_weights(const float* w_oihw, float* w_fwd, float* w_bwd, int Co
                          void* stream) {
     if (KS != 1 && KS != 3) return (int)hipErrorInvalidValue;
     const int ck = KS == 3 ? 8 : 32, NT = KS * KS;
-    const int CinPk = round_up(Cin, ck), CoutPm = round_up(Cout, TCO);
-    const int CoutPk = round_up(Cout, ck), CinPm = round_up(Cin, TCO);
-    const size_t n = (size_t)NT * CinPk * CoutPm + (w_bwd ? (size_t)NT * CoutPk * CinPm : 0);
+    const size_t nf = (size_t)NT * round_up(Cin, ck) * round_up(Cout, TCO);
+    const size_t nb = w_bwd ? (size_t)NT * round_up(Cout, ck) * round_up(Cin, TCO) : 0;
+    const size_t n = nf + nb;
     hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       w_oihw, w_fwd, w_bwd, Cout, Cin, NT, CinPk, CoutPm, CoutPk, CinPm);
+                       w_oihw, w_fwd, w_bwd, Cout, Cin, KS, nf, nb);
     VF_RETURN_LAST_ERROR();
 }
 
 // y[S][Cout][H][W] = conv(x) (+bias +view_bias +residual).  H == W == power of two in [8,128]
-// is the OUTPUT size.  `w_packed` is [tap][round_up(Cin,ck)][round_up(Cout,64)].
+// is the OUTPUT size.  `w_packed` comes from vf_conv_pack_weights.
 // mode 0: x is [S][Cin][H][W]; 1: stride 2, x is [S][Cin][2H][2W]; 2: x is [S][Cin][H/2][W/2]
 // nearest-upsampled on the fly; 3: x is [S][Cin][H/2][W/2] zero-dilated on the fly.
 int vf_conv_fwd(const float* x, const float* w_packed, const float* bias, const float* view_bias,
@@ -464,7 +585,7 @@ long vf_conv_wgrad_ws_floats(int S, int Cin, int Cout, int H, int W, int KS) {
     const long slab = (long)KS * KS * round_up(Cout, TCO) * round_up(Cin, 32);
     const int nco = round_up(Cout, TCO) / TCO, nci = round_up(Cin, 32) / 32;
     long z = (WGRAD_TARGET_WGS + nco * nci - 1) / (nco * nci);
-    long ntiles = ((long)S * H * W + TPIX - 1) / TPIX;
+    long ntiles = ((long)S * H * W + 127) / 128;
     if (z > ntiles) z = ntiles;
     if (z < 1) z = 1;
     return z * slab;
