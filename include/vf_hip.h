@@ -35,8 +35,11 @@ int vf_conv_pack_weights(const float* w_oihw, float* w_fwd, float* w_bwd /*or NU
 /* mode 0 stride-1 | 1 stride-2 (x is 2Hx2W) | 2 nearest-x2 upsampled x (x is H/2xW/2) |
  * 3 zero-dilated x (dgrad of mode 1).  H,W = OUTPUT size, square power of two in [8,128]. */
 int vf_conv_fwd(const float* x, const float* w_packed, const float* bias /*[Cout]|NULL*/,
-                const float* view_bias /*[S][Cout]|NULL*/, const float* residual /*like y|NULL*/, float* y, int S,
-                int Cin, int Cout, int H, int W, int KS, int mode, void* stream);
+                const float* view_bias /*[S][Cout]|NULL*/, const float* residual /*like y|NULL*/, float* y,
+                float* ws /*|NULL*/, long ws_floats, int S, int Cin, int Cout, int H, int W, int KS, int mode,
+                void* stream);
+/* split-K workspace the call above wants at this shape (0 when the natural grid fills the chip) */
+long vf_conv_fwd_ws_floats(int S, int Cin, int Cout, int H, int W, int KS);
 long vf_conv_wgrad_ws_floats(int S, int Cin, int Cout, int H, int W, int KS);
 int vf_conv_wgrad(const float* x, const float* dy, float* dw_oihw, float* ws, long ws_floats, int S, int Cin,
                   int Cout, int H, int W, int KS, int mode, void* stream);

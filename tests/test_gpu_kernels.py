@@ -100,6 +100,15 @@ def test_conv_fwd_bwd(dev, Cin, Cout, Hin, KS, mode, S):
     assert rel(rg.grad, rc.grad) < 1e-6
 
 
+@pytest.mark.parametrize("S", [1, 2, 5])
+@pytest.mark.parametrize("Cin,Cout,Hin,KS,mode", [(320, 320, 8, 3, "same"), (64, 64, 64, 3, "same"),
+                                                  (192, 576, 16, 1, "same"), (128, 128, 32, 3, "down2"),
+                                                  (192, 192, 16, 3, "up2"), (640, 320, 8, 1, "same")])
+def test_conv_small_batch_split_k_forward(dev, Cin, Cout, Hin, KS, mode, S):
+    """Sampler regime: tiny grids take the split-K path (partials + reduce with the fused epilogue)."""
+    test_conv_fwd_bwd(dev, Cin, Cout, Hin, KS, mode, S)
+
+
 def test_conv_large_batch_split_k(dev):
     """S large enough that wgrad runs many pixel tiles per slice; odd S for the 8x8 two-image tiles."""
     from view_fusion_amd import ops

@@ -87,13 +87,14 @@ def test_train_forward_loss_and_grads_vs_reference(dev, tag):
     check_grads(g, vf.denoise_fn.named_parameters())
 
 
+@pytest.mark.parametrize("use_graph", [True, False])
 @pytest.mark.parametrize("tag,weighting", [("w", True), ("mean", False)])
-def test_generate_chain_vs_reference(dev, tag, weighting):
+def test_generate_chain_vs_reference(dev, tag, weighting, use_graph):
     g = load(f"sample_generate_{tag}.npz")
     vf = make_vf(TINY, dict(schedule="linear", num_timesteps=10, linear_start=1e-4, linear_end=0.09), dev, weighting)
     y, ret, logit_arr, weight_arr, samples = vf.generate(
         T(g["y_cond"], dev), torch.tensor(g["view_count"]), T(g["angle"], dev), y_t=T(g["y_T"], dev),
-        z_seq=T(g["z_seq"], dev))
+        z_seq=T(g["z_seq"], dev), use_graph=use_graph)
     np.testing.assert_allclose(y.cpu().numpy(), g["y"], rtol=1e-4, atol=5e-5)
     np.testing.assert_allclose(ret.cpu().numpy(), g["ret"], rtol=1e-4, atol=5e-5)
     np.testing.assert_allclose(samples.cpu().numpy(), g["samples"], rtol=1e-4, atol=5e-5)

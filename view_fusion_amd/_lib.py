@@ -23,7 +23,8 @@ SIGNATURES = {
     "vf_colsum": [_P, _P, _I, _I, _I, _P],
     "vf_conv_pack_sizes": [_I, _I, _I, ctypes.POINTER(_L), ctypes.POINTER(_L)],
     "vf_conv_pack_weights": [_P, _P, _P, _I, _I, _I, _P],
-    "vf_conv_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "vf_conv_fwd": [_P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _P],
+    "vf_conv_fwd_ws_floats": [_I, _I, _I, _I, _I, _I],
     "vf_conv_wgrad_ws_floats": [_I, _I, _I, _I, _I, _I],
     "vf_conv_wgrad": [_P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _P],
     "vf_sumpool2": [_P, _P, _L, _I, _P],
@@ -41,7 +42,7 @@ SIGNATURES = {
     "vf_compose_mse_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "vf_p_sample_tail": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
 }
-_RESTYPE = {"vf_conv_wgrad_ws_floats": _L}
+_RESTYPE = {"vf_conv_wgrad_ws_floats": _L, "vf_conv_fwd_ws_floats": _L}
 
 _lib = None
 

@@ -64,6 +64,9 @@ struct ConvArgs {
     const float* res;    // [S][Cout][H][W] or null
     float* y;
     int S, Cin, Cout, CinP, CoutP;
+    int ablate;   // tuning aid (VF_CONV_ABLATE): 1 = stage only the first chunk, 2 = and drop the barriers
+    int ksplit;   // > 1: split the K (input-channel) loop over ksplit workgroups, partials go to ws
+    float* ws;    // [ksplit][S][Cout][H*W] partial sums (small-batch / sampler regime)
 };
 
 // Global -> register load of one float4 of the input patch (zero outside the image / tensor).
@@ -107,10 +110,14 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
     const int li = lane & 31, lh = lane >> 5;
 
     const int ncot = a.CoutP / TCO;
-    const unsigned logical = xcd_remap(blockIdx.x, gridDim.x);
+    const unsigned logical0 = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = logical0 % a.ksplit;
+    const unsigned logical = logical0 / a.ksplit;
     const int cot = logical % ncot;
     const int tile = logical / ncot;
     const int co0 = cot * TCO;
+    const int nch = a.CinP / CK;
+    const int cbeg = (split * nch / a.ksplit) * CK, cend = ((split + 1) * nch / a.ksplit) * CK;
     const int s0 = G::IM > 1 ? tile * G::IM : tile / G::TPI;
     const int r0 = G::IM > 1 ? 0 : (tile % G::TPI) * G::TH;
 
@@ -174,12 +181,12 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
         return xl[xo[nt] + off];
     };
 
-    VF_LOAD_CHUNK(0);
-    for (int c0 = 0; c0 < a.CinP; c0 += CK) {
-        __syncthreads();                 // previous chunk's LDS reads (and the zero fill) done
-        VF_STORE_CHUNK();
-        __syncthreads();
-        if (c0 + CK < a.CinP) VF_LOAD_CHUNK(c0 + CK);
+    VF_LOAD_CHUNK(cbeg);
+    for (int c0 = cbeg; c0 < cend; c0 += CK) {
+        if (a.ablate < 2 || c0 == cbeg) __syncthreads();   // previous chunk's LDS reads (and the zero fill) done
+        if (a.ablate == 0 || c0 == cbeg) VF_STORE_CHUNK();
+        if (a.ablate < 2 || c0 == cbeg) __syncthreads();
+        if (c0 + CK < cend && a.ablate == 0) VF_LOAD_CHUNK(c0 + CK);
         // software pipeline over the groups: fragments of group g+1 are fetched from LDS before
         // the MFMAs of group g are issued (sched_barrier pins that order)
         float4 a_cur = frag_a(0);
@@ -230,6 +237,15 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
         if (s >= a.S) continue;
         const int cob = co0 + cw * 32 + 4 * lh;
         const size_t ob = ((size_t)s * a.Cout + cob) * G::HW + pix;
+        if (a.ksplit > 1) {            // raw partial sums; bias / residual are added by the reduce kernel
+            float* wsp = a.ws + (size_t)split * a.S * a.Cout * G::HW;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int dco = (r & 3) + 8 * (r >> 2);
+                if (cob + dco < a.Cout) wsp[ob + (size_t)dco * G::HW] = acc[nt][r];
+            }
+            continue;
+        }
         float add[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -458,6 +474,35 @@ __global__ void sumpool2_kernel(const float* __restrict__ x, float* __restrict__
     y[i] = (p[0] + p[1]) + (p[2 * Wo] + p[2 * Wo + 1]);
 }
 
+// y = sum_split ws[split] + bias[co] + view_bias[s][co] + residual      (float4 over S*Cout*HW)
+__global__ void conv_splitk_reduce_kernel(const float4* __restrict__ ws, const float* __restrict__ bias,
+                                          const float* __restrict__ vbias, const float4* __restrict__ res,
+                                          float4* __restrict__ y, int ksplit, size_t n4, int HW4, int Cout) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    float4 v = ws[i];
+    for (int k = 1; k < ksplit; ++k) {
+        const float4 t = ws[(size_t)k * n4 + i];
+        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+    }
+    const size_t sc = i / HW4;                 // s*Cout + co
+    float b = 0.f;
+    if (bias) b += bias[sc % Cout];
+    if (vbias) b += vbias[sc];
+    if (res) {
+        const float4 r = res[i];
+        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+    }
+    y[i] = make_float4(v.x + b, v.y + b, v.z + b, v.w + b);
+}
+
+// Split-K factor: only when the natural grid cannot fill the chip (small S: the sampler).
+inline int choose_ksplit(int nblk, int nchunks) {
+    if (nblk >= 384 || nchunks < 2) return 1;
+    int k = (768 + nblk - 1) / nblk;
+    return k < nchunks ? k : nchunks;
+}
+
 template <int KS, int LOGW, int MODE, int NPT>
 int conv_blocks(const ConvArgs& a) {
     using G = Geo<KS, LOGW, MODE, 64 * NPT>;
@@ -466,9 +511,21 @@ int conv_blocks(const ConvArgs& a) {
 }
 
 template <int KS, int LOGW, int MODE, int NPT>
-int launch_conv_npt(const ConvArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL((conv_mfma_kernel<KS, LOGW, MODE, NPT>), dim3(conv_blocks<KS, LOGW, MODE, NPT>(a)),
-                       dim3(256), 0, st, a);
+int launch_conv_npt(ConvArgs a, hipStream_t st, long ws_floats) {
+    constexpr int HW = 1 << (2 * LOGW);
+    const int nblk = conv_blocks<KS, LOGW, MODE, NPT>(a);
+    const size_t out_floats = (size_t)a.S * a.Cout * HW;
+    int ks = choose_ksplit(nblk, a.CinP / (KS == 3 ? 8 : 32));
+    if (a.ws == nullptr) ks = 1;
+    while (ks > 1 && (size_t)ks * out_floats > (size_t)ws_floats) --ks;
+    a.ksplit = ks;
+    hipLaunchKernelGGL((conv_mfma_kernel<KS, LOGW, MODE, NPT>), dim3(nblk * ks), dim3(256), 0, st, a);
+    if (ks > 1) {
+        const size_t n4 = out_floats / 4;
+        hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st,
+                           (const float4*)a.ws, a.bias, a.vbias, (const float4*)a.res, (float4*)a.y, ks, n4, HW / 4,
+                           a.Cout);
+    }
     VF_RETURN_LAST_ERROR();
 }
 
@@ -487,14 +544,14 @@ inline int npt_override() {
 }
 
 template <int KS, int LOGW, int MODE>
-int launch_conv(const ConvArgs& a, hipStream_t st) {
+int launch_conv(const ConvArgs& a, hipStream_t st, long ws_floats) {
     constexpr bool ok1 = LOGW <= 4;                       // 64-pixel tiles
     if constexpr (ok1) {
         const int force = npt_override();
         if (force == 1 || (force == 0 && conv_blocks<KS, LOGW, MODE, 2>(a) < CONV_MIN_WGS))
-            return launch_conv_npt<KS, LOGW, MODE, 1>(a, st);
+            return launch_conv_npt<KS, LOGW, MODE, 1>(a, st, ws_floats);
     }
-    return launch_conv_npt<KS, LOGW, MODE, 2>(a, st);
+    return launch_conv_npt<KS, LOGW, MODE, 2>(a, st, ws_floats);
 }
 
 template <int KS, int LOGW, int MODE>
@@ -555,9 +612,10 @@ int vf_conv_pack_weights(const float* w_oihw, float* w_fwd, float* w_bwd, int Co
 // is the OUTPUT size.  `w_packed` comes from vf_conv_pack_weights.
 // mode 0: x is [S][Cin][H][W]; 1: stride 2, x is [S][Cin][2H][2W]; 2: x is [S][Cin][H/2][W/2]
 // nearest-upsampled on the fly; 3: x is [S][Cin][H/2][W/2] zero-dilated on the fly.
+// ws / ws_floats: optional split-K workspace (see vf_conv_fwd_ws_floats); NULL disables split-K.
 int vf_conv_fwd(const float* x, const float* w_packed, const float* bias, const float* view_bias,
-                const float* residual, float* y, int S, int Cin, int Cout, int H, int W, int KS, int mode,
-                void* stream) {
+                const float* residual, float* y, float* ws, long ws_floats, int S, int Cin, int Cout, int H,
+                int W, int KS, int mode, void* stream) {
     if (S <= 0) return 0;
     const int lw = ilog2_exact(W);
     if (H != W || lw < 3 || lw > 7 || (KS != 1 && KS != 3)) return (int)hipErrorInvalidValue;
@@ -567,9 +625,13 @@ int vf_conv_fwd(const float* x, const float* w_packed, const float* bias, const 
     a.S = S; a.Cin = Cin; a.Cout = Cout;
     a.CinP = round_up(Cin, KS == 3 ? 8 : 32);
     a.CoutP = round_up(Cout, TCO);
+    static const int ablate = [] { const char* e = getenv("VF_CONV_ABLATE"); return e ? atoi(e) : 0; }();
+    a.ablate = ablate;
+    a.ksplit = 1;
+    a.ws = ws;
     hipStream_t st = (hipStream_t)stream;
 #define VF_CASE(KS_, LW_, M_) \
-    if (KS == KS_ && lw == LW_ && mode == M_) return launch_conv<KS_, LW_, M_>(a, st);
+    if (KS == KS_ && lw == LW_ && mode == M_) return launch_conv<KS_, LW_, M_>(a, st, ws_floats);
     VF_CASE(3, 3, 0) VF_CASE(3, 4, 0) VF_CASE(3, 5, 0) VF_CASE(3, 6, 0) VF_CASE(3, 7, 0)
     VF_CASE(3, 3, 1) VF_CASE(3, 4, 1) VF_CASE(3, 5, 1) VF_CASE(3, 6, 1)
     VF_CASE(3, 4, 2) VF_CASE(3, 5, 2) VF_CASE(3, 6, 2) VF_CASE(3, 7, 2)
@@ -577,6 +639,18 @@ int vf_conv_fwd(const float* x, const float* w_packed, const float* bias, const 
     VF_CASE(1, 3, 0) VF_CASE(1, 4, 0) VF_CASE(1, 5, 0) VF_CASE(1, 6, 0) VF_CASE(1, 7, 0)
 #undef VF_CASE
     return (int)hipErrorInvalidValue;
+}
+
+// Workspace floats vf_conv_fwd wants for its split-K path at this shape (0: no split-K, the
+// natural grid already fills the chip).  Upper bound over the tile choices.
+long vf_conv_fwd_ws_floats(int S, int Cin, int Cout, int H, int W, int KS) {
+    const long tiles64 = ((long)S * H * W + 63) / 64;
+    const long nblk_min = ((long)S * H * W + 127) / 128 * (round_up(Cout, TCO) / TCO);
+    if (nblk_min >= 384) return 0;
+    (void)tiles64;
+    const int nch = round_up(Cin, KS == 3 ? 8 : 32) / (KS == 3 ? 8 : 32);
+    const int ks = choose_ksplit((int)nblk_min, nch);
+    return ks > 1 ? (long)ks * S * Cout * H * W : 0;
 }
 
 // Workspace floats needed by vf_conv_wgrad for the preferred split (a smaller workspace is

@@ -103,6 +103,15 @@ def group_norm(x, weight, bias, groups, silu):
 
 
 # ---------------------------------------------------------------------------------------------
+def _conv_ws(device, S, Cin, Cout, H, W, KS):
+    """Split-K workspace for small grids (sampler regime); (None, 0) when the grid fills the chip."""
+    need = _lib.load().vf_conv_fwd_ws_floats(S, Cin, Cout, H, W, KS)
+    if need <= 0:
+        return None, 0
+    ws = _workspace(device, need)
+    return ws, ws.numel()
+
+
 def _packed(layer, force):
     """Packed forward / dgrad weights of a conv layer.
 
@@ -132,17 +141,18 @@ def _packed(layer, force):
 
 class _Conv2dFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, view_bias, residual, layer, mode):
+    def forward(ctx, x, weight, bias, view_bias, residual, layer, mode, training):
         _check(x, bias, view_bias, residual)
-        wf, wb = _packed(layer, force=ctx.needs_input_grad[1])
+        wf, wb = _packed(layer, force=training)
         S, Cin, Hi, Wi = x.shape
         Cout, _, KS, _ = weight.shape
         m = _MODES[mode]
         H, W = (Hi // 2, Wi // 2) if m == 1 else ((Hi * 2, Wi * 2) if m == 2 else (Hi, Wi))
         y = torch.empty(S, Cout, H, W, device=x.device, dtype=torch.float32)
         flops = 2.0 * S * Cout * Cin * KS * KS * H * W
+        ws, nws = _conv_ws(x.device, S, Cin, Cout, H, W, KS)
         _launch("conv_fwd", flops, "vf_conv_fwd", _ptr(x), _ptr(wf), _ptr(bias), _ptr(view_bias), _ptr(residual),
-                _ptr(y), S, Cin, Cout, H, W, KS, m, _stream(), tag=(Cin, Cout, H, KS, m))
+                _ptr(y), _ptr(ws), nws, S, Cin, Cout, H, W, KS, m, _stream(), tag=(Cin, Cout, H, KS, m))
         ctx.flops, ctx.tag = flops, (Cin, Cout, H, KS, m)
         ctx.save_for_backward(x)
         ctx.wb, ctx.m, ctx.KS, ctx.Cout = wb, m, KS, Cout
@@ -161,16 +171,17 @@ class _Conv2dFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if m == 0:
                 dx = torch.empty_like(x)
+                ws, nws = _conv_ws(x.device, S, Cout, Cin, H, W, KS)
                 _launch("conv_dgrad", ctx.flops, "vf_conv_fwd", _ptr(dy), _ptr(ctx.wb), None, None, None, _ptr(dx),
-                        S, Cout, Cin, H, W, KS, 0, st, tag=ctx.tag)
+                        _ptr(ws), nws, S, Cout, Cin, H, W, KS, 0, st, tag=ctx.tag)
             elif m == 1:      # stride-2 conv: transposed conv = conv over the zero-dilated dy
                 dx = torch.empty_like(x)
                 _launch("conv_dgrad", ctx.flops, "vf_conv_fwd", _ptr(dy), _ptr(ctx.wb), None, None, None, _ptr(dx),
-                        S, Cout, Cin, Hi, Wi, KS, 3, st, tag=ctx.tag)
+                        None, 0, S, Cout, Cin, Hi, Wi, KS, 3, st, tag=ctx.tag)
             else:             # upsample + conv: dgrad at the upsampled size, then 2x2 sum-pool
                 dup = torch.empty(S, Cin, H, W, device=x.device, dtype=torch.float32)
                 _launch("conv_dgrad", ctx.flops, "vf_conv_fwd", _ptr(dy), _ptr(ctx.wb), None, None, None, _ptr(dup),
-                        S, Cout, Cin, H, W, KS, 0, st, tag=ctx.tag)
+                        None, 0, S, Cout, Cin, H, W, KS, 0, st, tag=ctx.tag)
                 dx = torch.empty_like(x)
                 _lib.call("vf_sumpool2", _ptr(dup), _ptr(dx), dx.numel(), Wi, st)
         if ctx.needs_input_grad[1]:
@@ -190,7 +201,7 @@ class _Conv2dFn(torch.autograd.Function):
                 _lib.call("vf_colsum", _ptr(rs), _ptr(db), 1, S, Cout, st)
         if hr and ctx.needs_input_grad[4]:
             dres = dy
-        return dx, dw, db, dvb, dres, None, None
+        return dx, dw, db, dvb, dres, None, None, None
 
 
 def conv2d(x, layer, view_bias=None, residual=None, mode="same"):
@@ -199,7 +210,8 @@ def conv2d(x, layer, view_bias=None, residual=None, mode="same"):
     mode "same": stride 1; "down2": stride 2; "up2": nearest x2 upsample fused into the load.
     Epilogue adds bias[c] + view_bias[s,c] + residual.
     """
-    return _Conv2dFn.apply(x, layer.weight, layer.bias, view_bias, residual, layer, mode)
+    training = torch.is_grad_enabled() and layer.weight.requires_grad
+    return _Conv2dFn.apply(x, layer.weight, layer.bias, view_bias, residual, layer, mode, training)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -281,12 +293,11 @@ class _AttentionFn(torch.autograd.Function):
     """softmax(Q^T K / sqrt(C)) applied to V for single-head spatial attention; qkv (S,3C,H,W)."""
 
     @staticmethod
-    def forward(ctx, qkv):
+    def forward(ctx, qkv, need_p):
         _check(qkv)
         S, C3, H, W = qkv.shape
         C, L = C3 // 3, H * W
         alpha = 1.0 / math.sqrt(C)
-        need_p = ctx.needs_input_grad[0]
         out = torch.empty(S, C, H, W, device=qkv.device, dtype=torch.float32)
         if L in (64, 256) and C % 32 == 0:        # fused flash-style kernel, scores stay in registers
             P = torch.empty(S, L, L, device=qkv.device, dtype=torch.float32) if need_p else None
@@ -320,11 +331,11 @@ class _AttentionFn(torch.autograd.Function):
         # dK[c][j] = alpha sum_i q[c][i] dS[i][j]
         _bgemm(qkv, dS, dqkv, None, S, C, L, L, (C3 * L, L, 1), (L * L, L, 1), (C3 * L, L, 1), alpha,
                offA=0, offC=C * L)
-        return dqkv
+        return dqkv, None
 
 
 def attention(qkv):
-    return _AttentionFn.apply(qkv)
+    return _AttentionFn.apply(qkv, torch.is_grad_enabled() and qkv.requires_grad)
 
 
 class _ConcatFn(torch.autograd.Function):
@@ -447,13 +458,13 @@ def compose(unet_out, off, B, max_views, weighting, want_weights=True):
 
 
 def p_sample_tail(unet_out, off, y_t, z, t, sched, B, max_views, weighting, clip=True, want_weights=True,
-                  want_mean=False):
+                  want_mean=False, inplace=False):
     """Fused compose -> y0_hat -> clamp -> posterior mean -> + z*sigma.
     Returns (y_next, mean | None, weights | None)."""
     _check(unet_out, y_t, z)
     S, Cout, H, W = unet_out.shape
     t = _c(t.to(torch.int64))
-    y_next = torch.empty_like(y_t)
+    y_next = y_t if inplace else torch.empty_like(y_t)     # elementwise: safe to overwrite y_t
     mean = torch.empty_like(y_t) if want_mean else None
     wts = None
     if weighting and want_weights:

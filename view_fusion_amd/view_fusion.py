@@ -90,39 +90,76 @@ class ViewFusion(nn.Module):
         return y, (out[:, 3:, ...] if w_on else None), weights
 
     @torch.no_grad()
-    def generate(self, y_cond, view_count, angle, y_t=None, sample_num=8, z_seq=None):
+    def generate(self, y_cond, view_count, angle, y_t=None, sample_num=8, z_seq=None, use_graph=None):
+        """Reverse diffusion over all T steps (reference view_fusion.py:179-214).
+
+        use_graph (default: on for GPU tensors with S <= 8 stacked views): one reverse step -- level gather, re-stack of
+        y_t, the whole UNet forward and the fused compose/posterior tail (~260 launches) -- is
+        captured once into a HIP graph and replayed T times, so the loop is not launch-bound at
+        small S.  Per step the host only refreshes the step index and the noise buffer.
+        """
         from . import ops
         b = y_cond.shape[0]
         assert self.num_timesteps > sample_num, "num_timesteps must greater than sample_num"
         every = self.num_timesteps // sample_num
         if y_t is None:
             y_t = torch.randn_like(y_cond[:, :1, :3, ...]).squeeze(dim=1)
-        y_t = y_t.contiguous()
-        off, S, max_v = ops.view_offsets(view_count, y_t.device)
+        y = y_t.contiguous().clone()                      # updated in place, step after step
+        dev = y.device
+        off, S, max_v = ops.view_offsets(view_count, dev)
         w_on = bool(self.weighting_inference)
         sched = self._sched()
+        if use_graph is None:                             # measured: replay wins while the step is launch-bound
+            use_graph = y.is_cuda and S <= 8
+        t = torch.full((b,), self.num_timesteps - 1, device=dev, dtype=torch.long)
+        z = torch.zeros_like(y)
+        y_cond = y_cond.contiguous()
+        angle = angle.contiguous()
+        # the conditioning half of the stacked input never changes: copy it once
+        x, _, _ = ops.stack_views(y_cond, y, None, ops.gather_level(self.gammas, t), angle, off, S)
+
+        def step():
+            _, out = self._denoise(y, y_cond, angle, t, off, S, x=x, copy_cond=False)
+            _, _, weights = ops.p_sample_tail(out, off, y, z, t, sched, b, max_v, w_on, inplace=True)
+            return out, weights
+
+        graph = None
+        if use_graph:
+            y0 = y.clone()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):                 # warm-up: packs weights, fills caches
+                step()
+            torch.cuda.current_stream().wait_stream(side)
+            y.copy_(y0)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out, weights = step()
+            y.copy_(y0)                                    # capture does not execute, but be explicit
+
         ret, logit_arr, weight_arr = [y_t], [], []
-        x = None
         for i in reversed(range(self.num_timesteps)):
-            t = torch.full((b,), i, device=y_t.device, dtype=torch.long)
-            stash = i % every == 0
-            # the conditioning half of the stacked input never changes: copy it once
-            x, out = self._denoise(y_t, y_cond, angle, t, off, S, x=x, copy_cond=x is None)
-            z = None
-            if i > 0:
-                z = z_seq[i] if z_seq is not None else torch.randn_like(y_t)
-            y_t, _, weights = ops.p_sample_tail(out, off, y_t, z, t, sched, b, max_v, w_on,
-                                                want_weights=stash)
-            if stash:
-                ret.append(y_t)
+            t.fill_(i)
+            if i == 0:
+                z.zero_()
+            elif z_seq is not None:
+                z.copy_(z_seq[i])
+            else:
+                z.normal_()
+            if graph is not None:
+                graph.replay()
+            else:
+                out, weights = step()
+            if i % every == 0:
+                ret.append(y.clone())
                 logit_arr.append(out[:, 3:, ...].clone() if w_on else None)
-                weight_arr.append(weights)
+                weight_arr.append(weights.clone() if w_on else None)
         ret = torch.stack(ret, dim=1)
         samples = ret[:, -1, ...]
         if w_on:
             logit_arr = torch.stack(logit_arr, dim=1)
             weight_arr = torch.stack(weight_arr, dim=1)
-        return y_t, ret, logit_arr, weight_arr, samples
+        return y, ret, logit_arr, weight_arr, samples
 
     sample = generate
 
