@@ -121,6 +121,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
     const int s0 = G::IM > 1 ? tile * G::IM : tile / G::TPI;
     const int r0 = G::IM > 1 ? 0 : (tile % G::TPI) * G::TH;
 
+#ifdef VF_CONV_STAMPS   // diagnostic build only (tools/conv_stamps.py): per-workgroup phase clocks
+    long long st_[4] = {clock64(), 0, 0, 0}, rt_[2] = {wall_clock64(), 0};
+#endif
     // zero the patch once: the left/right halo columns are never written again
     for (int i = tid; i < CK * G::PS; i += 256) xl[i] = 0.f;
 
@@ -186,6 +189,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
         if (a.ablate < 2 || c0 == cbeg) __syncthreads();   // previous chunk's LDS reads (and the zero fill) done
         if (a.ablate == 0 || c0 == cbeg) VF_STORE_CHUNK();
         if (a.ablate < 2 || c0 == cbeg) __syncthreads();
+#ifdef VF_CONV_STAMPS
+        if (c0 == cbeg) st_[1] = clock64();
+#endif
         if (c0 + CK < cend && a.ablate == 0) VF_LOAD_CHUNK(c0 + CK);
         // software pipeline over the groups: fragments of group g+1 are fetched from LDS before
         // the MFMAs of group g are issued (sched_barrier pins that order)
@@ -227,6 +233,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
     // epilogue: lane = pixel (coalesced), register = output channel
 #undef VF_LOAD_CHUNK
 #undef VF_STORE_CHUNK
+#ifdef VF_CONV_STAMPS
+    st_[2] = clock64();
+#endif
     // All loads of a 32x32 tile (residual, biases) are issued before any of its stores so that
     // their latency overlaps instead of forming a load->add->store chain per element.
 #pragma unroll
@@ -264,6 +273,18 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
             if (cob + dco < a.Cout) a.y[ob + (size_t)dco * G::HW] = acc[nt][r] + add[r];
         }
     }
+#ifdef VF_CONV_STAMPS
+    __syncthreads();
+    if (tid == 0 && a.ws) {
+        st_[3] = clock64();
+        rt_[1] = wall_clock64();
+        long long* o = reinterpret_cast<long long*>(a.ws) + (size_t)blockIdx.x * 8;
+        o[0] = st_[0]; o[1] = st_[1]; o[2] = st_[2]; o[3] = st_[3]; o[4] = rt_[0]; o[5] = rt_[1];
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        o[6] = hwid;
+    }
+#endif
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -276,12 +297,17 @@ struct WgradArgs {
     int ntiles, tiles_per_slice;
 };
 
-template <int KS, int LOGW, int MODE>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
+// BIG = true : 64 co x 64 ci tile, waves = 2 (co) x 2 (ci), ONE workgroup per CU with the whole
+//              512-register file per lane: 144 accumulators + a full pixel tile prefetched in
+//              registers while the previous one is multiplied (stride-1 / upsampled inputs).
+// BIG = false: 64 co x 32 ci tile, waves = 2 (co) x 2 (pixel halves, summed through LDS), two
+//              workgroups per CU, no register prefetch (stride-2 inputs: the patch is too large).
+template <int KS, int LOGW, int MODE, bool BIG>
+__global__ __launch_bounds__(256, BIG ? 1 : 2) void conv_wgrad_kernel(WgradArgs a) {
     constexpr int TPIX = 128;
     using G = Geo<KS, LOGW, MODE, TPIX>;
     constexpr int NT = KS * KS;
-    constexpr int TCI = 32;
+    constexpr int TCI = BIG ? 64 : 32;
     constexpr int DYS = TPIX + 4;                 // 4*odd row stride: conflict-free ds_read_b128 down a column
     constexpr int PSO = G::PS | 1;                // odd plane stride
     constexpr int NX4 = TCI * G::IM * G::PH * G::Q;
@@ -294,7 +320,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
     float* const xl = lds + TCO * DYS;
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int cw = wid & 1, kq = wid >> 1;
+    const int cw = wid & 1;
+    const int kq = BIG ? 0 : (wid >> 1);          // pixel half of this wave (small tile only)
+    const int ciw = BIG ? (wid >> 1) : 0;         // ci half of this wave (big tile only)
     const int li = lane & 31, lh = lane >> 5;
     const int co0 = blockIdx.x * TCO, ci0 = blockIdx.y * TCI;
     const int t_begin = blockIdx.z * a.tiles_per_slice;
@@ -307,40 +335,72 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
     for (int t = 0; t < NT; ++t) acc[t] = (f32x16){0};
 
     const float* ab = dyl + (cw * 32 + li) * DYS + kq * 64 + 4 * lh;
-    const float* bb = xl + li * PSO + G::pix_off(kq * 64 + 4 * lh);
+    const float* bb = xl + (ciw * 32 + li) * PSO + G::pix_off(kq * 64 + 4 * lh);
 
-    for (int tile = t_begin; tile < t_end; ++tile) {
+    // Global -> register staging of one pixel tile (issued a whole tile ahead of its use when the
+    // register budget allows: PF) and register -> LDS write-out.
+    constexpr int NXF = NX4 / 256;
+    constexpr bool XT = (NX4 % 256) != 0;
+    constexpr bool PF = BIG;
+    float4 dreg[ND4 / 256], xreg[NXF > 0 ? NXF : 1];
+    float4 xtail = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto load_dy = [&](int e, int tile) -> float4 {
         const int s0 = G::IM > 1 ? tile * G::IM : tile / G::TPI;
         const int r0 = G::IM > 1 ? 0 : (tile % G::TPI) * G::TH;
+        const int q = e & 31, co = e >> 5;                   // 32 float4 per row
+        const int p = 4 * q;
+        const int s = G::IM > 1 ? s0 + (p >> (2 * LOGW)) : s0;
+        const int pix = G::IM > 1 ? (p & (OHW - 1)) : r0 * G::W + p;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (s < a.S && co0 + co < a.Cout)
+            v = *reinterpret_cast<const float4*>(a.dy + ((size_t)s * a.Cout + co0 + co) * OHW + pix);
+        return v;
+    };
+    auto load_x = [&](int e, int tile) -> float4 {
+        const int s0 = G::IM > 1 ? tile * G::IM : tile / G::TPI;
+        const int r0 = G::IM > 1 ? 0 : (tile % G::TPI) * G::TH;
+        const int q = e % G::Q;
+        const int t1 = e / G::Q;
+        const int pr = t1 % G::PH;
+        const int t2 = t1 / G::PH;
+        const int im = t2 % G::IM, ci = t2 / G::IM;
+        return load_patch4<G, MODE>(a.x, a.S, a.Cin, s0 + im, ci0 + ci, r0, pr, q);
+    };
+    auto store_x = [&](int e, const float4& v) {
+        const int q = e % G::Q;
+        const int t1 = e / G::Q;                              // (ci*IM + im)*PH + pr
+        const int ci = t1 / (G::IM * G::PH), rest = t1 % (G::IM * G::PH);
+        float* d = xl + ci * PSO + rest * G::PW + 4 * q + (KS == 1 ? 0 : 4);
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    };
+#define VF_WG_LOAD(TILE)                                                                    \
+    {                                                                                       \
+        _Pragma("unroll") for (int i = 0; i < ND4 / 256; ++i) dreg[i] = load_dy(tid + i * 256, (TILE)); \
+        _Pragma("unroll") for (int i = 0; i < NXF; ++i) xreg[i] = load_x(tid + i * 256, (TILE));        \
+        if (XT && tid + NXF * 256 < NX4) xtail = load_x(tid + NXF * 256, (TILE));            \
+    }
+#define VF_WG_STORE()                                                                       \
+    {                                                                                       \
+        _Pragma("unroll") for (int i = 0; i < ND4 / 256; ++i) {                              \
+            const int e = tid + i * 256;                                                    \
+            *reinterpret_cast<float4*>(dyl + (e >> 5) * DYS + 4 * (e & 31)) = dreg[i];       \
+        }                                                                                   \
+        _Pragma("unroll") for (int i = 0; i < NXF; ++i) store_x(tid + i * 256, xreg[i]);     \
+        if (XT && tid + NXF * 256 < NX4) store_x(tid + NXF * 256, xtail);                    \
+    }
+
+    if (PF && t_begin < t_end) VF_WG_LOAD(t_begin);
+    for (int tile = t_begin; tile < t_end; ++tile) {
         __syncthreads();
-        // dY tile: 64 channels x 128 pixels
-        for (int e = tid; e < ND4; e += 256) {
-            const int q = e & 31, co = e >> 5;               // 32 float4 per row
-            const int p = 4 * q;
-            const int s = G::IM > 1 ? s0 + (p >> (2 * LOGW)) : s0;
-            const int pix = G::IM > 1 ? (p & (OHW - 1)) : r0 * G::W + p;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (s < a.S && co0 + co < a.Cout)
-                v = *reinterpret_cast<const float4*>(a.dy + ((size_t)s * a.Cout + co0 + co) * OHW + pix);
-            *reinterpret_cast<float4*>(dyl + co * DYS + p) = v;
-        }
-        // input patch: 32 channels
-        for (int e = tid; e < NX4; e += 256) {
-            const int q = e % G::Q;
-            const int t1 = e / G::Q;
-            const int pr = t1 % G::PH;
-            const int t2 = t1 / G::PH;
-            const int im = t2 % G::IM, ci = t2 / G::IM;
-            const float4 v = load_patch4<G, MODE>(a.x, a.S, a.Cin, s0 + im, ci0 + ci, r0, pr, q);
-            float* d = xl + ci * PSO + (im * G::PH + pr) * G::PW + 4 * q + (KS == 1 ? 0 : 4);
-            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-        }
+        if (!PF) VF_WG_LOAD(tile);
+        VF_WG_STORE();
         __syncthreads();
+        if (PF && tile + 1 < t_end) VF_WG_LOAD(tile + 1);
         // 8 pixel groups of 8 per wave; k order inside a group: MFMA step e pairs pixel e (lane
         // half 0) with pixel 4+e (half 1) -> the four A values of a lane are one ds_read_b128.
         // Software pipeline: the B fragments of stage (group, tap row) + 1 are fetched before the
         // MFMAs of the current stage are issued.
-        constexpr int NSTG = 8 * KS;                       // stages per chunk: (group, kh)
+        constexpr int NSTG = (BIG ? 16 : 8) * KS;          // stages per chunk: (pixel group of 8, kh)
         auto frag_b = [&](int stg, int kw, int e) -> float {
             const int grp = stg / KS, kh = stg % KS;
             const int d = G::pix_off(8 * grp) - G::pix_off(0);
@@ -383,11 +443,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
         }
     }
 
+#undef VF_WG_LOAD
+#undef VF_WG_STORE
     // the two pixel halves (kq) of each co-half are summed through LDS, in passes of NTP taps
     constexpr int NTP = NT > 1 ? (NT + 1) / 2 : 1;
     static_assert(2 * NTP * 16 * 64 <= LDSF, "k-half reduce buffer does not fit");
 #pragma unroll
-    for (int t0 = 0; t0 < NT; t0 += NTP) {
+    for (int t0 = 0; t0 < (BIG ? 0 : NT); t0 += NTP) {
         __syncthreads();
         if (kq == 1) {
 #pragma unroll
@@ -410,7 +472,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int co = co0 + cw * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            a.ws[(((size_t)slab * NT + tap) * a.CoutP + co) * a.CinQ + ci0 + li] = acc[tap][r];
+            const int ci = ci0 + ciw * 32 + li;
+            if (ci < a.CinQ) a.ws[(((size_t)slab * NT + tap) * a.CoutP + co) * a.CinQ + ci] = acc[tap][r];
         }
     }
 }
@@ -558,10 +621,12 @@ template <int KS, int LOGW, int MODE>
 int launch_wgrad(WgradArgs a, float* dw, size_t ws_floats, hipStream_t st) {
     using G = Geo<KS, LOGW, MODE, 128>;
     constexpr int NT = KS * KS;
+    constexpr bool BIG = MODE != 1;                  // stride-2 patches do not fit the big tile
+    constexpr int TCI = BIG ? 64 : 32;
     a.ntiles = G::IM > 1 ? (a.S + G::IM - 1) / G::IM : a.S * G::TPI;
-    const int nco = a.CoutP / TCO, nci = a.CinQ / 32;
+    const int nco = a.CoutP / TCO, nci = (a.CinQ + TCI - 1) / TCI;
     const size_t slab_floats = (size_t)NT * a.CoutP * a.CinQ;
-    int z = WGRAD_TARGET_WGS / (nco * nci);          // never more workgroups than fit at once
+    int z = (BIG ? 256 : WGRAD_TARGET_WGS) / (nco * nci);   // never more workgroups than fit at once
     if (z < 1) z = 1;
     if (z > a.ntiles) z = a.ntiles;
     const size_t zmax = ws_floats / slab_floats;
@@ -569,7 +634,7 @@ int launch_wgrad(WgradArgs a, float* dw, size_t ws_floats, hipStream_t st) {
     if ((size_t)z > zmax) z = (int)zmax;
     a.tiles_per_slice = (a.ntiles + z - 1) / z;
     z = (a.ntiles + a.tiles_per_slice - 1) / a.tiles_per_slice;
-    hipLaunchKernelGGL((conv_wgrad_kernel<KS, LOGW, MODE>), dim3(nco, nci, z), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((conv_wgrad_kernel<KS, LOGW, MODE, BIG>), dim3(nco, nci, z), dim3(256), 0, st, a);
     const int total = NT * a.Cout * a.Cin;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, a.ws, dw, z, NT,
                        a.Cout, a.Cin, a.CoutP, a.CinQ);
