@@ -76,6 +76,110 @@ __global__ __launch_bounds__(256) void bgemm_kernel(GemmArgs g) {
     }
 }
 
+
+// Fast path: both operands have a unit stride (along k or along m/n), all extents and the other
+// strides are multiples of 4 floats.  16-byte global loads, LDS image oriented like the global
+// one (so LDS writes are b128 too), next K-chunk prefetched in registers while the current one is
+// multiplied, fragment reads one chunk-group ahead of the MFMAs.
+// k order inside a group of 8: MFMA step e pairs k = e (lane half 0) with k = 4 + e (half 1), so a
+// k-contiguous operand is fetched with one ds_read_b128 per 4 MFMAs.
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) void bgemm_v2_kernel(GemmArgs g) {
+    constexpr int KS_ = BK + 4;                      // [m][k] image row stride: 4*odd -> conflict-free b128
+    __shared__ __attribute__((aligned(16))) float Al[A_KC ? BM * KS_ : BK * BM];
+    __shared__ __attribute__((aligned(16))) float Bl[B_KC ? BN * KS_ : BK * BN];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid & 1, wn = wid >> 1, li = lane & 31, lh = lane >> 5;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN, b = blockIdx.z;
+    const float* A = g.A + (long)b * g.sAb;
+    const float* B = g.B + (long)b * g.sBb;
+
+    float4 ar[2], br[2];
+    auto load = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (A_KC) {
+                const int m = (tid >> 3) + 32 * i, kq = tid & 7;
+                if (m0 + m < g.M && k0 + 4 * kq < g.K)
+                    v = *reinterpret_cast<const float4*>(A + (long)(m0 + m) * g.sAm + k0 + 4 * kq);
+            } else {
+                const int k = (tid >> 4) + 16 * i, mq = tid & 15;
+                if (k0 + k < g.K && m0 + 4 * mq < g.M)
+                    v = *reinterpret_cast<const float4*>(A + (long)(k0 + k) * g.sAk + m0 + 4 * mq);
+            }
+            ar[i] = v;
+            float4 u = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (B_KC) {
+                const int n = (tid >> 3) + 32 * i, kq = tid & 7;
+                if (n0 + n < g.N && k0 + 4 * kq < g.K)
+                    u = *reinterpret_cast<const float4*>(B + (long)(n0 + n) * g.sBn + k0 + 4 * kq);
+            } else {
+                const int k = (tid >> 4) + 16 * i, nq = tid & 15;
+                if (k0 + k < g.K && n0 + 4 * nq < g.N)
+                    u = *reinterpret_cast<const float4*>(B + (long)(k0 + k) * g.sBk + n0 + 4 * nq);
+            }
+            br[i] = u;
+        }
+    };
+    auto store = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (A_KC) *reinterpret_cast<float4*>(Al + ((tid >> 3) + 32 * i) * KS_ + 4 * (tid & 7)) = ar[i];
+            else      *reinterpret_cast<float4*>(Al + ((tid >> 4) + 16 * i) * BM + 4 * (tid & 15)) = ar[i];
+            if (B_KC) *reinterpret_cast<float4*>(Bl + ((tid >> 3) + 32 * i) * KS_ + 4 * (tid & 7)) = br[i];
+            else      *reinterpret_cast<float4*>(Bl + ((tid >> 4) + 16 * i) * BN + 4 * (tid & 15)) = br[i];
+        }
+    };
+    auto frag_a = [&](int grp) -> float4 {
+        if (A_KC) return *reinterpret_cast<const float4*>(Al + (wm * 32 + li) * KS_ + 8 * grp + 4 * lh);
+        const float* p = Al + (8 * grp + 4 * lh) * BM + wm * 32 + li;
+        return make_float4(p[0], p[BM], p[2 * BM], p[3 * BM]);
+    };
+    auto frag_b = [&](int grp) -> float4 {
+        if (B_KC) return *reinterpret_cast<const float4*>(Bl + (wn * 32 + li) * KS_ + 8 * grp + 4 * lh);
+        const float* p = Bl + (8 * grp + 4 * lh) * BN + wn * 32 + li;
+        return make_float4(p[0], p[BN], p[2 * BN], p[3 * BN]);
+    };
+
+    f32x16 acc = {0};
+    load(0);
+    for (int k0 = 0; k0 < g.K; k0 += BK) {
+        __syncthreads();
+        store();
+        __syncthreads();
+        if (k0 + BK < g.K) load(k0 + BK);
+        float4 a_cur = frag_a(0), b_cur = frag_b(0);
+#pragma unroll
+        for (int grp = 0; grp < BK / 8; ++grp) {
+            float4 a_nxt = a_cur, b_nxt = b_cur;
+            if (grp + 1 < BK / 8) { a_nxt = frag_a(grp + 1); b_nxt = frag_b(grp + 1); }
+            __builtin_amdgcn_sched_barrier(0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.x, b_cur.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.y, b_cur.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.z, b_cur.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.w, b_cur.w, acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            a_cur = a_nxt; b_cur = b_nxt;
+        }
+    }
+    float* C = g.C + (long)b * g.sCb;
+    const int n = n0 + wn * 32 + li;
+    if (n < g.N) {
+        const float bn = g.bias ? g.bias[n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (m < g.M) {
+                float* p = C + (long)m * g.sCm + n;
+                float v = g.alpha * acc[r] + bn;
+                if (g.beta != 0.f) v += g.beta * *p;
+                *p = v;
+            }
+        }
+    }
+}
+
 // One wave per row; cols <= 64*MAXV.
 template <int MAXV>
 __global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
@@ -148,8 +252,21 @@ int vf_bgemm(const float* A, const float* B, float* C, const float* bias, int ba
     g.A = A; g.B = B; g.C = C; g.bias = bias; g.M = M; g.N = N; g.K = K;
     g.sAb = sAb; g.sAm = sAm; g.sAk = sAk; g.sBb = sBb; g.sBk = sBk; g.sBn = sBn;
     g.sCb = sCb; g.sCm = sCm; g.sCn = sCn; g.alpha = alpha; g.beta = beta;
-    hipLaunchKernelGGL(bgemm_kernel, dim3((N + BN - 1) / BN, (M + BM - 1) / BM, batch), dim3(256), 0,
-                       (hipStream_t)stream, g);
+    const dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, batch);
+    hipStream_t st = (hipStream_t)stream;
+    auto mul4 = [](long v) { return (v & 3) == 0; };
+    const bool a_kc = sAk == 1, a_mc = sAm == 1, b_kc = sBk == 1, b_nc = sBn == 1;
+    const bool fast = (a_kc || a_mc) && (b_kc || b_nc) && sCn == 1 && mul4(K) && mul4(sAb) && mul4(sBb) &&
+                      (a_kc ? mul4(sAm) : (mul4(sAk) && mul4(M))) && (b_kc ? mul4(sBn) : (mul4(sBk) && mul4(N))) &&
+                      ((reinterpret_cast<size_t>(A) | reinterpret_cast<size_t>(B)) & 15) == 0;
+    if (fast) {
+        if (a_kc && b_kc) hipLaunchKernelGGL((bgemm_v2_kernel<true, true>), grid, dim3(256), 0, st, g);
+        else if (a_kc) hipLaunchKernelGGL((bgemm_v2_kernel<true, false>), grid, dim3(256), 0, st, g);
+        else if (b_kc) hipLaunchKernelGGL((bgemm_v2_kernel<false, true>), grid, dim3(256), 0, st, g);
+        else hipLaunchKernelGGL((bgemm_v2_kernel<false, false>), grid, dim3(256), 0, st, g);
+        VF_RETURN_LAST_ERROR();
+    }
+    hipLaunchKernelGGL(bgemm_kernel, grid, dim3(256), 0, st, g);
     VF_RETURN_LAST_ERROR();
 }
 
