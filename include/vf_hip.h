@@ -19,10 +19,11 @@ extern "C" {
 /* ---- GroupNorm (+Swish) : nn.GroupNorm(32,C,eps) -> Swish, unet.py:211-212,254,180-182 ---- */
 int vf_gn_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean /*[S*G]*/,
               float* rstd /*[S*G]*/, int S, int C, int HW, int groups, float eps, int silu, void* stream);
-/* dgamma_part/dbeta_part: [S][C] per-view partials; reduce over S with vf_colsum. */
+/* dgamma_part/dbeta_part: [S][C] per-view partials; reduce over S with vf_colsum.
+ * addend (like x, or NULL) is added to dx: gradient of a second consumer of x (residual branch). */
 int vf_gn_bwd(const float* x, const float* gamma, const float* beta, const float* mean, const float* rstd,
-              const float* dy, float* dx, float* dgamma_part, float* dbeta_part, int S, int C, int HW, int groups,
-              int silu, void* stream);
+              const float* dy, const float* addend, float* dx, float* dgamma_part, float* dbeta_part, int S, int C,
+              int HW, int groups, int silu, void* stream);
 int vf_rowsum(const float* x, float* out /*[rows]*/, int rows, int len, void* stream);
 int vf_colsum(const float* part /*[batch][S][C]*/, float* out /*[batch][C]*/, int batch, int S, int C,
               void* stream);

@@ -169,6 +169,113 @@ __global__ __launch_bounds__(256) void gn_bwd_dx_kernel(const float* __restrict_
     }
 }
 
+
+// Single-pass backward: the whole (view, group) lives in registers (x and dy read ONCE), like the
+// forward.  Requires H*W >= 256 so that the 64 float4 of one wave-wide access sit in one channel:
+// per-channel sums are then wave reductions accumulated by lane 0 into a per-(wave, channel) LDS
+// slot in a fixed order (deterministic), combined after one barrier.
+// Optional `addend` (same shape as x) is added to dx: fuses the gradient of a second use of x
+// (residual / skip branch) that autograd would otherwise sum with a separate kernel.
+template <int NV, int NT>
+__global__ __launch_bounds__(NT) void gn_bwd_fused_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta,
+                                                          const float* __restrict__ mean,
+                                                          const float* __restrict__ rstd,
+                                                          const float* __restrict__ addend, float* __restrict__ dx,
+                                                          float* __restrict__ dgamma_part,
+                                                          float* __restrict__ dbeta_part, int C, int HW, int cpg,
+                                                          int silu) {
+    constexpr int NWV = NT / 64;
+    extern __shared__ float part[];                  // [NWV][cpg][2]
+    const int G = C / cpg;
+    const int sg = blockIdx.x;
+    const int s = sg / G, g = sg - s * G;
+    const size_t base = ((size_t)s * C + (size_t)g * cpg) * HW;
+    const int n = cpg * HW, n4 = n >> 2, hw4 = HW >> 2;
+    const float4* x4 = reinterpret_cast<const float4*>(x + base);
+    const float4* d4 = reinterpret_cast<const float4*>(dy + base);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const float mu = mean[sg], r = rstd[sg];
+
+    for (int i = threadIdx.x; i < NWV * cpg * 2; i += NT) part[i] = 0.f;
+    __syncthreads();
+
+    float4 xv[NV], dv[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int idx = threadIdx.x + i * NT;
+        if (idx < n4) { xv[i] = x4[idx]; dv[i] = d4[idx]; }
+        else { xv[i] = make_float4(0.f, 0.f, 0.f, 0.f); dv[i] = xv[i]; }
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int idx0 = wid * 64 + i * NT;          // wave-uniform first index of this access
+        float a = 0.f, b = 0.f;
+        int cl = 0;
+        if (idx0 < n4) {
+            cl = idx0 / hw4;                         // channel within the group (wave-uniform)
+            const float ga = gamma[g * cpg + cl], be = beta[g * cpg + cl];
+            float xs[4] = {xv[i].x, xv[i].y, xv[i].z, xv[i].w};
+            float ds[4] = {dv[i].x, dv[i].y, dv[i].z, dv[i].w};
+            const bool ok = threadIdx.x + i * NT < n4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float xh = (xs[j] - mu) * r;
+                float dz = silu ? dsilu_mul(xh * ga + be, ds[j]) : ds[j];
+                if (!ok) dz = 0.f;
+                xs[j] = xh; ds[j] = dz;
+                a += dz; b += dz * xh;
+            }
+            xv[i] = make_float4(xs[0], xs[1], xs[2], xs[3]);
+            dv[i] = make_float4(ds[0], ds[1], ds[2], ds[3]);
+        }
+        a = wave_sum(a);
+        b = wave_sum(b);
+        if (lane == 0 && idx0 < n4) {
+            part[(wid * cpg + cl) * 2 + 0] += a;
+            part[(wid * cpg + cl) * 2 + 1] += b;
+        }
+    }
+    __syncthreads();
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = 0; c < cpg; ++c) {
+        float A = 0.f, B = 0.f;
+#pragma unroll
+        for (int w = 0; w < NWV; ++w) { A += part[(w * cpg + c) * 2]; B += part[(w * cpg + c) * 2 + 1]; }
+        const float ga = gamma[g * cpg + c];
+        s1 += ga * A; s2 += ga * B;
+        if (threadIdx.x == c) {
+            dbeta_part[(size_t)s * C + g * cpg + c] = A;
+            dgamma_part[(size_t)s * C + g * cpg + c] = B;
+        }
+    }
+    const float inv_n = 1.0f / (float)n;
+    s1 *= inv_n; s2 *= inv_n;
+    float4* o4 = reinterpret_cast<float4*>(dx + base);
+    const float4* a4 = addend ? reinterpret_cast<const float4*>(addend + base) : nullptr;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int idx = threadIdx.x + i * NT;
+        if (idx < n4) {
+            const float ga = gamma[g * cpg + idx / hw4];
+            float4 o;
+            o.x = r * (dv[i].x * ga - (s1 + xv[i].x * s2));
+            o.y = r * (dv[i].y * ga - (s1 + xv[i].y * s2));
+            o.z = r * (dv[i].z * ga - (s1 + xv[i].z * s2));
+            o.w = r * (dv[i].w * ga - (s1 + xv[i].w * s2));
+            if (a4) { const float4 t = a4[idx]; o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w; }
+            o4[idx] = o;
+        }
+    }
+}
+
+// dx += addend for the two-kernel fallback path
+__global__ void add_inplace_kernel(float4* __restrict__ y, const float4* __restrict__ a, size_t n4) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n4) { float4 v = y[i]; const float4 t = a[i]; v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; y[i] = v; }
+}
+
 // out[row] = sum_j x[row][j]   (one wave per row; row length multiple of 4)
 __global__ __launch_bounds__(256) void rowsum_kernel(const float* __restrict__ x, float* __restrict__ out,
                                                      int rows, int len) {
@@ -237,13 +344,30 @@ int vf_gn_fwd(const float* x, const float* gamma, const float* beta, float* y, f
 }
 
 int vf_gn_bwd(const float* x, const float* gamma, const float* beta, const float* mean, const float* rstd,
-              const float* dy, float* dx, float* dgamma_part, float* dbeta_part, int S, int C, int HW,
-              int groups, int silu, void* stream) {
+              const float* dy, const float* addend, float* dx, float* dgamma_part, float* dbeta_part, int S, int C,
+              int HW, int groups, int silu, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (S <= 0) return 0;
     if (C % groups != 0 || (HW & 3)) return (int)hipErrorInvalidValue;
     const int cpg = C / groups;
     const int rows = S * C;
+    const long n4g = (long)cpg * HW / 4;
+    if (HW >= 256 && n4g <= 8192) {
+#define VF_GNB(NV, NT)                                                                                     \
+    {                                                                                                      \
+        hipLaunchKernelGGL((gn_bwd_fused_kernel<NV, NT>), dim3(S * groups), dim3(NT), (NT / 64) * cpg * 2 * 4, st, \
+                           x, dy, gamma, beta, mean, rstd, addend, dx, dgamma_part, dbeta_part, C, HW, cpg, silu); \
+        VF_RETURN_LAST_ERROR();                                                                            \
+    }
+        if (n4g <= 256) VF_GNB(1, 256)
+        if (n4g <= 512) VF_GNB(2, 256)
+        if (n4g <= 1024) VF_GNB(4, 256)
+        if (n4g <= 2048) VF_GNB(8, 256)
+        if (n4g <= 4096) VF_GNB(8, 512)
+        if (n4g <= 6144) VF_GNB(12, 512)
+        VF_GNB(8, 1024)
+#undef VF_GNB
+    }
     hipLaunchKernelGGL(gn_bwd_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, x, dy, gamma, beta, mean, rstd,
                        dbeta_part, dgamma_part, rows, C, HW, cpg, silu);
     const int n4 = cpg * HW / 4;
@@ -251,6 +375,11 @@ int vf_gn_bwd(const float* x, const float* gamma, const float* beta, const float
     if (chunks < 1) chunks = 1;
     hipLaunchKernelGGL(gn_bwd_dx_kernel, dim3(S * groups, chunks), dim3(256), 0, st, x, dy, gamma, beta, mean,
                        rstd, dbeta_part, dgamma_part, dx, C, HW, cpg, silu);
+    if (addend) {
+        const size_t t4 = (size_t)S * C * HW / 4;
+        hipLaunchKernelGGL(add_inplace_kernel, dim3((unsigned)((t4 + 255) / 256)), dim3(256), 0, st, (float4*)dx,
+                           (const float4*)addend, t4);
+    }
     VF_RETURN_LAST_ERROR();
 }
 

@@ -69,37 +69,69 @@ def _workspace(device, nfloats):
 
 
 # ---------------------------------------------------------------------------------------------
+def _gn_forward(x, gamma, beta, groups, silu):
+    _check(x, gamma, beta)
+    S, C, H, W = x.shape
+    y = torch.empty_like(x)
+    mean = torch.empty(S * groups, device=x.device, dtype=torch.float32)
+    rstd = torch.empty_like(mean)
+    _lib.call("vf_gn_fwd", _ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(mean), _ptr(rstd), S, C, H * W,
+              groups, 1e-5, int(silu), _stream())
+    return y, mean, rstd
+
+
+def _gn_backward(ctx, dy, addend):
+    x, gamma, beta, mean, rstd = ctx.saved_tensors
+    dy = _c(dy)
+    S, C, H, W = x.shape
+    dx = torch.empty_like(x)
+    parts = torch.empty(2, S, C, device=x.device, dtype=torch.float32)
+    _lib.call("vf_gn_bwd", _ptr(x), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd), _ptr(dy), _ptr(addend),
+              _ptr(dx), _ptr(parts[0]), _ptr(parts[1]), S, C, H * W, ctx.groups, ctx.silu, _stream())
+    dgb = torch.empty(2, C, device=x.device, dtype=torch.float32)
+    _lib.call("vf_colsum", _ptr(parts), _ptr(dgb), 2, S, C, _stream())
+    return dx, dgb[0], dgb[1]
+
+
 class _GroupNormFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, groups, silu):
-        _check(x, gamma, beta)
-        S, C, H, W = x.shape
-        y = torch.empty_like(x)
-        mean = torch.empty(S * groups, device=x.device, dtype=torch.float32)
-        rstd = torch.empty_like(mean)
-        _lib.call("vf_gn_fwd", _ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(mean), _ptr(rstd), S, C, H * W,
-                  groups, 1e-5, int(silu), _stream())
+        y, mean, rstd = _gn_forward(x, gamma, beta, groups, silu)
         ctx.save_for_backward(x, gamma, beta, mean, rstd)
         ctx.groups, ctx.silu = groups, int(silu)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, gamma, beta, mean, rstd = ctx.saved_tensors
-        dy = _c(dy)
-        S, C, H, W = x.shape
-        dx = torch.empty_like(x)
-        parts = torch.empty(2, S, C, device=x.device, dtype=torch.float32)
-        _lib.call("vf_gn_bwd", _ptr(x), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd), _ptr(dy), _ptr(dx),
-                  _ptr(parts[0]), _ptr(parts[1]), S, C, H * W, ctx.groups, ctx.silu, _stream())
-        dgb = torch.empty(2, C, device=x.device, dtype=torch.float32)
-        _lib.call("vf_colsum", _ptr(parts), _ptr(dgb), 2, S, C, _stream())
-        return dx, dgb[0], dgb[1], None, None
+        return (*_gn_backward(ctx, dy, None), None, None)
+
+
+class _GroupNormSkipFn(torch.autograd.Function):
+    """(GN(x), x): the second output is x itself for a residual / skip consumer, so that its
+    gradient is added inside the GroupNorm backward kernel instead of by a separate autograd add."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, groups, silu):
+        y, mean, rstd = _gn_forward(x, gamma, beta, groups, silu)
+        ctx.save_for_backward(x, gamma, beta, mean, rstd)
+        ctx.groups, ctx.silu = groups, int(silu)
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, dskip):
+        return (*_gn_backward(ctx, dy, None if dskip is None else _c(dskip)), None, None)
 
 
 def group_norm(x, weight, bias, groups, silu):
     """GroupNorm(groups, C, eps=1e-5) [+ x*sigmoid(x)] on (S,C,H,W)."""
     return _GroupNormFn.apply(x, weight, bias, groups, silu)
+
+
+def group_norm_skip(x, weight, bias, groups, silu):
+    """-> (GroupNorm(x), x_for_the_residual_branch); see _GroupNormSkipFn."""
+    if not (torch.is_grad_enabled() and x.requires_grad):
+        return _GroupNormFn.apply(x, weight, bias, groups, silu), x
+    return _GroupNormSkipFn.apply(x, weight, bias, groups, silu)
 
 
 # ---------------------------------------------------------------------------------------------

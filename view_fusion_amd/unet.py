@@ -49,10 +49,12 @@ class _ResBlock(nn.Module):
         b1, b2 = self.block1["block"], self.block2["block"]
         lin = self.noise_func["noise_func"]["0"]
         e = ops.linear(emb, lin.weight, lin.bias)                                   # (S,Cout)
-        a = ops.group_norm(x, b1["0"].weight, b1["0"].bias, self.groups, silu=True)
+        # x feeds both the first GroupNorm and the residual branch: the GN op hands x back so that
+        # the residual gradient is summed inside its backward kernel
+        a, xs = ops.group_norm_skip(x, b1["0"].weight, b1["0"].bias, self.groups, silu=True)
         h = ops.conv2d(a, b1["3"], view_bias=e)
         a = ops.group_norm(h, b2["0"].weight, b2["0"].bias, self.groups, silu=True)
-        skip = x if isinstance(self.res_conv, nn.Identity) else ops.conv2d(x, self.res_conv)
+        skip = xs if isinstance(self.res_conv, nn.Identity) else ops.conv2d(xs, self.res_conv)
         return ops.conv2d(a, b2["3"], residual=skip)
 
 
@@ -66,10 +68,10 @@ class _SelfAttention(nn.Module):
 
     def forward(self, x):
         from . import ops
-        n = ops.group_norm(x, self.norm.weight, self.norm.bias, self.groups, silu=False)
+        n, xs = ops.group_norm_skip(x, self.norm.weight, self.norm.bias, self.groups, silu=False)
         qkv = ops.conv2d(n, self.qkv)                                               # (S,3C,H,W)
         o = ops.attention(qkv)                                                      # (S,C,H,W)
-        return ops.conv2d(o, self.out, residual=x)
+        return ops.conv2d(o, self.out, residual=xs)
 
 
 class _ResAttnBlock(nn.Module):
