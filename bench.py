@@ -15,6 +15,7 @@ Rank 0 prints ONE JSON line.  At --gpus 1 it also carries
   roofline     : the dominant kernel (conv_mfma_kernel, fwd + dgrad launches) timed with HIP events
                  on its launch stream over extra instrumented steps; algorithmic FLOPs / time
                  against the 157.3 TF fp32 matrix peak
+  sampler      : sampled views/s of the T=1000 reverse loop (HIP-graph replay at small S)
   cpu_baseline : the CPU oracle (fresh PyTorch-CPU restatement of the reference, kind "port")
                  timed on a bounded sample (B=1, N=6 -> 6 views/iteration) on the host cores.
 """
@@ -92,6 +93,20 @@ def roofline(trainer, batch, steps=2):
     return out
 
 
+def sampler_leg():
+    """Second half of BASELINE's metric: sampled views/s of the reverse-diffusion loop (config C5:
+    T=1000 test schedule, N conditioning views).  A bounded number of reverse steps is timed and
+    extrapolated linearly to T=1000 (the loop is strictly sequential with constant step cost)."""
+    from view_fusion_amd import sampling_bench
+    model = train.build_model(device="cuda:0", phase="test")
+    out = {"unit": "completed target views/s at T=1000", "schedule": "linear T=1000 1e-4..0.09"}
+    for B, N, steps in ((1, 1, 100), (1, 6, 100), (1, 12, 100), (16, 6, 20)):
+        r = sampling_bench.time_sampler(B, N, steps=steps, model=model, use_graph=None)
+        out[f"B{B}_N{N}"] = dict(sampled_views_per_sec=r["sampled_views_per_sec"], ms_per_step=r["ms_per_step"],
+                                 view_unet_evals_per_sec=r["view_unet_evals_per_sec"], steps_timed=steps)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -101,6 +116,7 @@ def main():
     ap.add_argument("--views", type=int, default=6)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-sampler", action="store_true")
     args = ap.parse_args()
 
     rank, local_rank, world = train.init_distributed()
@@ -148,6 +164,8 @@ def main():
         }
         if world == 1 and not args.no_roofline:
             res["roofline"] = roofline(trainer, batch)
+        if world == 1 and not args.no_sampler:
+            res["sampler"] = sampler_leg()
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(64, args.views)
         print(json.dumps(res), flush=True)

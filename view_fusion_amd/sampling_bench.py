@@ -36,6 +36,6 @@ def _run(model, b, batch, views, steps, full_T, use_graph):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     per_step = dt / steps
-    return dict(batch=batch, views=views, steps_timed=steps, T=full_T, graph=bool(use_graph),
+    return dict(batch=batch, views=views, steps_timed=steps, T=full_T, graph=use_graph,
                 ms_per_step=per_step * 1e3, sampled_views_per_sec=batch / (per_step * full_T),
                 view_unet_evals_per_sec=batch * views / per_step)
