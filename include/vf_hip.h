@@ -25,6 +25,8 @@ int vf_gn_bwd(const float* x, const float* gamma, const float* beta, const float
               const float* dy, const float* addend, float* dx, float* dgamma_part, float* dbeta_part, int S, int C,
               int HW, int groups, int silu, void* stream);
 int vf_rowsum(const float* x, float* out /*[rows]*/, int rows, int len, void* stream);
+/* conv epilogue gradients in one launch: db[C] (|NULL) and dvb[S][C] (|NULL) from dy[S][C][HW] */
+int vf_bias_grad(const float* dy, float* db, float* dvb, int S, int C, int HW, void* stream);
 int vf_colsum(const float* part /*[batch][S][C]*/, float* out /*[batch][C]*/, int batch, int S, int C,
               void* stream);
 

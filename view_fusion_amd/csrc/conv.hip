@@ -479,19 +479,30 @@ __global__ __launch_bounds__(256, BIG ? 1 : 2) void conv_wgrad_kernel(WgradArgs 
 }
 
 // dw[co][ci][tap] = sum_slab ws[slab][tap][co][ci]
-__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nslab, int NT,
-                                    int Cout, int Cin, int CoutP, int CinQ) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // over (tap, co, ci), ci fastest
+// block = 64 consecutive (tap,co,ci) outputs x 4 slab groups (fixed 4-way split + fixed tree:
+// deterministic), so that small weight tensors still spread over the chip.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
+                                                           int nslab, int NT, int Cout, int Cin, int CoutP,
+                                                           int CinQ) {
+    __shared__ float red[4][64];
+    const int ox = threadIdx.x & 63, sy = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 64 + ox;                     // over (tap, co, ci), ci fastest
     const int total = NT * Cout * Cin;
-    if (idx >= total) return;
-    const int ci = idx % Cin;
-    const int t = idx / Cin;
-    const int co = t % Cout, tap = t / Cout;
-    const size_t stride = (size_t)NT * CoutP * CinQ;
-    const float* p = ws + ((size_t)tap * CoutP + co) * CinQ + ci;
     float acc = 0.f;
-    for (int s = 0; s < nslab; ++s) acc += p[s * stride];
-    dw[((size_t)co * Cin + ci) * NT + tap] = acc;
+    int ci = 0, co = 0, tap = 0;
+    if (idx < total) {
+        ci = idx % Cin;
+        const int t = idx / Cin;
+        co = t % Cout;
+        tap = t / Cout;
+        const size_t stride = (size_t)NT * CoutP * CinQ;
+        const float* p = ws + ((size_t)tap * CoutP + co) * CinQ + ci;
+        for (int s = sy; s < nslab; s += 4) acc += p[s * stride];
+    }
+    red[sy][ox] = acc;
+    __syncthreads();
+    if (sy == 0 && idx < total)
+        dw[((size_t)co * Cin + ci) * NT + tap] = (red[0][ox] + red[1][ox]) + (red[2][ox] + red[3][ox]);
 }
 
 // OIHW -> packed forward  [co tile][ci chunk][group][co 64][ci 8]   (M = Cout, K = Cin x taps)
@@ -636,7 +647,7 @@ int launch_wgrad(WgradArgs a, float* dw, size_t ws_floats, hipStream_t st) {
     z = (a.ntiles + a.tiles_per_slice - 1) / a.tiles_per_slice;
     hipLaunchKernelGGL((conv_wgrad_kernel<KS, LOGW, MODE, BIG>), dim3(nco, nci, z), dim3(256), 0, st, a);
     const int total = NT * a.Cout * a.Cin;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, a.ws, dw, z, NT,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 63) / 64), dim3(256), 0, st, a.ws, dw, z, NT,
                        a.Cout, a.Cin, a.CoutP, a.CinQ);
     VF_RETURN_LAST_ERROR();
 }

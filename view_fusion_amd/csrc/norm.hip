@@ -292,6 +292,30 @@ __global__ __launch_bounds__(256) void rowsum_kernel(const float* __restrict__ x
     if (lane == 0) out[row] = a;
 }
 
+// Gradients of the conv epilogue's bias[c] and view_bias[s][c] from dy[S][C][HW] in ONE launch:
+//   dvb[s][c] = sum_p dy[s][c][p]      db[c] = sum_s dvb[s][c]
+// One workgroup per channel; wave w handles views w, w+4, ...; fixed order -> deterministic.
+__global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict__ dy, float* __restrict__ db,
+                                                        float* __restrict__ dvb, int S, int C, int HW) {
+    __shared__ float red[4];
+    const int c = blockIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    float tot = 0.f;
+    for (int s = wid; s < S; s += 4) {
+        const float4* p = reinterpret_cast<const float4*>(dy + ((size_t)s * C + c) * HW);
+        float a = 0.f;
+        for (int i = lane; i < (HW >> 2); i += 64) {
+            const float4 v = p[i];
+            a += (v.x + v.y) + (v.z + v.w);
+        }
+        a = wave_sum(a);
+        if (lane == 0 && dvb) dvb[(size_t)s * C + c] = a;
+        tot += a;
+    }
+    if (lane == 0) red[wid] = tot;
+    __syncthreads();
+    if (threadIdx.x == 0 && db) db[c] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 // out[b][c] = sum_s part[b][s][c]   (deterministic: fixed 4-way row split + fixed tree)
 // block = 64 columns x 4 row groups; grid (ceil(C/64), batch)
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ part, float* __restrict__ out,
@@ -387,6 +411,13 @@ int vf_rowsum(const float* x, float* out, int rows, int len, void* stream) {
     if (rows <= 0) return 0;
     if (len & 3) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(rowsum_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, out, rows, len);
+    VF_RETURN_LAST_ERROR();
+}
+
+int vf_bias_grad(const float* dy, float* db, float* dvb, int S, int C, int HW, void* stream) {
+    if (S <= 0 || C <= 0) return 0;
+    if (HW & 3) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(bias_grad_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, dy, db, dvb, S, C, HW);
     VF_RETURN_LAST_ERROR();
 }
 

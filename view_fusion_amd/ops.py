@@ -223,14 +223,19 @@ class _Conv2dFn(torch.autograd.Function):
             _launch("conv_wgrad", ctx.flops, "vf_conv_wgrad", _ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), ws.numel(), S,
                     Cin, Cout, H, W, KS, m, st, tag=ctx.tag)
         hb, hv, hr = ctx.has
-        if (hb and ctx.needs_input_grad[2]) or (hv and ctx.needs_input_grad[3]):
-            rs = torch.empty(S, Cout, device=x.device, dtype=torch.float32)
-            _lib.call("vf_rowsum", _ptr(dy), _ptr(rs), S * Cout, H * W, st)
-            if hv and ctx.needs_input_grad[3]:
-                dvb = rs
-            if hb and ctx.needs_input_grad[2]:
-                db = torch.empty(Cout, device=x.device, dtype=torch.float32)
-                _lib.call("vf_colsum", _ptr(rs), _ptr(db), 1, S, Cout, st)
+        want_b, want_v = hb and ctx.needs_input_grad[2], hv and ctx.needs_input_grad[3]
+        if want_b or want_v:
+            db = torch.empty(Cout, device=x.device, dtype=torch.float32) if want_b else None
+            if Cout >= 192:       # one launch, one workgroup per channel (enough channels to fill the chip)
+                dvb = torch.empty(S, Cout, device=x.device, dtype=torch.float32) if want_v else None
+                _lib.call("vf_bias_grad", _ptr(dy), _ptr(db), _ptr(dvb), S, Cout, H * W, st)
+            else:                 # few channels: wave-per-row partial sums, then the column sum
+                dvb = torch.empty(S, Cout, device=x.device, dtype=torch.float32)
+                _lib.call("vf_rowsum", _ptr(dy), _ptr(dvb), S * Cout, H * W, st)
+                if want_b:
+                    _lib.call("vf_colsum", _ptr(dvb), _ptr(db), 1, S, Cout, st)
+                if not want_v:
+                    dvb = None
         if hr and ctx.needs_input_grad[4]:
             dres = dy
         return dx, dw, db, dvb, dres, None, None, None
