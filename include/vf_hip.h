@@ -35,6 +35,9 @@ int vf_colsum(const float* part /*[batch][S][C]*/, float* out /*[batch][C]*/, in
 int vf_conv_pack_sizes(int Cout, int Cin, int KS, long* fwd_floats, long* bwd_floats);
 int vf_conv_pack_weights(const float* w_oihw, float* w_fwd, float* w_bwd /*or NULL*/, int Cout, int Cin, int KS,
                          void* stream);
+/* every layer of a network in one launch; desc = device int64 [nlayers][9] rows
+ * {w, w_fwd, w_bwd, Cout, Cin, KS, fwd_floats, bwd_floats, first_block}, block = 256 elements */
+int vf_conv_pack_weights_multi(const void* desc, int nlayers, long total_blocks, void* stream);
 /* mode 0 stride-1 | 1 stride-2 (x is 2Hx2W) | 2 nearest-x2 upsampled x (x is H/2xW/2) |
  * 3 zero-dilated x (dgrad of mode 1).  H,W = OUTPUT size, square power of two in [8,128]. */
 int vf_conv_fwd(const float* x, const float* w_packed, const float* bias /*[Cout]|NULL*/,

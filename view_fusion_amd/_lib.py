@@ -24,6 +24,7 @@ SIGNATURES = {
     "vf_colsum": [_P, _P, _I, _I, _I, _P],
     "vf_conv_pack_sizes": [_I, _I, _I, ctypes.POINTER(_L), ctypes.POINTER(_L)],
     "vf_conv_pack_weights": [_P, _P, _P, _I, _I, _I, _P],
+    "vf_conv_pack_weights_multi": [_P, _I, _L, _P],
     "vf_conv_fwd": [_P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _P],
     "vf_conv_fwd_ws_floats": [_I, _I, _I, _I, _I, _I],
     "vf_conv_wgrad_ws_floats": [_I, _I, _I, _I, _I, _I],

@@ -509,10 +509,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 //      and packed backward [ci tile][co chunk][group][ci 64][co 8]   (dgrad: M = Cin, K = Cout x flipped taps)
 // group = tap for 3x3 (chunk = 8 channels), = 8-channel sub-chunk for 1x1 (chunk = 32 channels).
 // Zero padded to whole tiles / chunks.
-__global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wf, float* __restrict__ wb,
-                                    int Cout, int Cin, int KS, size_t nf, size_t nb) {
+__device__ __forceinline__ void pack_one(const float* __restrict__ w, float* __restrict__ wf,
+                                         float* __restrict__ wb, int Cout, int Cin, int KS, size_t nf, size_t nb,
+                                         size_t idx) {
     const int NT = KS * KS, CK = KS == 3 ? 8 : 32, NG = KS == 3 ? 9 : 4;
-    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool bwd = idx >= nf;
     if (bwd) {
         idx -= nf;
@@ -536,6 +536,30 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
         v = w[((size_t)co * Cin + ci) * NT + tap];
     }
     (bwd ? wb : wf)[idx] = v;
+}
+
+__global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wf, float* __restrict__ wb,
+                                    int Cout, int Cin, int KS, size_t nf, size_t nb) {
+    pack_one(w, wf, wb, Cout, Cin, KS, nf, nb, (size_t)blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+// All conv layers of a network in ONE launch.  desc[l] = {w, wf, wb, Cout, Cin, KS, nf, nb, first
+// block}; a block finds its layer by binary search over the first-block column.
+struct PackDesc {
+    const float* w;
+    float* wf;
+    float* wb;
+    long long Cout, Cin, KS, nf, nb, first_block;
+};
+__global__ void pack_weights_multi_kernel(const PackDesc* __restrict__ desc, int nlayers) {
+    int lo = 0, hi = nlayers;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (desc[mid].first_block <= (long long)blockIdx.x) lo = mid; else hi = mid;
+    }
+    const PackDesc d = desc[lo];
+    const size_t idx = ((size_t)blockIdx.x - (size_t)d.first_block) * blockDim.x + threadIdx.x;
+    pack_one(d.w, d.wf, d.wb, (int)d.Cout, (int)d.Cin, (int)d.KS, (size_t)d.nf, (size_t)d.nb, idx);
 }
 
 // y[s][c][h][w] = sum of the 2x2 block of x (backward of nearest x2 upsampling)
@@ -681,6 +705,15 @@ int vf_conv_pack_weights(const float* w_oihw, float* w_fwd, float* w_bwd, int Co
     const size_t n = nf + nb;
     hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        w_oihw, w_fwd, w_bwd, Cout, Cin, KS, nf, nb);
+    VF_RETURN_LAST_ERROR();
+}
+
+// Pack every layer described by the device table `desc` ([nlayers][9] int64:
+// {w_ptr, wf_ptr, wb_ptr, Cout, Cin, KS, nf, nb, first_block}) in one launch of total_blocks x 256.
+int vf_conv_pack_weights_multi(const void* desc, int nlayers, long total_blocks, void* stream) {
+    if (nlayers <= 0 || total_blocks <= 0) return 0;
+    hipLaunchKernelGGL(pack_weights_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const PackDesc*)desc, nlayers);
     VF_RETURN_LAST_ERROR();
 }
 

@@ -156,6 +156,9 @@ def _packed(layer, force):
     key = (w._version, w.data_ptr(), w.device)
     if not force and cache is not None and cache[0] == key:
         return cache[1], cache[2]
+    if force and cache is not None and getattr(layer, "_vf_pack_fresh", False):
+        object.__setattr__(layer, "_vf_pack_fresh", False)       # packed by pack_all() for THIS forward
+        return cache[1], cache[2]
     Cout, Cin, KS, _ = w.shape
     nf, nb = ctypes.c_long(), ctypes.c_long()
     _lib.call("vf_conv_pack_sizes", Cout, Cin, KS, ctypes.byref(nf), ctypes.byref(nb))
@@ -169,6 +172,39 @@ def _packed(layer, force):
     _lib.call("vf_conv_pack_weights", _ptr(wd), _ptr(wf), _ptr(wb), Cout, Cin, KS, _stream())
     object.__setattr__(layer, "_vf_pack", (key, wf, wb))
     return wf, wb
+
+
+def pack_all(root):
+    """Training forward: re-pack the weights of EVERY conv layer under `root` with one launch
+    (device-side descriptor table, rebuilt only if a parameter moved).  Each layer's fresh pack is
+    consumed by its next training-mode conv2d call."""
+    plan = getattr(root, "_vf_pack_plan", None)
+    layers = plan[0] if plan is not None else [m for m in root.modules() if isinstance(m, torch.nn.Conv2d)]
+    if not layers:
+        return
+    _check(layers[0].weight.detach())
+    key = tuple(l.weight.data_ptr() for l in layers)
+    if plan is None or plan[1] != key:
+        rows, first = [], 0
+        for l in layers:
+            w = l.weight
+            Cout, Cin, KS, _ = w.shape
+            nf, nb = ctypes.c_long(), ctypes.c_long()
+            _lib.call("vf_conv_pack_sizes", Cout, Cin, KS, ctypes.byref(nf), ctypes.byref(nb))
+            wf = torch.empty(nf.value, device=w.device, dtype=torch.float32)
+            wb = torch.empty(nb.value, device=w.device, dtype=torch.float32)
+            object.__setattr__(l, "_vf_pack", (None, wf, wb))
+            rows.append([w.data_ptr(), wf.data_ptr(), wb.data_ptr(), Cout, Cin, KS, nf.value, nb.value, first])
+            first += (nf.value + nb.value + 255) // 256
+        desc = torch.tensor(rows, dtype=torch.int64).to(layers[0].weight.device)
+        plan = (layers, key, desc, first)
+        object.__setattr__(root, "_vf_pack_plan", plan)
+    _lib.call("vf_conv_pack_weights_multi", ctypes.c_void_p(plan[2].data_ptr()), len(layers), plan[3], _stream())
+    for l in layers:
+        w = l.weight
+        c = l._vf_pack
+        object.__setattr__(l, "_vf_pack", ((w._version, w.data_ptr(), w.device), c[1], c[2]))
+        object.__setattr__(l, "_vf_pack_fresh", True)
 
 
 class _Conv2dFn(torch.autograd.Function):

@@ -146,6 +146,8 @@ class UNet(nn.Module):
     def forward(self, x, angle, time):
         """x (S,Cin,H,W), angle (S,1), time = noise level (S,1)  ->  (S,Cout,H,W)."""
         from . import ops
+        if torch.is_grad_enabled() and self.final_conv["block"]["3"].weight.requires_grad:
+            ops.pack_all(self)          # training: all 103 conv layers re-packed by one launch
         mlp = self.noise_level_mlp
         pe = ops.sincos_embedding(time, angle, self.inner_channel)                  # (S,inner)
         emb = ops.linear(pe, mlp["0"].weight, mlp["0"].bias)
