@@ -68,6 +68,20 @@ def cpu_baseline(hw, n_views, iters=2):
                        f"after 1 warm-up, {dt:.2f} s/iteration")
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same bench
+    command (profiles/r01_bench_pmc_traffic_kib_per_launch.json: FETCH_SIZE and WRITE_SIZE collected
+    in separate --pmc runs; FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 correction).  PMC
+    counters cannot be read from inside the process, so this is the recorded, not a live, figure."""
+    path = os.path.join(ROOT, "profiles", "r01_bench_pmc_traffic_kib_per_launch.json")
+    try:
+        d = json.load(open(path))[kernel]
+        return dict(bytes_per_launch=(2 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0,
+                    source="profiles/r01_bench_pmc_traffic_kib_per_launch.json (rocprofv3 --pmc, separate passes)")
+    except (OSError, KeyError):
+        return None
+
+
 def roofline(trainer, batch, steps=2):
     """Per-launch HIP-event timing of the conv contraction kernels over `steps` extra iterations."""
     ops.KERNEL_LOG = []
@@ -84,9 +98,10 @@ def roofline(trainer, batch, steps=2):
     f = agg["conv_fwd"][0] + agg["conv_dgrad"][0]
     s = agg["conv_fwd"][1] + agg["conv_dgrad"][1]
     n = agg["conv_fwd"][2] + agg["conv_dgrad"][2]
-    out = dict(bound="mfma", kernel="conv_mfma_kernel<KS,LOGW,MODE> (forward + dgrad launches)",
+    out = dict(bound="mfma", kernel="conv_mfma_kernel<KS,LOGW,MODE,NPT> (forward + dgrad launches)",
                achieved=f / s / 1e12, peak=PEAK_FP32_MATRIX_TFLOPS, unit="TFLOP/s",
-               frac=f / s / 1e12 / PEAK_FP32_MATRIX_TFLOPS, traffic=None, launches_per_step=n // steps,
+               frac=f / s / 1e12 / PEAK_FP32_MATRIX_TFLOPS, traffic=pmc_traffic("conv_mfma_kernel"),
+               launches_per_step=n // steps,
                avg_launch_us=s / n * 1e6, algorithmic_gflop_per_launch=f / n / 1e9)
     out["other_kernels"] = {k: dict(achieved_tflops=v[0] / v[1] / 1e12, launches_per_step=v[2] // steps,
                                     avg_launch_us=v[1] / v[2] * 1e6) for k, v in agg.items()}
