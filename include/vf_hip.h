@@ -88,6 +88,11 @@ int vf_p_sample_tail(const float* unet_out, const int* off, const float* y_t, co
                      float* weights /*|NULL*/, int B, int Cout, int HW, int maxV, int weighting, int clip,
                      void* stream);
 
+/* ---- optimizer step next to the path: torch.optim.Adam, experiment.py:118-120,293 ----
+ * desc = device int64 [ntensors][6] rows {p, g, exp_avg, exp_avg_sq, numel, first_block}, block = 1024 elems */
+int vf_adam_multi(const void* desc, int ntensors, long total_blocks, float lr, float beta1, float beta2, float eps,
+                  float bias_correction1, float bias_correction2, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -234,3 +234,24 @@ def test_p_sample_tail(dev):
     sd = {k: v.to(dev) for k, v in sched.items()}
     y, m, w2 = ops.p_sample_tail(out.to(dev), off, y_t.to(dev), z.to(dev), t.to(dev), sd, B, maxv, True, want_mean=True)
     assert rel(y, ref) < 1e-5 and rel(m, mean) < 1e-5 and rel(w2, w) < 1e-5
+
+
+def test_fused_adam_matches_torch_adam(dev):
+    from view_fusion_amd.optim import FusedAdam
+    g = torch.Generator().manual_seed(0)
+    shapes = [(64, 6, 3, 3), (6,), (320, 320, 3, 3), (1027,), (64, 64)]
+    pc = [torch.nn.Parameter(torch.randn(s, generator=g)) for s in shapes]
+    pg = [torch.nn.Parameter(p.detach().clone().to(dev)) for p in pc]
+    oc, og = torch.optim.Adam(pc, lr=1e-3), FusedAdam(pg, lr=1e-3)
+    for it in range(4):
+        for a, b in zip(pc, pg):
+            gr = torch.randn(a.shape, generator=g)
+            a.grad, b.grad = gr.clone(), gr.to(dev)
+        lr = 1e-3 * (it + 1)
+        for o in (oc, og):
+            o.param_groups[0]["lr"] = lr
+            o.step()
+    for a, b in zip(pc, pg):
+        assert rel(b, a) < 1e-6
+    sd = og.state_dict()
+    assert set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"} and float(sd["state"][0]["step"]) == 4
