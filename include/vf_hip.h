@@ -88,6 +88,9 @@ int vf_p_sample_tail(const float* unet_out, const int* off, const float* y_t, co
                      float* weights /*|NULL*/, int B, int Cout, int HW, int maxV, int weighting, int clip,
                      void* stream);
 
+/* eval metric next to the path: utils/metrics.py:6-8; out[b] = PSNR of image b (n floats each) */
+int vf_psnr(const float* generated, const float* target, float* out /*[B]*/, int B, int n, void* stream);
+
 /* ---- optimizer step next to the path: torch.optim.Adam, experiment.py:118-120,293 ----
  * desc = device int64 [ntensors][6] rows {p, g, exp_avg, exp_avg_sq, numel, first_block}, block = 1024 elems */
 int vf_adam_multi(const void* desc, int ntensors, long total_blocks, float lr, float beta1, float beta2, float eps,

@@ -186,3 +186,24 @@ def test_three_adam_steps_track_the_oracle(dev):
     moved = max(float((p.cpu() - q).abs().max()) for (k, p), q in
                 zip(vf.denoise_fn.state_dict().items(), make_unet(TINY, torch.device("cpu")).state_dict().values()))
     assert moved > 1e-4                                           # the weights really were updated
+
+
+def test_psnr_and_sampler_drivers(dev):
+    """§8(f) rows: PSNR kernel vs the reference formula; extrapolation (more views than trained on,
+    ragged 7..23) and the autoregressive rollout (view_count 1 -> k) run through generate()."""
+    from view_fusion_amd import drivers
+    g = torch.Generator().manual_seed(2)
+    a, b = torch.rand(5, 3, 16, 16, generator=g), torch.rand(5, 3, 16, 16, generator=g)
+    ref = 20 * torch.log10(1.0 / torch.sqrt(torch.mean((a - b) ** 2, dim=(1, 2, 3))))
+    got = drivers.compute_psnr(a.to(dev), b.to(dev))
+    assert float((got.cpu() - ref).abs().max()) < 1e-4
+    vf = make_vf(TINY, dict(schedule="linear", num_timesteps=10, linear_start=1e-4, linear_end=0.09), dev, True)
+    cond = torch.rand(2, 23, 3, 16, 16, generator=g).to(dev)
+    angle = torch.rand(2, 1, generator=g).to(dev)
+    ret, logit_arr, weight_arr, vc = drivers.extrapolate(vf, cond, angle, max_views=6, generator=g)
+    S, mx = int(vc.sum()), int(vc.max())
+    assert ret.shape == (2, 11, 3, 16, 16) and logit_arr.shape == (S, 10, 3, 16, 16)
+    assert weight_arr.shape == (2, 10, mx, 3, 16, 16) and 7 <= int(vc.min()) and mx <= 23
+    assert float((weight_arr.sum(dim=2) - 1).abs().max()) < 1e-5 and bool(torch.isfinite(ret).all())
+    orbit = drivers.autoregressive_rollout(vf, cond[:, 0], steps=4)
+    assert orbit.shape == (2, 4, 3, 16, 16) and bool(torch.isfinite(orbit).all())

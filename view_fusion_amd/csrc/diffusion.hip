@@ -9,8 +9,6 @@
 
 namespace {
 
-constexpr int MAXB_SCAN = 4096;
-
 __device__ __forceinline__ int sample_of_view(const int* __restrict__ off, int B, int v) {
     int lo = 0, hi = B;                       // find b with off[b] <= v < off[b+1]
     while (hi - lo > 1) {
@@ -54,10 +52,6 @@ __global__ void stack_views_kernel(const float4* __restrict__ y_cond, const floa
         o[n4 + i] = y;
     }
 }
-
-struct ComposeOut {
-    float4 nh;
-};
 
 // Composed noise for one float4 of (b, c, pixels): softmax over the sample's views of the
 // logits (channels 3..5) weighting the per-view noise (channels 0..2); or the plain mean.
@@ -260,6 +254,22 @@ __global__ void gather_level_kernel(const float* __restrict__ gammas, const long
     }
 }
 
+// psnr[b] = 20 log10(1 / sqrt(mean((a-b)^2)))  -- one workgroup per image (utils/metrics.py:6-8)
+__global__ __launch_bounds__(256) void psnr_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                   float* __restrict__ out, int n) {
+    __shared__ float red[4];
+    const float4* a4 = reinterpret_cast<const float4*>(a + (size_t)blockIdx.x * n);
+    const float4* b4 = reinterpret_cast<const float4*>(b + (size_t)blockIdx.x * n);
+    float s = 0.f;
+    for (int i = threadIdx.x; i < (n >> 2); i += 256) {
+        const float4 u = a4[i], v = b4[i];
+        const float dx = u.x - v.x, dy = u.y - v.y, dz = u.z - v.z, dw = u.w - v.w;
+        s += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+    }
+    s = block_sum<256>(s, red);
+    if (threadIdx.x == 0) out[blockIdx.x] = 20.0f * log10f(1.0f / sqrtf(s / (float)n));
+}
+
 inline int chunks_for(int n4) {
     int c = (n4 + 255) / 256;
     return c < 1 ? 1 : (c > 64 ? 64 : c);
@@ -268,6 +278,13 @@ inline int chunks_for(int n4) {
 }  // namespace
 
 extern "C" {
+
+int vf_psnr(const float* generated, const float* target, float* out, int B, int n, void* stream) {
+    if (B <= 0) return 0;
+    if (n & 3) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(psnr_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, generated, target, out, n);
+    VF_RETURN_LAST_ERROR();
+}
 
 int vf_gather_level(const float* gammas, const long long* t, const float* u, float* level, int B, void* stream) {
     if (B <= 0) return 0;

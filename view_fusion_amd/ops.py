@@ -548,3 +548,13 @@ def p_sample_tail(unet_out, off, y_t, z, t, sched, B, max_views, weighting, clip
               _ptr(sched["posterior_mean_coef2"]), _ptr(y_next), _ptr(mean), _ptr(wts), B, Cout, H * W, max_views,
               int(weighting), int(clip), _stream())
     return y_next, mean, wts
+
+
+def psnr(generated, target):
+    """Per-image PSNR (B,) of (B,C,H,W) tensors in [0,1]."""
+    generated, target = _c(generated), _c(target)
+    _check(generated, target)
+    B = generated.shape[0]
+    out = torch.empty(B, device=generated.device, dtype=torch.float32)
+    _lib.call("vf_psnr", _ptr(generated), _ptr(target), _ptr(out), B, generated[0].numel(), _stream())
+    return out
