@@ -51,6 +51,18 @@ int vf_conv_wgrad(const float* x, const float* dy, float* dw_oihw, float* ws, lo
                   int Cout, int H, int W, int KS, int mode, void* stream);
 int vf_sumpool2(const float* x, float* y, long n_out, int Wo, void* stream);
 
+/* fused Winograd F(2x2,3x3) path for stride-1 3x3 convs on 32x32 / 64x64 / 128x128 maps (forward and
+ * dgrad); modes 0 and 2 as above.  Pack layout differs from the direct kernel's. */
+int vf_wino_supported(int H, int W, int mode);
+int vf_wino_pack_sizes(int Cout, int Cin, long* fwd_floats, long* bwd_floats);
+int vf_wino_pack_weights(const float* w_oihw, float* u_fwd, float* u_bwd /*or NULL*/, int Cout, int Cin,
+                         void* stream);
+/* desc = device int64 [nlayers][8] rows {w, u_fwd, u_bwd, Cout, Cin, fwd_floats, bwd_floats, first_block} */
+int vf_wino_pack_weights_multi(const void* desc, int nlayers, long total_blocks, void* stream);
+int vf_wino_conv_fwd(const float* x, const float* u_packed, const float* bias, const float* view_bias,
+                     const float* residual, float* y, int S, int Cin, int Cout, int H, int W, int mode,
+                     void* stream);
+
 /* ---- batched GEMM + softmax : torch.einsum / torch.softmax / nn.Linear,
  *      unet.py:267-274 (attention), :29-31,165 (linears) ---- */
 int vf_bgemm(const float* A, const float* B, float* C, const float* bias /*[N]|NULL*/, int batch, int M, int N,

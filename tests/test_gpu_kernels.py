@@ -109,6 +109,19 @@ def test_conv_small_batch_split_k_forward(dev, Cin, Cout, Hin, KS, mode, S):
     test_conv_fwd_bwd(dev, Cin, Cout, Hin, KS, mode, S)
 
 
+@pytest.mark.parametrize("Cin,Cout,Hin,mode", [(64, 64, 64, "same"), (6, 64, 64, "same"), (64, 6, 64, "same"),
+                                               (192, 64, 64, "same"), (128, 128, 32, "same"), (320, 128, 32, "same"),
+                                               (128, 128, 32, "up2"), (192, 192, 16, "up2"), (32, 32, 32, "same")])
+def test_conv_winograd_path(dev, Cin, Cout, Hin, mode):
+    """Fused Winograd F(2x2,3x3) forward + dgrad (forced on; wgrad stays direct) vs CPU conv2d."""
+    from view_fusion_amd import ops
+    ops.FORCE_WINOGRAD = True
+    try:
+        test_conv_fwd_bwd(dev, Cin, Cout, Hin, 3, mode, 3)
+    finally:
+        ops.FORCE_WINOGRAD = False
+
+
 def test_conv_large_batch_split_k(dev):
     """S large enough that wgrad runs many pixel tiles per slice; odd S for the 8x8 two-image tiles."""
     from view_fusion_amd import ops

@@ -29,6 +29,11 @@ SIGNATURES = {
     "vf_conv_fwd_ws_floats": [_I, _I, _I, _I, _I, _I],
     "vf_conv_wgrad_ws_floats": [_I, _I, _I, _I, _I, _I],
     "vf_conv_wgrad": [_P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _P],
+    "vf_wino_supported": [_I, _I, _I],
+    "vf_wino_pack_sizes": [_I, _I, ctypes.POINTER(_L), ctypes.POINTER(_L)],
+    "vf_wino_pack_weights": [_P, _P, _P, _I, _I, _P],
+    "vf_wino_pack_weights_multi": [_P, _I, _L, _P],
+    "vf_wino_conv_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "vf_sumpool2": [_P, _P, _L, _I, _P],
     "vf_bgemm": [_P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _L, _L, _L, _L, _L, _F, _F, _P],
     "vf_attention_fwd": [_P, _P, _P, _I, _I, _I, _P],

@@ -174,55 +174,125 @@ def _packed(layer, force):
     return wf, wb
 
 
-def pack_all(root):
-    """Training forward: re-pack the weights of EVERY conv layer under `root` with one launch
-    (device-side descriptor table, rebuilt only if a parameter moved).  Each layer's fresh pack is
+WINOGRAD = True           # fused Winograd F(2x2,3x3) for stride-1 3x3 convs on large maps
+FORCE_WINOGRAD = False    # tests: take the Winograd path even when the grid would not fill the chip
+
+
+def use_winograd(S, Cout, H, W, KS, m):
+    """Winograd needs >= one 64-tile workgroup per CU (its kernel runs one workgroup per CU);
+    small batches (sampler) and small maps stay on the direct kernel (+ split-K)."""
+    if not WINOGRAD or KS != 3 or m not in (0, 2) or not _lib.load().vf_wino_supported(H, W, m):
+        return False
+    return FORCE_WINOGRAD or S * (H * W // 256) * ((Cout + 63) // 64) >= 256
+
+
+def _packed_wino(layer, force):
+    """Winograd-transformed packed weights (forward / dgrad) of a 3x3 layer; same caching rules as _packed."""
+    w = layer.weight
+    cache = getattr(layer, "_vf_wpack", None)
+    key = (w._version, w.data_ptr(), w.device)
+    if not force and cache is not None and cache[0] == key:
+        return cache[1], cache[2]
+    if force and cache is not None and getattr(layer, "_vf_wpack_fresh", False):
+        object.__setattr__(layer, "_vf_wpack_fresh", False)
+        return cache[1], cache[2]
+    Cout, Cin = w.shape[0], w.shape[1]
+    nf, nb = ctypes.c_long(), ctypes.c_long()
+    _lib.call("vf_wino_pack_sizes", Cout, Cin, ctypes.byref(nf), ctypes.byref(nb))
+    if cache is not None and cache[1].numel() == nf.value and cache[1].device == w.device:
+        uf, ub = cache[1], cache[2]
+    else:
+        uf = torch.empty(nf.value, device=w.device, dtype=torch.float32)
+        ub = torch.empty(nb.value, device=w.device, dtype=torch.float32)
+    wd = w.detach()
+    _check(wd)
+    _lib.call("vf_wino_pack_weights", _ptr(wd), _ptr(uf), _ptr(ub), Cout, Cin, _stream())
+    object.__setattr__(layer, "_vf_wpack", (key, uf, ub))
+    return uf, ub
+
+
+def pack_all(root, S=None):
+    """Training forward: re-pack the weights of EVERY conv layer under `root` with one launch per
+    format (device-side descriptor tables, rebuilt only if a parameter moved).  Layers annotated by
+    the UNet with their output size (`_vf_geom` = (H, mode)) that will take the Winograd path at
+    batch S get the transformed pack, all others the direct pack.  Each layer's fresh pack is
     consumed by its next training-mode conv2d call."""
     plan = getattr(root, "_vf_pack_plan", None)
     layers = plan[0] if plan is not None else [m for m in root.modules() if isinstance(m, torch.nn.Conv2d)]
     if not layers:
         return
     _check(layers[0].weight.detach())
-    key = tuple(l.weight.data_ptr() for l in layers)
+
+    def wants_wino(l):
+        geom = getattr(l, "_vf_geom", None)
+        if geom is None or S is None:
+            return False
+        return use_winograd(S, l.weight.shape[0], geom[0], geom[0], l.weight.shape[2], _MODES[geom[1]])
+
+    key = tuple((l.weight.data_ptr(), wants_wino(l)) for l in layers)
     if plan is None or plan[1] != key:
-        rows, first = [], 0
-        for l in layers:
+        dev = layers[0].weight.device
+        rows_d, rows_w, first_d, first_w = [], [], 0, 0
+        for l, (_, wino) in zip(layers, key):
             w = l.weight
             Cout, Cin, KS, _ = w.shape
             nf, nb = ctypes.c_long(), ctypes.c_long()
-            _lib.call("vf_conv_pack_sizes", Cout, Cin, KS, ctypes.byref(nf), ctypes.byref(nb))
-            wf = torch.empty(nf.value, device=w.device, dtype=torch.float32)
-            wb = torch.empty(nb.value, device=w.device, dtype=torch.float32)
-            object.__setattr__(l, "_vf_pack", (None, wf, wb))
-            rows.append([w.data_ptr(), wf.data_ptr(), wb.data_ptr(), Cout, Cin, KS, nf.value, nb.value, first])
-            first += (nf.value + nb.value + 255) // 256
-        desc = torch.tensor(rows, dtype=torch.int64).to(layers[0].weight.device)
-        plan = (layers, key, desc, first)
+            if wino:
+                _lib.call("vf_wino_pack_sizes", Cout, Cin, ctypes.byref(nf), ctypes.byref(nb))
+            else:
+                _lib.call("vf_conv_pack_sizes", Cout, Cin, KS, ctypes.byref(nf), ctypes.byref(nb))
+            pf = torch.empty(nf.value, device=dev, dtype=torch.float32)
+            pb = torch.empty(nb.value, device=dev, dtype=torch.float32)
+            nblk = (nf.value + nb.value + 255) // 256
+            if wino:
+                object.__setattr__(l, "_vf_wpack", (None, pf, pb))
+                rows_w.append([w.data_ptr(), pf.data_ptr(), pb.data_ptr(), Cout, Cin, nf.value, nb.value, first_w])
+                first_w += nblk
+            else:
+                object.__setattr__(l, "_vf_pack", (None, pf, pb))
+                rows_d.append([w.data_ptr(), pf.data_ptr(), pb.data_ptr(), Cout, Cin, KS, nf.value, nb.value, first_d])
+                first_d += nblk
+        desc_d = torch.tensor(rows_d, dtype=torch.int64).to(dev) if rows_d else None
+        desc_w = torch.tensor(rows_w, dtype=torch.int64).to(dev) if rows_w else None
+        plan = (layers, key, (desc_d, len(rows_d), first_d), (desc_w, len(rows_w), first_w))
         object.__setattr__(root, "_vf_pack_plan", plan)
-    _lib.call("vf_conv_pack_weights_multi", ctypes.c_void_p(plan[2].data_ptr()), len(layers), plan[3], _stream())
-    for l in layers:
+    (desc_d, nd, blk_d), (desc_w, nw, blk_w) = plan[2], plan[3]
+    if nd:
+        _lib.call("vf_conv_pack_weights_multi", ctypes.c_void_p(desc_d.data_ptr()), nd, blk_d, _stream())
+    if nw:
+        _lib.call("vf_wino_pack_weights_multi", ctypes.c_void_p(desc_w.data_ptr()), nw, blk_w, _stream())
+    for l, (_, wino) in zip(layers, plan[1]):
         w = l.weight
-        c = l._vf_pack
-        object.__setattr__(l, "_vf_pack", ((w._version, w.data_ptr(), w.device), c[1], c[2]))
-        object.__setattr__(l, "_vf_pack_fresh", True)
+        attr = "_vf_wpack" if wino else "_vf_pack"
+        c = getattr(l, attr)
+        object.__setattr__(l, attr, ((w._version, w.data_ptr(), w.device), c[1], c[2]))
+        object.__setattr__(l, attr + "_fresh", True)
 
 
 class _Conv2dFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, view_bias, residual, layer, mode, training):
         _check(x, bias, view_bias, residual)
-        wf, wb = _packed(layer, force=training)
         S, Cin, Hi, Wi = x.shape
         Cout, _, KS, _ = weight.shape
         m = _MODES[mode]
         H, W = (Hi // 2, Wi // 2) if m == 1 else ((Hi * 2, Wi * 2) if m == 2 else (Hi, Wi))
         y = torch.empty(S, Cout, H, W, device=x.device, dtype=torch.float32)
         flops = 2.0 * S * Cout * Cin * KS * KS * H * W
-        ws, nws = _conv_ws(x.device, S, Cin, Cout, H, W, KS)
-        _launch("conv_fwd", flops, "vf_conv_fwd", _ptr(x), _ptr(wf), _ptr(bias), _ptr(view_bias), _ptr(residual),
-                _ptr(y), _ptr(ws), nws, S, Cin, Cout, H, W, KS, m, _stream(), tag=(Cin, Cout, H, KS, m))
+        wino = use_winograd(S, Cout, H, W, KS, m)
+        if wino:
+            wf, wb = _packed_wino(layer, force=training)
+            _launch("conv_fwd", flops, "vf_wino_conv_fwd", _ptr(x), _ptr(wf), _ptr(bias), _ptr(view_bias),
+                    _ptr(residual), _ptr(y), S, Cin, Cout, H, W, m, _stream(), tag=(Cin, Cout, H, KS, m))
+        else:
+            wf, wb = _packed(layer, force=training)
+            ws, nws = _conv_ws(x.device, S, Cin, Cout, H, W, KS)
+            _launch("conv_fwd", flops, "vf_conv_fwd", _ptr(x), _ptr(wf), _ptr(bias), _ptr(view_bias),
+                    _ptr(residual), _ptr(y), _ptr(ws), nws, S, Cin, Cout, H, W, KS, m, _stream(),
+                    tag=(Cin, Cout, H, KS, m))
         ctx.flops, ctx.tag = flops, (Cin, Cout, H, KS, m)
         ctx.save_for_backward(x)
+        ctx.wino = wino
         ctx.wb, ctx.m, ctx.KS, ctx.Cout = wb, m, KS, Cout
         ctx.has = (bias is not None, view_bias is not None, residual is not None)
         return y
@@ -236,7 +306,16 @@ class _Conv2dFn(torch.autograd.Function):
         KS, m = ctx.KS, ctx.m
         st = _stream()
         dx = dw = db = dvb = dres = None
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and ctx.wino:      # Winograd dgrad (dy and dx have the conv's output size)
+            dfull = torch.empty(S, Cin, H, W, device=x.device, dtype=torch.float32)
+            _launch("conv_dgrad", ctx.flops, "vf_wino_conv_fwd", _ptr(dy), _ptr(ctx.wb), None, None, None,
+                    _ptr(dfull), S, Cout, Cin, H, W, 0, st, tag=ctx.tag)
+            if m == 2:                                 # upsample + conv: 2x2 sum-pool back to the source size
+                dx = torch.empty_like(x)
+                _lib.call("vf_sumpool2", _ptr(dfull), _ptr(dx), dx.numel(), Wi, st)
+            else:
+                dx = dfull
+        elif ctx.needs_input_grad[0]:
             if m == 0:
                 dx = torch.empty_like(x)
                 ws, nws = _conv_ws(x.device, S, Cout, Cin, H, W, KS)

@@ -142,12 +142,48 @@ class UNet(nn.Module):
         self.final_conv = _norm_act_conv(ch, out_channel if out_channel is not None else in_channel,
                                          norm_groups)
         self.norm_groups = norm_groups
+        self._annotate_geometry(image_size)
+
+    def _annotate_geometry(self, image_size):
+        """Record every conv layer's OUTPUT size and mode (`_vf_geom`) so that the per-step weight
+        packing knows which layers take the Winograd format."""
+        def mark(conv, res, mode="same"):
+            object.__setattr__(conv, "_vf_geom", (res, mode))
+
+        def mark_block(blk, res):
+            rb = blk.res_block
+            mark(rb.block1["block"]["3"], res)
+            mark(rb.block2["block"]["3"], res)
+            if isinstance(rb.res_conv, nn.Conv2d):
+                mark(rb.res_conv, res)
+            if blk.with_attn:
+                mark(blk.attn.qkv, res)
+                mark(blk.attn.out, res)
+
+        res = image_size
+        for layer in self.downs:
+            if isinstance(layer, _ResAttnBlock):
+                mark_block(layer, res)
+            elif isinstance(layer, _Resample):
+                res //= 2
+                mark(layer.conv, res, "down2")
+            else:
+                mark(layer, res)
+        for layer in self.mid:
+            mark_block(layer, res)
+        for layer in self.ups:
+            if isinstance(layer, _ResAttnBlock):
+                mark_block(layer, res)
+            else:
+                res *= 2
+                mark(layer.conv, res, "up2")
+        mark(self.final_conv["block"]["3"], res)
 
     def forward(self, x, angle, time):
         """x (S,Cin,H,W), angle (S,1), time = noise level (S,1)  ->  (S,Cout,H,W)."""
         from . import ops
         if torch.is_grad_enabled() and self.final_conv["block"]["3"].weight.requires_grad:
-            ops.pack_all(self)          # training: all 103 conv layers re-packed by one launch
+            ops.pack_all(self, x.shape[0])   # training: all 103 conv layers re-packed (one launch per format)
         mlp = self.noise_level_mlp
         pe = ops.sincos_embedding(time, angle, self.inner_channel)                  # (S,inner)
         emb = ops.linear(pe, mlp["0"].weight, mlp["0"].bias)
