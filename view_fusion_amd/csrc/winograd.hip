@@ -111,58 +111,66 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(WinoArgs a) {
 #define VF_USTORE(I, BUF) *reinterpret_cast<float4*>(Ul + (BUF) * USZ + 4 * (tid + (I) * 256)) = ur##I
 #define VF_ULOAD_ALL(C) { VF_ULOAD(0, C); VF_ULOAD(1, C); VF_ULOAD(2, C); VF_ULOAD(3, C); VF_ULOAD(4, C); VF_ULOAD(5, C); VF_ULOAD(6, C); VF_ULOAD(7, C); }
 #define VF_USTORE_ALL(BUF) { VF_USTORE(0, BUF); VF_USTORE(1, BUF); VF_USTORE(2, BUF); VF_USTORE(3, BUF); VF_USTORE(4, BUF); VF_USTORE(5, BUF); VF_USTORE(6, BUF); VF_USTORE(7, BUF); }
-    auto load_x1 = [&](int e, int c) -> float4 {
+    // per-thread staging descriptors of the raw input rows, fixed over the chunk loop: global offset
+    // (within channel 0 of this chunk), validity and LDS destination of each float4 this thread moves
+    constexpr int NXR_ = NXF + (XT ? 1 : 0);
+    int xgo[NXR_], xlo[NXR_];
+    bool xok[NXR_];
+    int xci[NXR_];
+#pragma unroll
+    for (int i = 0; i < NXR_; ++i) {
+        const int e = tid + i * 256;
         const int q = e % G::Q;
         const int t1 = e / G::Q;
         const int pr = t1 % G::PH, ci = t1 / G::PH;
-        return wino_load4<G, MODE>(a.x, a.S, a.Cin, s, c * WCK + ci, r0, pr, q);
-    };
-    auto load_x = [&](int i, int c) {                        // i == NXF -> ragged tail
-        if (i < NXF) xreg[i] = load_x1(tid + i * 256, c);
-        else if (XT && tid + NXF * 256 < NX4) xtail = load_x1(tid + NXF * 256, c);
-    };
-    auto store_x1 = [&](int e, const float4& v, int buf) {
-        const int q = e % G::Q;
-        const int t1 = e / G::Q;                             // ci*PH + pr
-        *reinterpret_cast<float4*>(Pl + buf * PSZ + t1 * G::PW + 4 * q + 4) = v;
+        const int uy = r0 + pr - 1;
+        xok[i] = e < NX4 && s < a.S && uy >= 0 && uy < G::H;
+        xci[i] = ci;
+        xgo[i] = ci * (G::SH * G::SW) + (MODE == 0 ? uy * G::SW + 4 * q : (uy >> 1) * G::SW + 2 * q);
+        xlo[i] = t1 * G::PW + 4 * q + 4;
+    }
+    const float* xsrc = a.x + (size_t)s * a.Cin * (G::SH * G::SW);
+    auto load_x = [&](int i, int c) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (xok[i] && c * WCK + xci[i] < a.Cin) {
+            const float* p = xsrc + (size_t)c * WCK * (G::SH * G::SW) + xgo[i];
+            if (MODE == 0) v = *reinterpret_cast<const float4*>(p);
+            else { const float2 t = *reinterpret_cast<const float2*>(p); v = make_float4(t.x, t.x, t.y, t.y); }
+        }
+        if (i < NXF) xreg[i < NXF ? i : 0] = v; else xtail = v;
     };
     auto store_x = [&](int i, int buf) {
-        if (i < NXF) store_x1(tid + i * 256, xreg[i], buf);
-        else if (XT && tid + NXF * 256 < NX4) store_x1(tid + NXF * 256, xtail, buf);
+        if (tid + i * 256 < NX4) *reinterpret_cast<float4*>(Pl + buf * PSZ + xlo[i]) = i < NXF ? xreg[i < NXF ? i : 0] : xtail;
     };
-    constexpr int NXR = NXF + (XT ? 1 : 0);
+    constexpr int NXR = NXR_;
 
     // input transform of one 4x4 window (B^T d B), split in a read half and a write half
     float d[2][16];
-    auto win_ptr = [&](int it, int buf) -> const float* {
+    int wpo[2], wvo[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
         const int idx = tid + 256 * it;
         const int tl = idx & 63, ci = idx >> 6;
-        return Pl + buf * PSZ + ci * G::PS + (2 * (tl / G::TW)) * G::PW + 2 * (tl % G::TW) + 3;
+        wpo[it] = ci * G::PS + (2 * (tl / G::TW)) * G::PW + 2 * (tl % G::TW) + 3;
+        wvo[it] = ci * WTT + tl;
+    }
+    auto win_read_row = [&](int it, int r, int buf) {        // one row of the 4x4 window
+        const float* p = Pl + buf * PSZ + wpo[it] + r * G::PW;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) d[it][r * 4 + c] = p[c];
     };
-    auto win_read = [&](int it, int half, int buf) {       // rows 2*half, 2*half+1 of the window
-        const float* p = win_ptr(it, buf) + 2 * half * G::PW;
+    auto win_write_row = [&](int it, int r, int buf) {       // one row of V = B^T d B
+        float* vo = Vl + buf * VSZ + wvo[it];
+        float t[4];
 #pragma unroll
-        for (int r = 0; r < 2; ++r)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) d[it][(2 * half + r) * 4 + c] = p[r * G::PW + c];
-    };
-    auto win_write = [&](int it, int half, int buf) {      // output rows 2*half, 2*half+1 of V
-        const int idx = tid + 256 * it;
-        float* vo = Vl + buf * VSZ + (idx >> 6) * WTT + (idx & 63);
-#pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-            const int r = 2 * half + rr;
-            float t[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const float d0 = d[it][c], d1 = d[it][4 + c], d2 = d[it][8 + c], d3 = d[it][12 + c];
-                t[c] = r == 0 ? d0 - d2 : (r == 1 ? d1 + d2 : (r == 2 ? d2 - d1 : d1 - d3));
-            }
-            vo[(4 * r + 0) * WCK * WTT] = t[0] - t[2];
-            vo[(4 * r + 1) * WCK * WTT] = t[1] + t[2];
-            vo[(4 * r + 2) * WCK * WTT] = t[2] - t[1];
-            vo[(4 * r + 3) * WCK * WTT] = t[1] - t[3];
+        for (int c = 0; c < 4; ++c) {
+            const float d0 = d[it][c], d1 = d[it][4 + c], d2 = d[it][8 + c], d3 = d[it][12 + c];
+            t[c] = r == 0 ? d0 - d2 : (r == 1 ? d1 + d2 : (r == 2 ? d2 - d1 : d1 - d3));
         }
+        vo[(4 * r + 0) * WCK * WTT] = t[0] - t[2];
+        vo[(4 * r + 1) * WCK * WTT] = t[1] + t[2];
+        vo[(4 * r + 2) * WCK * WTT] = t[2] - t[1];
+        vo[(4 * r + 3) * WCK * WTT] = t[1] - t[3];
     };
 
     f32x16 acc[16];
@@ -186,8 +194,10 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(WinoArgs a) {
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
-        win_read(it, 0, 0); win_read(it, 1, 0);
-        win_write(it, 0, 0); win_write(it, 1, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) win_read_row(it, r, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) win_write_row(it, r, 0);
     }
     if (nch > 1) VF_ULOAD_ALL(1);
     if (nch > 2) {
@@ -216,39 +226,41 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(WinoArgs a) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) b_nxt[e] = vb[(k + 1) * WCK * WTT + e * WTT];
             }
-            // ---- side work of this slice, issued in the gaps between the MFMAs ----
+            // ---- side work of this slice (a dozen light instructions), issued in the MFMA gaps ----
 #if defined(VF_WINO_ABL) && (VF_WINO_ABL & 2)
             const bool has1 = false;           // shadow: no transform / U store side work
 #endif
-            if (k == 0 && has1) { win_read(0, 0, nxt); win_read(0, 1, nxt); }
-            if (k == 1 && has1) { VF_USTORE(0, nxt); VF_USTORE(1, nxt); VF_USTORE(2, nxt); VF_USTORE(3, nxt); }
-            if (k == 2 && has1) { VF_USTORE(4, nxt); VF_USTORE(5, nxt); VF_USTORE(6, nxt); VF_USTORE(7, nxt); }
-            if (k == 3 && has2) {
-#pragma unroll
-                for (int i = 0; i < NXR; ++i) store_x(i, cur);       // rows of chunk c+2 -> the buffer chunk c used
+            if (has1) {
+                if (k < 4) win_read_row(0, k, nxt);                       // window 0: rows of chunk c+1
+                if (k == 0) { VF_USTORE(0, nxt); VF_USTORE(1, nxt); }
+                if (k == 1) { VF_USTORE(2, nxt); VF_USTORE(3, nxt); }
+                if (k == 2) { VF_USTORE(4, nxt); VF_USTORE(5, nxt); }
+                if (k == 3) { VF_USTORE(6, nxt); VF_USTORE(7, nxt); }
+                if (k >= 4 && k < 8) { win_write_row(0, k - 4, nxt); win_read_row(1, k - 4, nxt); }
+                if (k >= 8 && k < 12) win_write_row(1, k - 8, nxt);
             }
-            if (k == 4 && has1) win_write(0, 0, nxt);
-            if (k == 5 && has1) win_write(0, 1, nxt);
-            if (k == 6 && has1) { win_read(1, 0, nxt); win_read(1, 1, nxt); }
+            if (k == 4 && has2) {
+#pragma unroll
+                for (int i = 0; i < NXR; ++i) store_x(i, cur);           // rows of chunk c+2 -> buffer of chunk c
+            }
 #if defined(VF_WINO_ABL) && (VF_WINO_ABL & 1)
             if (false) {
 #else
             if (has2) {
 #endif
-                if (k == 4) VF_ULOAD(0, c + 2);
-                if (k == 5) VF_ULOAD(1, c + 2);
-                if (k == 6) VF_ULOAD(2, c + 2);
-                if (k == 7) VF_ULOAD(3, c + 2);
-                if (k == 8) VF_ULOAD(4, c + 2);
-                if (k == 9) VF_ULOAD(5, c + 2);
-                if (k == 10) VF_ULOAD(6, c + 2);
-                if (k == 11) VF_ULOAD(7, c + 2);
+                // one global load per slice: bursts stall at issue (measured: 2 per slice = -8 %)
+                if (k == 5) VF_ULOAD(0, c + 2);
+                if (k == 6) VF_ULOAD(1, c + 2);
+                if (k == 7) VF_ULOAD(2, c + 2);
+                if (k == 8) VF_ULOAD(3, c + 2);
+                if (k == 9) VF_ULOAD(4, c + 2);
+                if (k == 10) VF_ULOAD(5, c + 2);
+                if (k == 11) VF_ULOAD(6, c + 2);
+                if (k == 12) VF_ULOAD(7, c + 2);
             }
 #if !defined(VF_WINO_ABL) || !(VF_WINO_ABL & 1)
-            if (k >= 12 && k < 12 + NXR && has3) load_x(k - 12, c + 3);
+            if (k >= 13 && k < 13 + NXR && has3) load_x(k - 13, c + 3);
 #endif
-            if (k == 8 && has1) win_write(1, 0, nxt);
-            if (k == 9 && has1) win_write(1, 1, nxt);
             __builtin_amdgcn_sched_barrier(0);
             acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.x, b_cur[0], acc[k], 0, 0, 0);
             acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.y, b_cur[1], acc[k], 0, 0, 0);
