@@ -64,28 +64,34 @@ __device__ __forceinline__ float4 wino_load4(const float* __restrict__ x, int S,
     return v;
 }
 
+// Workgroup = 8 waves (two per SIMD): wave (cw, tw, kh) owns 32 channels x 32 tiles x the 8 slices of
+// Winograd rows {2kh, 2kh+1} = 128 accumulators.  The two waves of a SIMD are the two row halves of
+// the same block, so while one issues its staging / transform instructions the other keeps the
+// matrix pipe busy.  The output transform is linear in the rows, so each half produces a partial
+// 2x2 tile and the halves are summed through LDS once, in the epilogue.
 template <int LOGW, int MODE>
-__global__ __launch_bounds__(256, 1) void wino_conv_kernel(WinoArgs a) {
+__global__ __launch_bounds__(512, 2) void wino_conv_kernel(WinoArgs a) {
     using G = WGeo<LOGW, MODE>;
-    constexpr int NU4 = 16 * WTCO * 2;                   // float4 per U chunk (8 per thread)
-    constexpr int NUR = NU4 / 256;
+    constexpr int NT_ = 512;
+    constexpr int NU4 = 16 * WTCO * 2;                   // float4 per U chunk
+    constexpr int NUR = NU4 / NT_;                       // 4 per thread
     constexpr int NX4 = WCK * G::PH * G::Q;
-    constexpr int NXF = NX4 / 256;
-    constexpr bool XT = (NX4 % 256) != 0;
+    constexpr int NXR = (NX4 + NT_ - 1) / NT_;           // 1-2 per thread (tail predicated)
     constexpr int USZ = 16 * WTCO * WCK;                 // unpadded [k][co][ci 8] (2-way b128 conflict, cheap)
     constexpr int VSZ = 16 * WCK * WTT;
     constexpr int PSZ = WCK * G::PS;
+    static_assert(NUR == 4, "U staging assumes 4 float4 per thread");
 
     // Everything is double buffered so that ONE barrier per chunk suffices: while the MFMAs of chunk c
-    // read U[c&1] / V[c&1], the same waves (in the issue gaps between MFMAs) write U(c+1), the raw
-    // rows of chunk c+2, and transform the rows of chunk c+1 into V[(c+1)&1].
+    // read U[c&1] / V[c&1], the waves also write U(c+1), the raw rows of chunk c+2, and transform
+    // the rows of chunk c+1 into V[(c+1)&1].
     __shared__ __attribute__((aligned(16))) float lds[2 * USZ + 2 * VSZ + 2 * PSZ];
     float* const Ul = lds;
     float* const Vl = lds + 2 * USZ;
     float* const Pl = lds + 2 * USZ + 2 * VSZ;
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int cw = wid & 1, tw = wid >> 1;
+    const int cw = wid & 1, tw = (wid >> 1) & 1, kh = wid >> 2;
     const int li = lane & 31, lh = lane >> 5;
     const int ncot = a.CoutP / WTCO;
     const unsigned logical = xcd_remap(blockIdx.x, gridDim.x);
@@ -99,72 +105,65 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(WinoArgs a) {
 #ifdef VF_CONV_STAMPS   // diagnostic build only (tools/wino_stamps.py)
     long long st_[2] = {clock64(), 0}, rt0_ = wall_clock64();
 #endif
-    for (int i = tid; i < 2 * PSZ; i += 256) Pl[i] = 0.f;    // halo columns stay zero in both buffers
+    for (int i = tid; i < 2 * PSZ; i += NT_) Pl[i] = 0.f;    // halo columns stay zero in both buffers
 
     const float* usrc = a.u + (size_t)cot * nch * USZ;
     // named registers + macros (not arrays behind lambdas: those end up in scratch memory)
-    static_assert(NUR == 8, "U staging assumes 8 float4 per thread");
-    float4 ur0, ur1, ur2, ur3, ur4, ur5, ur6, ur7;
-    float4 xreg[NXF > 0 ? NXF : 1];
-    float4 xtail = make_float4(0.f, 0.f, 0.f, 0.f);
-#define VF_ULOAD(I, C) ur##I = *reinterpret_cast<const float4*>(usrc + (size_t)(C) * USZ + 4 * (tid + (I) * 256))
-#define VF_USTORE(I, BUF) *reinterpret_cast<float4*>(Ul + (BUF) * USZ + 4 * (tid + (I) * 256)) = ur##I
-#define VF_ULOAD_ALL(C) { VF_ULOAD(0, C); VF_ULOAD(1, C); VF_ULOAD(2, C); VF_ULOAD(3, C); VF_ULOAD(4, C); VF_ULOAD(5, C); VF_ULOAD(6, C); VF_ULOAD(7, C); }
-#define VF_USTORE_ALL(BUF) { VF_USTORE(0, BUF); VF_USTORE(1, BUF); VF_USTORE(2, BUF); VF_USTORE(3, BUF); VF_USTORE(4, BUF); VF_USTORE(5, BUF); VF_USTORE(6, BUF); VF_USTORE(7, BUF); }
-    // per-thread staging descriptors of the raw input rows, fixed over the chunk loop: global offset
-    // (within channel 0 of this chunk), validity and LDS destination of each float4 this thread moves
-    constexpr int NXR_ = NXF + (XT ? 1 : 0);
-    int xgo[NXR_], xlo[NXR_];
-    bool xok[NXR_];
-    int xci[NXR_];
+    float4 ur0, ur1, ur2, ur3;
+    float4 xr0 = make_float4(0.f, 0.f, 0.f, 0.f), xr1 = xr0;
+#define VF_ULOAD(I, C) ur##I = *reinterpret_cast<const float4*>(usrc + (size_t)(C) * USZ + 4 * (tid + (I) * NT_))
+#define VF_USTORE(I, BUF) *reinterpret_cast<float4*>(Ul + (BUF) * USZ + 4 * (tid + (I) * NT_)) = ur##I
+#define VF_ULOAD_ALL(C) { VF_ULOAD(0, C); VF_ULOAD(1, C); VF_ULOAD(2, C); VF_ULOAD(3, C); }
+#define VF_USTORE_ALL(BUF) { VF_USTORE(0, BUF); VF_USTORE(1, BUF); VF_USTORE(2, BUF); VF_USTORE(3, BUF); }
+
+    // per-thread staging descriptors of the raw input rows, fixed over the chunk loop
+    int xgo[2], xlo[2], xci[2];
+    bool xok[2];
 #pragma unroll
-    for (int i = 0; i < NXR_; ++i) {
-        const int e = tid + i * 256;
+    for (int i = 0; i < 2; ++i) {
+        const int e = tid + i * NT_;
         const int q = e % G::Q;
         const int t1 = e / G::Q;
         const int pr = t1 % G::PH, ci = t1 / G::PH;
         const int uy = r0 + pr - 1;
-        xok[i] = e < NX4 && s < a.S && uy >= 0 && uy < G::H;
+        xok[i] = i < NXR && e < NX4 && s < a.S && uy >= 0 && uy < G::H;
         xci[i] = ci;
         xgo[i] = ci * (G::SH * G::SW) + (MODE == 0 ? uy * G::SW + 4 * q : (uy >> 1) * G::SW + 2 * q);
         xlo[i] = t1 * G::PW + 4 * q + 4;
     }
     const float* xsrc = a.x + (size_t)s * a.Cin * (G::SH * G::SW);
-    auto load_x = [&](int i, int c) {
+    auto fetch_x = [&](int i, int c) -> float4 {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (xok[i] && c * WCK + xci[i] < a.Cin) {
             const float* p = xsrc + (size_t)c * WCK * (G::SH * G::SW) + xgo[i];
             if (MODE == 0) v = *reinterpret_cast<const float4*>(p);
             else { const float2 t = *reinterpret_cast<const float2*>(p); v = make_float4(t.x, t.x, t.y, t.y); }
         }
-        if (i < NXF) xreg[i < NXF ? i : 0] = v; else xtail = v;
+        return v;
     };
-    auto store_x = [&](int i, int buf) {
-        if (tid + i * 256 < NX4) *reinterpret_cast<float4*>(Pl + buf * PSZ + xlo[i]) = i < NXF ? xreg[i < NXF ? i : 0] : xtail;
-    };
-    constexpr int NXR = NXR_;
-
-    // input transform of one 4x4 window (B^T d B), split in a read half and a write half
-    float d[2][16];
-    int wpo[2], wvo[2];
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const int idx = tid + 256 * it;
-        const int tl = idx & 63, ci = idx >> 6;
-        wpo[it] = ci * G::PS + (2 * (tl / G::TW)) * G::PW + 2 * (tl % G::TW) + 3;
-        wvo[it] = ci * WTT + tl;
+#define VF_XLOAD(C) { xr0 = fetch_x(0, (C)); if (NXR > 1) xr1 = fetch_x(1, (C)); }
+#define VF_XSTORE(BUF)                                                                                  \
+    {                                                                                                   \
+        if (tid < NX4) *reinterpret_cast<float4*>(Pl + (BUF) * PSZ + xlo[0]) = xr0;                      \
+        if (NXR > 1 && tid + NT_ < NX4) *reinterpret_cast<float4*>(Pl + (BUF) * PSZ + xlo[1]) = xr1;     \
     }
-    auto win_read_row = [&](int it, int r, int buf) {        // one row of the 4x4 window
-        const float* p = Pl + buf * PSZ + wpo[it] + r * G::PW;
+
+    // input transform of this thread's 4x4 window (B^T d B): 512 windows = 8 channels x 64 tiles
+    float d[16];
+    const int wtl = tid & 63, wci = tid >> 6;
+    const int wpo = wci * G::PS + (2 * (wtl / G::TW)) * G::PW + 2 * (wtl % G::TW) + 3;
+    const int wvo = wci * WTT + wtl;
+    auto win_read_row = [&](int r, int buf) {
+        const float* p = Pl + buf * PSZ + wpo + r * G::PW;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) d[it][r * 4 + c] = p[c];
+        for (int c = 0; c < 4; ++c) d[r * 4 + c] = p[c];
     };
-    auto win_write_row = [&](int it, int r, int buf) {       // one row of V = B^T d B
-        float* vo = Vl + buf * VSZ + wvo[it];
+    auto win_write_row = [&](int r, int buf) {
+        float* vo = Vl + buf * VSZ + wvo;
         float t[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const float d0 = d[it][c], d1 = d[it][4 + c], d2 = d[it][8 + c], d3 = d[it][12 + c];
+            const float d0 = d[c], d1 = d[4 + c], d2 = d[8 + c], d3 = d[12 + c];
             t[c] = r == 0 ? d0 - d2 : (r == 1 ? d1 + d2 : (r == 2 ? d2 - d1 : d1 - d3));
         }
         vo[(4 * r + 0) * WCK * WTT] = t[0] - t[2];
@@ -173,41 +172,31 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(WinoArgs a) {
         vo[(4 * r + 3) * WCK * WTT] = t[1] - t[3];
     };
 
-    f32x16 acc[16];
+    f32x16 acc[8];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) acc[k] = (f32x16){0};
+    for (int k = 0; k < 8; ++k) acc[k] = (f32x16){0};
 
     // ---- prologue: U(0), rows(0), rows(1) staged; V(0) transformed; U(1), rows(2) in flight
     VF_ULOAD_ALL(0);
-#pragma unroll
-    for (int i = 0; i < NXR; ++i) load_x(i, 0);
+    VF_XLOAD(0);
     __syncthreads();                                      // zero fill done
     VF_USTORE_ALL(0);
-#pragma unroll
-    for (int i = 0; i < NXR; ++i) store_x(i, 0);
+    VF_XSTORE(0);
     if (nch > 1) {
-#pragma unroll
-        for (int i = 0; i < NXR; ++i) load_x(i, 1);
-#pragma unroll
-        for (int i = 0; i < NXR; ++i) store_x(i, 1);
+        VF_XLOAD(1);
+        VF_XSTORE(1);
     }
     __syncthreads();
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
+    for (int r = 0; r < 4; ++r) win_read_row(r, 0);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) win_read_row(it, r, 0);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) win_write_row(it, r, 0);
-    }
+    for (int r = 0; r < 4; ++r) win_write_row(r, 0);
     if (nch > 1) VF_ULOAD_ALL(1);
-    if (nch > 2) {
-#pragma unroll
-        for (int i = 0; i < NXR; ++i) load_x(i, 2);
-    }
+    if (nch > 2) VF_XLOAD(2);
     __syncthreads();
 
-    const int uoff = (cw * 32 + li) * WCK + 4 * lh;
-    const int voff = 4 * lh * WTT + tw * 32 + li;
+    const int uoff = 8 * kh * WTCO * WCK + (cw * 32 + li) * WCK + 4 * lh;
+    const int voff = 8 * kh * WCK * WTT + 4 * lh * WTT + tw * 32 + li;
     for (int c = 0; c < nch; ++c) {
         const int cur = c & 1, nxt = cur ^ 1;
         const bool has1 = c + 1 < nch, has2 = c + 2 < nch, has3 = c + 3 < nch;
@@ -218,56 +207,36 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(WinoArgs a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) b_cur[e] = vb[e * WTT];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
+        for (int k = 0; k < 8; ++k) {
             float4 a_nxt = a_cur;
             float b_nxt[4];
-            if (k + 1 < 16) {
+            if (k + 1 < 8) {
                 a_nxt = *reinterpret_cast<const float4*>(ub + (k + 1) * WTCO * WCK);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) b_nxt[e] = vb[(k + 1) * WCK * WTT + e * WTT];
             }
-            // ---- side work of this slice (a dozen light instructions), issued in the MFMA gaps ----
-#if defined(VF_WINO_ABL) && (VF_WINO_ABL & 2)
-            const bool has1 = false;           // shadow: no transform / U store side work
-#endif
+            // ---- side work of this slice, issued in the MFMA gaps (the partner wave covers the rest)
             if (has1) {
-                if (k < 4) win_read_row(0, k, nxt);                       // window 0: rows of chunk c+1
+                if (k < 4) win_read_row(k, nxt);                          // rows of chunk c+1
                 if (k == 0) { VF_USTORE(0, nxt); VF_USTORE(1, nxt); }
                 if (k == 1) { VF_USTORE(2, nxt); VF_USTORE(3, nxt); }
-                if (k == 2) { VF_USTORE(4, nxt); VF_USTORE(5, nxt); }
-                if (k == 3) { VF_USTORE(6, nxt); VF_USTORE(7, nxt); }
-                if (k >= 4 && k < 8) { win_write_row(0, k - 4, nxt); win_read_row(1, k - 4, nxt); }
-                if (k >= 8 && k < 12) win_write_row(1, k - 8, nxt);
+                if (k >= 4) win_write_row(k - 4, nxt);
             }
-            if (k == 4 && has2) {
-#pragma unroll
-                for (int i = 0; i < NXR; ++i) store_x(i, cur);           // rows of chunk c+2 -> buffer of chunk c
-            }
-#if defined(VF_WINO_ABL) && (VF_WINO_ABL & 1)
-            if (false) {
-#else
+            if (k == 2 && has2) VF_XSTORE(cur);                           // rows of chunk c+2 -> buffer of chunk c
             if (has2) {
-#endif
-                // one global load per slice: bursts stall at issue (measured: 2 per slice = -8 %)
-                if (k == 5) VF_ULOAD(0, c + 2);
-                if (k == 6) VF_ULOAD(1, c + 2);
-                if (k == 7) VF_ULOAD(2, c + 2);
-                if (k == 8) VF_ULOAD(3, c + 2);
-                if (k == 9) VF_ULOAD(4, c + 2);
-                if (k == 10) VF_ULOAD(5, c + 2);
-                if (k == 11) VF_ULOAD(6, c + 2);
-                if (k == 12) VF_ULOAD(7, c + 2);
+                if (k == 3) VF_ULOAD(0, c + 2);
+                if (k == 4) VF_ULOAD(1, c + 2);
+                if (k == 5) VF_ULOAD(2, c + 2);
+                if (k == 6) VF_ULOAD(3, c + 2);
             }
-#if !defined(VF_WINO_ABL) || !(VF_WINO_ABL & 1)
-            if (k >= 13 && k < 13 + NXR && has3) load_x(k - 13, c + 3);
-#endif
+            if (k == 7 && has3) VF_XLOAD(c + 3);
             __builtin_amdgcn_sched_barrier(0);
             acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.x, b_cur[0], acc[k], 0, 0, 0);
             acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.y, b_cur[1], acc[k], 0, 0, 0);
             acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.z, b_cur[2], acc[k], 0, 0, 0);
             acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.w, b_cur[3], acc[k], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if (k + 1 < 16) {
+            if (k + 1 < 8) {
                 a_cur = a_nxt;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) b_cur[e] = b_nxt[e];
@@ -279,25 +248,45 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(WinoArgs a) {
 #undef VF_USTORE
 #undef VF_ULOAD_ALL
 #undef VF_USTORE_ALL
+#undef VF_XLOAD
+#undef VF_XSTORE
 #ifdef VF_CONV_STAMPS
     st_[1] = clock64();
 #endif
 
-    // output transform Y = A^T M A per (co, tile); lane = tile, register = output channel
-    const int tl = tw * 32 + li;
-    const int tr = tl / G::TW, tq = tl % G::TW;
-    const int orow = r0 + 2 * tr, ocol = 2 * tq;
-    if (s < a.S) {
+    // ---- output transform Y = A^T M A.  This wave holds rows {2kh, 2kh+1} of M (acc[4*(i-2kh)+j]):
+    //   s0[j] = M0j+M1j (+M2j)      s1[j] = M1j (-M2j-M3j)     -> partial 2x2 tile, linear in the rows
+    float part[16][4];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float s0[4], s1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float m0 = acc[j][r], m1 = acc[4 + j][r];          // rows 2kh, 2kh+1
+            s0[j] = kh == 0 ? m0 + m1 : m0;
+            s1[j] = kh == 0 ? m1 : -m0 - m1;
+        }
+        part[r][0] = s0[0] + s0[1] + s0[2];
+        part[r][1] = s0[1] - s0[2] - s0[3];
+        part[r][2] = s1[0] + s1[1] + s1[2];
+        part[r][3] = s1[1] - s1[2] - s1[3];
+    }
+    float* xch = lds + (size_t)(wid & 3) * (64 * 64);                 // [value 64][lane 64] per (cw, tw) pair
+    if (kh == 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) xch[(r * 4 + q) * 64 + lane] = part[r][q];
+    }
+    __syncthreads();
+    if (kh == 0 && s < a.S) {
+        const int tl = tw * 32 + li;
+        const int tr = tl / G::TW, tq = tl % G::TW;
+        const int orow = r0 + 2 * tr, ocol = 2 * tq;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int co = co0 + cw * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
             if (co >= a.Cout) continue;
-            float sr[2][4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                sr[0][c] = acc[0 + c][r] + acc[4 + c][r] + acc[8 + c][r];
-                sr[1][c] = acc[4 + c][r] - acc[8 + c][r] - acc[12 + c][r];
-            }
             float b = 0.f;
             if (a.bias) b += a.bias[co];
 #ifndef VF_CONV_STAMPS
@@ -306,7 +295,8 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(WinoArgs a) {
             const size_t o = ((size_t)s * a.Cout + co) * G::HW + (size_t)orow * G::W + ocol;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                float2 v = make_float2(sr[i][0] + sr[i][1] + sr[i][2] + b, sr[i][1] - sr[i][2] - sr[i][3] + b);
+                float2 v = make_float2(part[r][2 * i] + xch[(r * 4 + 2 * i) * 64 + lane] + b,
+                                       part[r][2 * i + 1] + xch[(r * 4 + 2 * i + 1) * 64 + lane] + b);
                 if (a.res) {
                     const float2 rr = *reinterpret_cast<const float2*>(a.res + o + i * G::W);
                     v.x += rr.x; v.y += rr.y;
@@ -386,7 +376,7 @@ template <int LOGW, int MODE>
 int launch_wino(const WinoArgs& a, hipStream_t st) {
     using G = WGeo<LOGW, MODE>;
     const int nblk = a.S * G::WPI * (a.CoutP / WTCO);
-    hipLaunchKernelGGL((wino_conv_kernel<LOGW, MODE>), dim3(nblk), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((wino_conv_kernel<LOGW, MODE>), dim3(nblk), dim3(512), 0, st, a);
     VF_RETURN_LAST_ERROR();
 }
 
