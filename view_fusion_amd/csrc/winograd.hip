@@ -216,20 +216,24 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(WinoArgs a) {
                 for (int e = 0; e < 4; ++e) b_nxt[e] = vb[(k + 1) * WCK * WTT + e * WTT];
             }
             // ---- side work of this slice, issued in the MFMA gaps (the partner wave covers the rest)
+            // Each staging register is stored to LDS in slice i and re-loaded (two chunks ahead) in slice
+            // i+1: that leaves 7 of the 8 slices (~5000 cycles) between a global load and its use.
             if (has1) {
                 if (k < 4) win_read_row(k, nxt);                          // rows of chunk c+1
-                if (k == 0) { VF_USTORE(0, nxt); VF_USTORE(1, nxt); }
-                if (k == 1) { VF_USTORE(2, nxt); VF_USTORE(3, nxt); }
+                if (k == 0) VF_USTORE(0, nxt);
+                if (k == 1) VF_USTORE(1, nxt);
+                if (k == 2) VF_USTORE(2, nxt);
+                if (k == 3) VF_USTORE(3, nxt);
                 if (k >= 4) win_write_row(k - 4, nxt);
             }
-            if (k == 2 && has2) VF_XSTORE(cur);                           // rows of chunk c+2 -> buffer of chunk c
+            if (k == 4 && has2) VF_XSTORE(cur);                           // rows of chunk c+2 -> buffer of chunk c
             if (has2) {
-                if (k == 3) VF_ULOAD(0, c + 2);
-                if (k == 4) VF_ULOAD(1, c + 2);
-                if (k == 5) VF_ULOAD(2, c + 2);
-                if (k == 6) VF_ULOAD(3, c + 2);
+                if (k == 1) VF_ULOAD(0, c + 2);
+                if (k == 2) VF_ULOAD(1, c + 2);
+                if (k == 3) VF_ULOAD(2, c + 2);
+                if (k == 4) VF_ULOAD(3, c + 2);
             }
-            if (k == 7 && has3) VF_XLOAD(c + 3);
+            if (k == 5 && has3) VF_XLOAD(c + 3);
             __builtin_amdgcn_sched_barrier(0);
             acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.x, b_cur[0], acc[k], 0, 0, 0);
             acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.y, b_cur[1], acc[k], 0, 0, 0);
