@@ -75,10 +75,15 @@ def pmc_traffic(kernel):
     counters cannot be read from inside the process, so this is the recorded, not a live, figure."""
     path = os.path.join(ROOT, "profiles", "r01_bench_pmc_traffic_kib_per_launch.json")
     try:
-        d = json.load(open(path))[kernel]
-        return dict(bytes_per_launch=(2 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0,
+        tab = json.load(open(path))
+        tot = n = 0.0
+        for k in kernel:                      # launch-weighted mean over the kernels of the family
+            d = tab[k]
+            tot += (2 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0 * d["launches"]
+            n += d["launches"]
+        return dict(bytes_per_launch=tot / n,
                     source="profiles/r01_bench_pmc_traffic_kib_per_launch.json (rocprofv3 --pmc, separate passes)")
-    except (OSError, KeyError):
+    except (OSError, KeyError, ZeroDivisionError):
         return None
 
 
@@ -98,9 +103,10 @@ def roofline(trainer, batch, steps=2):
     f = agg["conv_fwd"][0] + agg["conv_dgrad"][0]
     s = agg["conv_fwd"][1] + agg["conv_dgrad"][1]
     n = agg["conv_fwd"][2] + agg["conv_dgrad"][2]
-    out = dict(bound="mfma", kernel="conv_mfma_kernel<KS,LOGW,MODE,NPT> (forward + dgrad launches)",
+    out = dict(bound="mfma", kernel="conv forward + dgrad launches: wino_conv_kernel<LOGW,MODE> (3x3 on 64x64/32x32 maps) "
+                                   "+ conv_mfma_kernel<KS,LOGW,MODE,NPT> (rest); FLOPs are the algorithmic direct-conv count",
                achieved=f / s / 1e12, peak=PEAK_FP32_MATRIX_TFLOPS, unit="TFLOP/s",
-               frac=f / s / 1e12 / PEAK_FP32_MATRIX_TFLOPS, traffic=pmc_traffic("conv_mfma_kernel"),
+               frac=f / s / 1e12 / PEAK_FP32_MATRIX_TFLOPS, traffic=pmc_traffic(("wino_conv_kernel", "conv_mfma_kernel")),
                launches_per_step=n // steps,
                avg_launch_us=s / n * 1e6, algorithmic_gflop_per_launch=f / n / 1e9)
     out["other_kernels"] = {k: dict(achieved_tflops=v[0] / v[1] / 1e12, launches_per_step=v[2] // steps,

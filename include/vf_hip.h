@@ -62,6 +62,11 @@ int vf_wino_pack_weights_multi(const void* desc, int nlayers, long total_blocks,
 int vf_wino_conv_fwd(const float* x, const float* u_packed, const float* bias, const float* view_bias,
                      const float* residual, float* y, int S, int Cin, int Cout, int H, int W, int mode,
                      void* stream);
+/* weight gradient of a plain stride-1 3x3 conv (mode 0) through the same transform: dU = sum over tiles of
+ * (A dY A^T) (B^T d B)^T per Winograd slice, split over tile ranges into `ws` slabs, then dW = G^T dU G */
+long vf_wino_wgrad_ws_floats(int S, int Cin, int Cout, int H, int W);
+int vf_wino_wgrad(const float* x, const float* dy, float* dw_oihw, float* ws, long ws_floats, int S, int Cin,
+                  int Cout, int H, int W, void* stream);
 
 /* ---- batched GEMM + softmax : torch.einsum / torch.softmax / nn.Linear,
  *      unet.py:267-274 (attention), :29-31,165 (linears) ---- */

@@ -118,10 +118,22 @@ def test_p_mean_variance_vs_reference(dev):
     np.testing.assert_allclose(w.cpu().numpy(), g["weights"], rtol=1e-4, atol=1e-5)
 
 
-def test_small_train_step_vs_oracle(dev):
-    """Full-size network (33.9 M params), B=2 N=2: loss and gradient digests vs the CPU oracle."""
+@pytest.mark.parametrize("winograd", [False, True])
+def test_small_train_step_vs_oracle(dev, winograd):
+    """Full-size network (33.9 M params), B=2 N=2: loss and every parameter gradient vs the CPU oracle.
+    winograd=True forces the fused Winograd kernels (and their one-launch weight packing) onto all
+    eligible layers, as the S=96 training step uses them."""
     from oracle import unet_ref, view_fusion_ref as vfr
-    from view_fusion_amd.utils import tensor_digest
+    from view_fusion_amd import ops
+    ops.FORCE_WINOGRAD = winograd
+    try:
+        _small_train_step(dev)
+    finally:
+        ops.FORCE_WINOGRAD = False
+
+
+def _small_train_step(dev):
+    from oracle import unet_ref, view_fusion_ref as vfr
     vf = make_vf(SMALL, SCHED_TRAIN, dev, True)
     g = torch.Generator().manual_seed(0)
     B, N = 2, 2

@@ -431,3 +431,302 @@ int vf_wino_conv_fwd(const float* x, const float* u_packed, const float* bias, c
 }
 
 }  // extern "C"
+
+// =================================================================================================
+// Winograd weight gradient:  dU_k[co][ci] = sum_tiles (A dY A^T)_k[co][tile] * (B^T d B)_k[ci][tile],
+// dW = G^T dU G (applied by the reduce kernel after the split-K slabs are summed, fixed order).
+// Same 8-wave structure as the forward kernel: wave (cw, ciw, kh) owns 32 co x 32 ci x 8 slices = 128
+// accumulators; K = tiles, 8 tiles (one 16-pixel x 2-row strip) per chunk; both MFMA operands come
+// from LDS by ds_read_b128 (4 consecutive tiles per lane half).  dY tiles are transformed straight
+// from global registers, x goes through a raw LDS strip (neighbouring windows overlap by 2 pixels).
+namespace {
+
+constexpr int GT = 8;                 // tiles per chunk
+constexpr int GXW = 24;               // raw x strip row: idx 3 = col 2q0-1, 4..19 = cols 2q0..2q0+15, 20 = col 2q0+16
+
+struct WinoWgradArgs {
+    const float* x;
+    const float* dy;
+    float* ws;                        // [slab][k 16][CoutP][CinQ]
+    int S, Cin, Cout, CoutP, CinQ;
+    int nchunks, chunks_per_slice;
+};
+
+template <int LOGW>
+__global__ __launch_bounds__(512, 2) void wino_wgrad_kernel(WinoWgradArgs a) {
+    constexpr int W = 1 << LOGW, H = W, HW = W * H;
+    constexpr int CPR = (W / 2) / GT;                 // chunks per tile row
+    constexpr int CPI = (H / 2) * CPR;                // chunks per image
+    constexpr int MSZ = 16 * 64 * GT;                 // floats of one dM (or V) buffer
+    constexpr int XSZ = 64 * 4 * GXW;
+
+    __shared__ __attribute__((aligned(16))) float lds[4 * MSZ + XSZ];
+    float* const Ml = lds;                            // dM[2][k][co][tile]
+    float* const Vl = lds + 2 * MSZ;                  // V [2][k][ci][tile]
+    float* const Xl = lds + 4 * MSZ;                  // raw x strip [ci][4 rows][GXW]
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int cw = wid & 1, ciw = (wid >> 1) & 1, kh = wid >> 2;
+    const int li = lane & 31, lh = lane >> 5;
+    const int co0 = blockIdx.x * 64, ci0 = blockIdx.y * 64;
+    const int c_begin = blockIdx.z * a.chunks_per_slice;
+    const int c_end = min(a.nchunks, c_begin + a.chunks_per_slice);
+    const int n = c_end - c_begin;
+
+    // this thread's transform duty: channel tch (a co for dM, a ci for V) and tile tt of the chunk
+    const int tch = tid >> 3, tt = tid & 7;
+    // raw x staging duty: 1024 float4 (2 per thread) + 512 halo scalars (1 per thread)
+    //   float4 e in [0,1024): ci = e >> 4, row = (e >> 2) & 3, q = e & 3 ; scalar e: ci = e >> 3, row = (e >> 1) & 3, side = e & 1
+    float4 xr0, xr1;
+    float xh;
+    float2 dy0, dy1;
+    auto chunk_pos = [&](int c, int& s, int& p, int& q0) {
+        s = c / CPI;
+        const int r = c - s * CPI;
+        p = r / CPR;                                   // tile row
+        q0 = (r - p * CPR) * GT;                       // first tile column
+    };
+    auto load_x = [&](int c) {
+        int s, p, q0;
+        chunk_pos(c, s, p, q0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int e = tid + 512 * i;
+            const int ci = e >> 4, row = (e >> 2) & 3, q = e & 3;
+            const int gy = 2 * p - 1 + row;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ci0 + ci < a.Cin && gy >= 0 && gy < H)
+                v = *reinterpret_cast<const float4*>(a.x + (((size_t)s * a.Cin + ci0 + ci) * H + gy) * W + 2 * q0 + 4 * q);
+            if (i == 0) xr0 = v; else xr1 = v;
+        }
+        const int ci = tid >> 3, row = (tid >> 1) & 3, side = tid & 1;
+        const int gy = 2 * p - 1 + row, gx = side ? 2 * q0 + 16 : 2 * q0 - 1;
+        xh = 0.f;
+        if (ci0 + ci < a.Cin && gy >= 0 && gy < H && gx >= 0 && gx < W)
+            xh = a.x[(((size_t)s * a.Cin + ci0 + ci) * H + gy) * W + gx];
+    };
+    auto store_x = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int e = tid + 512 * i;
+            *reinterpret_cast<float4*>(Xl + (e >> 2) * GXW + 4 + 4 * (e & 3)) = i == 0 ? xr0 : xr1;
+        }
+        Xl[(tid >> 1) * GXW + ((tid & 1) ? 20 : 3)] = xh;
+    };
+    auto load_dy = [&](int c) {
+        int s, p, q0;
+        chunk_pos(c, s, p, q0);
+        dy0 = dy1 = make_float2(0.f, 0.f);
+        if (co0 + tch < a.Cout) {
+            const float* g = a.dy + (((size_t)s * a.Cout + co0 + tch) * H + 2 * p) * W + 2 * (q0 + tt);
+            dy0 = *reinterpret_cast<const float2*>(g);
+            dy1 = *reinterpret_cast<const float2*>(g + W);
+        }
+    };
+    auto xform_dy = [&](int buf) {                     // dM = A dY A^T, A^T = [[1,1,1,0],[0,1,-1,-1]]
+        const float r[4][2] = {{dy0.x, dy0.y}, {dy0.x + dy1.x, dy0.y + dy1.y}, {dy0.x - dy1.x, dy0.y - dy1.y},
+                               {-dy1.x, -dy1.y}};
+        float* mo = Ml + buf * MSZ + tch * GT + tt;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            mo[(4 * i + 0) * 64 * GT] = r[i][0];
+            mo[(4 * i + 1) * 64 * GT] = r[i][0] + r[i][1];
+            mo[(4 * i + 2) * 64 * GT] = r[i][0] - r[i][1];
+            mo[(4 * i + 3) * 64 * GT] = -r[i][1];
+        }
+    };
+    float d[16];
+    auto xform_x_read = [&](int r) {
+        const float* p = Xl + (tch * 4 + r) * GXW + 2 * tt + 3;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) d[r * 4 + c] = p[c];
+    };
+    auto xform_x_write = [&](int r, int buf) {         // V = B^T d B
+        float* vo = Vl + buf * MSZ + tch * GT + tt;
+        float t[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float d0 = d[c], d1 = d[4 + c], d2 = d[8 + c], d3 = d[12 + c];
+            t[c] = r == 0 ? d0 - d2 : (r == 1 ? d1 + d2 : (r == 2 ? d2 - d1 : d1 - d3));
+        }
+        vo[(4 * r + 0) * 64 * GT] = t[0] - t[2];
+        vo[(4 * r + 1) * 64 * GT] = t[1] + t[2];
+        vo[(4 * r + 2) * 64 * GT] = t[2] - t[1];
+        vo[(4 * r + 3) * 64 * GT] = t[1] - t[3];
+    };
+
+    f32x16 acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = (f32x16){0};
+
+    if (n > 0) {
+        // ---- prologue: chunk 0 transformed into buffer 0; chunk 1 raw data in registers
+        load_x(c_begin);
+        load_dy(c_begin);
+        store_x();
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xform_x_read(r);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xform_x_write(r, 0);
+        xform_dy(0);
+        if (n > 1) { load_x(c_begin + 1); load_dy(c_begin + 1); }
+        __syncthreads();
+    }
+
+    const int aoff = 8 * kh * 64 * GT + (cw * 32 + li) * GT + 4 * lh;
+    const int boff = 8 * kh * 64 * GT + (ciw * 32 + li) * GT + 4 * lh;
+    for (int c = 0; c < n; ++c) {
+        const int cur = c & 1, nxt = cur ^ 1;
+        const bool has1 = c + 1 < n, has2 = c + 2 < n;
+        const float* ab = Ml + cur * MSZ + aoff;
+        const float* bb = Vl + cur * MSZ + boff;
+        float4 a_cur = *reinterpret_cast<const float4*>(ab);
+        float4 b_cur = *reinterpret_cast<const float4*>(bb);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float4 a_nxt = a_cur, b_nxt = b_cur;
+            if (k + 1 < 8) {
+                a_nxt = *reinterpret_cast<const float4*>(ab + (k + 1) * 64 * GT);
+                b_nxt = *reinterpret_cast<const float4*>(bb + (k + 1) * 64 * GT);
+            }
+            // ---- side work: raw strip of chunk c+1 -> LDS (slice 0), barrier, transforms (slices 4-7)
+            if (k == 0 && has1) store_x();
+            if (k == 1 && has2) load_x(c_begin + c + 2);
+            if (k == 4) __syncthreads();               // raw strip of chunk c+1 visible to every thread
+            if (has1) {
+                if (k == 4) { xform_x_read(0); xform_x_read(1); }
+                if (k == 5) { xform_x_read(2); xform_x_read(3); xform_dy(nxt); }
+                if (k == 6) { xform_x_write(0, nxt); xform_x_write(1, nxt); }
+                if (k == 7) { xform_x_write(2, nxt); xform_x_write(3, nxt); }
+            }
+            if (k == 6 && has2) load_dy(c_begin + c + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.x, b_cur.x, acc[k], 0, 0, 0);
+            acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.y, b_cur.y, acc[k], 0, 0, 0);
+            acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.z, b_cur.z, acc[k], 0, 0, 0);
+            acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.w, b_cur.w, acc[k], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            a_cur = a_nxt; b_cur = b_nxt;
+        }
+        __syncthreads();
+    }
+
+    // partial dU of this slice: rows k = 8kh .. 8kh+7
+    const int slab = blockIdx.z;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + cw * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int ci = ci0 + ciw * 32 + li;
+            if (ci < a.CinQ)
+                a.ws[(((size_t)slab * 16 + 8 * kh + k) * a.CoutP + co) * a.CinQ + ci] = acc[k][r];
+        }
+}
+
+// slab sum: one workgroup per (64 consecutive (co,ci) entries, slice k); 4 slab groups per entry, combined
+// through LDS in a fixed order.  out = dU[k][CoutP*CinQ]
+__global__ __launch_bounds__(256) void wino_wgrad_slabsum_kernel(const float* __restrict__ ws, float* __restrict__ out,
+                                                                 int nslab, long kstride) {
+    __shared__ float part[4][64];
+    const int e = threadIdx.x & 63, g = threadIdx.x >> 6, k = blockIdx.y;
+    const long off = (long)k * kstride + (long)blockIdx.x * 64 + e;
+    const long sstride = 16 * kstride;
+    float a0 = 0.f, a1 = 0.f;
+    int s = g;
+    for (; s + 4 < nslab; s += 8) {
+        a0 += ws[s * sstride + off];
+        a1 += ws[(s + 4) * sstride + off];
+    }
+    if (s < nslab) a0 += ws[s * sstride + off];
+    part[g][e] = a0 + a1;
+    __syncthreads();
+    if (g == 0) out[off] = (part[0][e] + part[1][e]) + (part[2][e] + part[3][e]);
+}
+
+// dW[co][ci][p][q] = sum_{i,j} G[i][p] G[j][q] dU[4i+j][co][ci]
+__global__ __launch_bounds__(256) void wino_wgrad_finish_kernel(const float* __restrict__ du, float* __restrict__ dw,
+                                                                int Cout, int Cin, int CoutP, int CinQ) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;           // over (co, ci), ci fastest
+    if (idx >= Cout * Cin) return;
+    const int ci = idx % Cin, co = idx / Cin;
+    const size_t kstride = (size_t)CoutP * CinQ;
+    const float* p = du + (size_t)co * CinQ + ci;
+    float u[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) u[k] = p[k * kstride];
+    // G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]] : rows first, then columns
+    float t[3][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float h1 = 0.5f * (u[4 + j] + u[8 + j]), h2 = 0.5f * (u[4 + j] - u[8 + j]);
+        t[0][j] = u[j] + h1;
+        t[1][j] = h2;
+        t[2][j] = h1 + u[12 + j];
+    }
+    float* o = dw + ((size_t)co * Cin + ci) * 9;
+#pragma unroll
+    for (int pp = 0; pp < 3; ++pp) {
+        const float h1 = 0.5f * (t[pp][1] + t[pp][2]), h2 = 0.5f * (t[pp][1] - t[pp][2]);
+        o[pp * 3 + 0] = t[pp][0] + h1;
+        o[pp * 3 + 1] = h2;
+        o[pp * 3 + 2] = h1 + t[pp][3];
+    }
+}
+
+template <int LOGW>
+int launch_wino_wgrad(WinoWgradArgs a, float* dw, size_t ws_floats, hipStream_t st) {
+    constexpr int W = 1 << LOGW;
+    a.nchunks = a.S * (W / 2) * (W / 2) / GT;
+    const int nco = a.CoutP / 64, nci = (a.CinQ + 63) / 64;
+    const size_t slab_floats = (size_t)16 * a.CoutP * a.CinQ;
+    int z = 256 / (nco * nci);
+    if (z < 1) z = 1;
+    if (z > a.nchunks) z = a.nchunks;
+    if (ws_floats < 2 * slab_floats) return (int)hipErrorInvalidValue;
+    const size_t zmax = ws_floats / slab_floats - 1;
+    if ((size_t)z > zmax) z = (int)zmax;
+    a.chunks_per_slice = (a.nchunks + z - 1) / z;
+    z = (a.nchunks + a.chunks_per_slice - 1) / a.chunks_per_slice;
+    hipLaunchKernelGGL((wino_wgrad_kernel<LOGW>), dim3(nco, nci, z), dim3(512), 0, st, a);
+    // the summed dU goes behind the slabs (vf_wino_wgrad_ws_floats reserves one extra slab)
+    float* du = a.ws + (size_t)z * slab_floats;
+    const long kstride = (long)a.CoutP * a.CinQ;
+    hipLaunchKernelGGL(wino_wgrad_slabsum_kernel, dim3((unsigned)(kstride / 64), 16), dim3(256), 0, st, a.ws, du, z,
+                       kstride);
+    const int total = a.Cout * a.Cin;
+    hipLaunchKernelGGL(wino_wgrad_finish_kernel, dim3((total + 255) / 256), dim3(256), 0, st, du, dw, a.Cout, a.Cin,
+                       a.CoutP, a.CinQ);
+    VF_RETURN_LAST_ERROR();
+}
+
+}  // namespace
+
+extern "C" {
+
+// workspace floats for vf_wino_wgrad at this shape (slabs of transformed partial gradients)
+long vf_wino_wgrad_ws_floats(int S, int Cin, int Cout, int H, int W) {
+    const long slab = 16L * rup(Cout, 64) * rup(Cin, 32);
+    const int nco = rup(Cout, 64) / 64, nci = (rup(Cin, 32) + 63) / 64;
+    long z = 256 / (nco * nci);
+    if (z < 1) z = 1;
+    const long nchunks = (long)S * (H / 2) * (W / 2) / GT;
+    if (z > nchunks) z = nchunks;
+    return (z + 1) * slab;
+}
+
+// dw[Cout][Cin][3][3] of a stride-1 3x3 conv (plain input, H = W in {32, 64}) via Winograd F(2x2,3x3)
+int vf_wino_wgrad(const float* x, const float* dy, float* dw, float* ws, long ws_floats, int S, int Cin, int Cout,
+                  int H, int W, void* stream) {
+    if (S <= 0) return 0;
+    if (!vf_wino_supported(H, W, 0)) return (int)hipErrorInvalidValue;
+    WinoWgradArgs a;
+    a.x = x; a.dy = dy; a.ws = ws; a.S = S; a.Cin = Cin; a.Cout = Cout;
+    a.CoutP = rup(Cout, 64); a.CinQ = rup(Cin, 32);
+    hipStream_t st = (hipStream_t)stream;
+    return W == 32 ? launch_wino_wgrad<5>(a, dw, (size_t)ws_floats, st)
+                   : launch_wino_wgrad<6>(a, dw, (size_t)ws_floats, st);
+}
+
+}  // extern "C"

@@ -176,6 +176,7 @@ def _packed(layer, force):
 
 WINOGRAD = True           # fused Winograd F(2x2,3x3) for stride-1 3x3 convs on large maps
 FORCE_WINOGRAD = False    # tests: take the Winograd path even when the grid would not fill the chip
+WINOGRAD_WGRAD = True     # weight gradients of those layers (plain stride-1 ones) through the same transform
 
 
 def use_winograd(S, Cout, H, W, KS, m):
@@ -331,7 +332,13 @@ class _Conv2dFn(torch.autograd.Function):
                         None, 0, S, Cout, Cin, H, W, KS, 0, st, tag=ctx.tag)
                 dx = torch.empty_like(x)
                 _lib.call("vf_sumpool2", _ptr(dup), _ptr(dx), dx.numel(), Wi, st)
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and ctx.wino and m == 0 and WINOGRAD_WGRAD and min(Cin, Cout) >= 32:
+            need = _lib.load().vf_wino_wgrad_ws_floats(S, Cin, Cout, H, W)
+            ws = _workspace(x.device, need)
+            dw = torch.empty(Cout, Cin, 3, 3, device=x.device, dtype=torch.float32)
+            _launch("conv_wgrad", ctx.flops, "vf_wino_wgrad", _ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), ws.numel(), S,
+                    Cin, Cout, H, W, st, tag=ctx.tag)
+        elif ctx.needs_input_grad[1]:
             need = _lib.load().vf_conv_wgrad_ws_floats(S, Cin, Cout, H, W, KS)
             ws = _workspace(x.device, need)
             dw = torch.empty(Cout, Cin, KS, KS, device=x.device, dtype=torch.float32)
