@@ -4,8 +4,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from view_fusion_amd import _lib, ops
 S = int(os.environ.get("S", 96))
 dev = torch.device("cuda:0")
-shapes = [(64, 64, 64), (128, 64, 64), (192, 64, 64), (64, 128, 32), (128, 128, 32), (192, 128, 32), (256, 128, 32),
-          (320, 128, 32)]
+shapes = [(6, 64, 64), (64, 6, 64), (64, 64, 64), (128, 64, 64), (192, 64, 64), (64, 128, 32), (128, 128, 32),
+          (256, 128, 32), (320, 128, 32), (128, 192, 16), (192, 192, 16), (384, 192, 16), (512, 192, 16)]
 lib = _lib.load()
 st = ops._stream()
 for Cin, Cout, H in shapes:
@@ -21,7 +21,7 @@ for Cin, Cout, H in shapes:
                   H, H, 3, 0, st)
     def wino():
         _lib.call("vf_wino_wgrad", x.data_ptr(), dy.data_ptr(), dw1.data_ptr(), ws.data_ptr(), ws.numel(), S, Cin, Cout,
-                  H, H, st)
+                  H, H, 0, st)
     res = []
     for fn in (direct, wino):
         for _ in range(3):

@@ -452,9 +452,10 @@ struct WinoWgradArgs {
     int nchunks, chunks_per_slice;
 };
 
-template <int LOGW>
+template <int LOGW, int MODE>
 __global__ __launch_bounds__(512, 2) void wino_wgrad_kernel(WinoWgradArgs a) {
-    constexpr int W = 1 << LOGW, H = W, HW = W * H;
+    constexpr int W = 1 << LOGW, H = W;
+    constexpr int SW = MODE == 2 ? W / 2 : W, SH = SW;      // stored input size (MODE 2: nearest-upsampled x2 on read)
     constexpr int CPR = (W / 2) / GT;                 // chunks per tile row
     constexpr int CPI = (H / 2) * CPR;                // chunks per image
     constexpr int MSZ = 16 * 64 * GT;                 // floats of one dM (or V) buffer
@@ -495,15 +496,23 @@ __global__ __launch_bounds__(512, 2) void wino_wgrad_kernel(WinoWgradArgs a) {
             const int ci = e >> 4, row = (e >> 2) & 3, q = e & 3;
             const int gy = 2 * p - 1 + row;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ci0 + ci < a.Cin && gy >= 0 && gy < H)
-                v = *reinterpret_cast<const float4*>(a.x + (((size_t)s * a.Cin + ci0 + ci) * H + gy) * W + 2 * q0 + 4 * q);
+            if (ci0 + ci < a.Cin && gy >= 0 && gy < H) {
+                if (MODE == 2) {
+                    const float2 h = *reinterpret_cast<const float2*>(
+                        a.x + (((size_t)s * a.Cin + ci0 + ci) * SH + (gy >> 1)) * SW + q0 + 2 * q);
+                    v = make_float4(h.x, h.x, h.y, h.y);
+                } else {
+                    v = *reinterpret_cast<const float4*>(a.x + (((size_t)s * a.Cin + ci0 + ci) * H + gy) * W + 2 * q0 + 4 * q);
+                }
+            }
             if (i == 0) xr0 = v; else xr1 = v;
         }
         const int ci = tid >> 3, row = (tid >> 1) & 3, side = tid & 1;
         const int gy = 2 * p - 1 + row, gx = side ? 2 * q0 + 16 : 2 * q0 - 1;
         xh = 0.f;
         if (ci0 + ci < a.Cin && gy >= 0 && gy < H && gx >= 0 && gx < W)
-            xh = a.x[(((size_t)s * a.Cin + ci0 + ci) * H + gy) * W + gx];
+            xh = MODE == 2 ? a.x[(((size_t)s * a.Cin + ci0 + ci) * SH + (gy >> 1)) * SW + (gx >> 1)]
+                           : a.x[(((size_t)s * a.Cin + ci0 + ci) * H + gy) * W + gx];
     };
     auto store_x = [&]() {
 #pragma unroll
@@ -675,7 +684,7 @@ __global__ __launch_bounds__(256) void wino_wgrad_finish_kernel(const float* __r
     }
 }
 
-template <int LOGW>
+template <int LOGW, int MODE>
 int launch_wino_wgrad(WinoWgradArgs a, float* dw, size_t ws_floats, hipStream_t st) {
     constexpr int W = 1 << LOGW;
     a.nchunks = a.S * (W / 2) * (W / 2) / GT;
@@ -689,7 +698,7 @@ int launch_wino_wgrad(WinoWgradArgs a, float* dw, size_t ws_floats, hipStream_t 
     if ((size_t)z > zmax) z = (int)zmax;
     a.chunks_per_slice = (a.nchunks + z - 1) / z;
     z = (a.nchunks + a.chunks_per_slice - 1) / a.chunks_per_slice;
-    hipLaunchKernelGGL((wino_wgrad_kernel<LOGW>), dim3(nco, nci, z), dim3(512), 0, st, a);
+    hipLaunchKernelGGL((wino_wgrad_kernel<LOGW, MODE>), dim3(nco, nci, z), dim3(512), 0, st, a);
     // the summed dU goes behind the slabs (vf_wino_wgrad_ws_floats reserves one extra slab)
     float* du = a.ws + (size_t)z * slab_floats;
     const long kstride = (long)a.CoutP * a.CinQ;
@@ -716,17 +725,27 @@ long vf_wino_wgrad_ws_floats(int S, int Cin, int Cout, int H, int W) {
     return (z + 1) * slab;
 }
 
-// dw[Cout][Cin][3][3] of a stride-1 3x3 conv (plain input, H = W in {32, 64}) via Winograd F(2x2,3x3)
+int vf_wino_wgrad_supported(int H, int W, int mode) {
+    return H == W && (W == 16 || W == 32 || W == 64) && (mode == 0 || mode == 2);
+}
+
+// dw[Cout][Cin][3][3] of a stride-1 3x3 conv (H = W = output size in {16, 32, 64}; mode 2: x is stored at half
+// size and nearest-upsampled on read) via Winograd F(2x2,3x3)
 int vf_wino_wgrad(const float* x, const float* dy, float* dw, float* ws, long ws_floats, int S, int Cin, int Cout,
-                  int H, int W, void* stream) {
+                  int H, int W, int mode, void* stream) {
     if (S <= 0) return 0;
-    if (!vf_wino_supported(H, W, 0)) return (int)hipErrorInvalidValue;
+    if (!vf_wino_wgrad_supported(H, W, mode)) return (int)hipErrorInvalidValue;
     WinoWgradArgs a;
     a.x = x; a.dy = dy; a.ws = ws; a.S = S; a.Cin = Cin; a.Cout = Cout;
     a.CoutP = rup(Cout, 64); a.CinQ = rup(Cin, 32);
     hipStream_t st = (hipStream_t)stream;
-    return W == 32 ? launch_wino_wgrad<5>(a, dw, (size_t)ws_floats, st)
-                   : launch_wino_wgrad<6>(a, dw, (size_t)ws_floats, st);
+#define VF_WG(LW) \
+    return mode == 2 ? launch_wino_wgrad<LW, 2>(a, dw, (size_t)ws_floats, st) \
+                     : launch_wino_wgrad<LW, 0>(a, dw, (size_t)ws_floats, st)
+    if (W == 16) VF_WG(4);
+    if (W == 32) VF_WG(5);
+    VF_WG(6);
+#undef VF_WG
 }
 
 }  // extern "C"

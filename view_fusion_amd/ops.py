@@ -187,6 +187,13 @@ def use_winograd(S, Cout, H, W, KS, m):
     return FORCE_WINOGRAD or S * (H * W // 256) * ((Cout + 63) // 64) >= 256
 
 
+def use_winograd_wgrad(S, Cin, Cout, H, W, KS, m):
+    """Weight gradients split over (co, ci, tile range), so the grid fills the chip at any map size."""
+    if not (WINOGRAD and WINOGRAD_WGRAD) or KS != 3 or not _lib.load().vf_wino_wgrad_supported(H, W, m):
+        return False
+    return FORCE_WINOGRAD or S * (H // 2) * (W // 2) >= 8 * 512
+
+
 def _packed_wino(layer, force):
     """Winograd-transformed packed weights (forward / dgrad) of a 3x3 layer; same caching rules as _packed."""
     w = layer.weight
@@ -332,12 +339,12 @@ class _Conv2dFn(torch.autograd.Function):
                         None, 0, S, Cout, Cin, H, W, KS, 0, st, tag=ctx.tag)
                 dx = torch.empty_like(x)
                 _lib.call("vf_sumpool2", _ptr(dup), _ptr(dx), dx.numel(), Wi, st)
-        if ctx.needs_input_grad[1] and ctx.wino and m == 0 and WINOGRAD_WGRAD and min(Cin, Cout) >= 32:
+        if ctx.needs_input_grad[1] and use_winograd_wgrad(S, Cin, Cout, H, W, KS, m):
             need = _lib.load().vf_wino_wgrad_ws_floats(S, Cin, Cout, H, W)
             ws = _workspace(x.device, need)
             dw = torch.empty(Cout, Cin, 3, 3, device=x.device, dtype=torch.float32)
             _launch("conv_wgrad", ctx.flops, "vf_wino_wgrad", _ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), ws.numel(), S,
-                    Cin, Cout, H, W, st, tag=ctx.tag)
+                    Cin, Cout, H, W, m, st, tag=ctx.tag)
         elif ctx.needs_input_grad[1]:
             need = _lib.load().vf_conv_wgrad_ws_floats(S, Cin, Cout, H, W, KS)
             ws = _workspace(x.device, need)
