@@ -62,7 +62,7 @@ int vf_wino_pack_weights_multi(const void* desc, int nlayers, long total_blocks,
 int vf_wino_conv_fwd(const float* x, const float* u_packed, const float* bias, const float* view_bias,
                      const float* residual, float* y, int S, int Cin, int Cout, int H, int W, int mode,
                      void* stream);
-/* weight gradient of a stride-1 3x3 conv (modes 0 and 2, output H = W in {16,32,64}) through the same
+/* weight gradient of a stride-1 3x3 conv (modes 0 and 2, output H = W in {8,16,32,64}) through the same
  * transform: dU = sum over tiles of (A dY A^T) (B^T d B)^T per Winograd slice, split over tile ranges into `ws`
  * slabs that are summed in a fixed order, then dW = G^T dU G */
 int vf_wino_wgrad_supported(int H, int W, int mode);

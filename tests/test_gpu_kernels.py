@@ -113,7 +113,8 @@ def test_conv_small_batch_split_k_forward(dev, Cin, Cout, Hin, KS, mode, S):
                                                (192, 64, 64, "same"), (128, 128, 32, "same"), (320, 128, 32, "same"),
                                                (128, 128, 32, "up2"), (192, 192, 16, "up2"), (32, 32, 32, "same"),
                                                (96, 160, 32, "same"), (40, 96, 64, "same"), (192, 192, 16, "same"),
-                                               (384, 192, 16, "same"), (128, 128, 8, "up2")])
+                                               (384, 192, 16, "same"), (128, 128, 8, "up2"), (320, 320, 8, "same"),
+                                               (640, 320, 8, "same")])
 def test_conv_winograd_path(dev, Cin, Cout, Hin, mode):
     """Fused Winograd F(2x2,3x3) forward, dgrad and (plain stride-1 layers with >= 32 channels) wgrad,
     forced on, vs CPU conv2d."""

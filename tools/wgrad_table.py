@@ -5,7 +5,7 @@ from view_fusion_amd import _lib, ops
 S = int(os.environ.get("S", 96))
 dev = torch.device("cuda:0")
 shapes = [(6, 64, 64), (64, 6, 64), (64, 64, 64), (128, 64, 64), (192, 64, 64), (64, 128, 32), (128, 128, 32),
-          (256, 128, 32), (320, 128, 32), (128, 192, 16), (192, 192, 16), (384, 192, 16), (512, 192, 16)]
+          (256, 128, 32), (320, 128, 32), (128, 192, 16), (192, 192, 16), (384, 192, 16), (512, 192, 16), (192, 320, 8), (320, 320, 8), (640, 320, 8)]
 lib = _lib.load()
 st = ops._stream()
 for Cin, Cout, H in shapes:

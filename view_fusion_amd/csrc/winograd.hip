@@ -77,7 +77,7 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(WinoArgs a) {
     constexpr int NUR = NU4 / NT_;                       // 4 per thread
     constexpr int NX4 = WCK * G::PH * G::Q;
     constexpr int NXR = (NX4 + NT_ - 1) / NT_;           // 1-2 per thread (tail predicated)
-    constexpr int USZ = 16 * WTCO * WCK;                 // unpadded [k][co][ci 8] (2-way b128 conflict, cheap)
+    constexpr int USZ = 16 * WTCO * WCK;                 // [k][co][ci 8], 16-B halves swizzled by the pack kernel
     constexpr int VSZ = 16 * WCK * WTT;
     constexpr int PSZ = WCK * G::PS;
     static_assert(NUR == 4, "U staging assumes 4 float4 per thread");
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(WinoArgs a) {
     if (nch > 2) VF_XLOAD(2);
     __syncthreads();
 
-    const int uoff = 8 * kh * WTCO * WCK + (cw * 32 + li) * WCK + 4 * lh;
+    const int uoff = 8 * kh * WTCO * WCK + (cw * 32 + li) * WCK + 4 * (lh ^ ((li >> 4) & 1));
     const int voff = 8 * kh * WCK * WTT + 4 * lh * WTT + tw * 32 + li;
     for (int c = 0; c < nch; ++c) {
         const int cur = c & 1, nxt = cur ^ 1;
@@ -330,8 +330,8 @@ __device__ __forceinline__ void wino_pack_one(const float* __restrict__ w, float
     }
     const int M = bwd ? Cin : Cout, K = bwd ? Cout : Cin;
     const int nchunk = (K + WCK - 1) / WCK;
-    const int k8 = idx & 7;
     const int m = (idx >> 3) & 63;
+    const int k8 = (idx & 7) ^ (((m >> 4) & 1) << 2);    // 16-B halves swapped on rows 16-31, 48-63: conflict-free ds_read_b128
     size_t t = idx >> 9;
     const int k = t & 15;
     t >>= 4;
@@ -442,7 +442,6 @@ int vf_wino_conv_fwd(const float* x, const float* u_packed, const float* bias, c
 namespace {
 
 constexpr int GT = 8;                 // tiles per chunk
-constexpr int GXW = 24;               // raw x strip row: idx 3 = col 2q0-1, 4..19 = cols 2q0..2q0+15, 20 = col 2q0+16
 
 struct WinoWgradArgs {
     const float* x;
@@ -456,15 +455,22 @@ template <int LOGW, int MODE>
 __global__ __launch_bounds__(512, 2) void wino_wgrad_kernel(WinoWgradArgs a) {
     constexpr int W = 1 << LOGW, H = W;
     constexpr int SW = MODE == 2 ? W / 2 : W, SH = SW;      // stored input size (MODE 2: nearest-upsampled x2 on read)
-    constexpr int CPR = (W / 2) / GT;                 // chunks per tile row
-    constexpr int CPI = (H / 2) * CPR;                // chunks per image
+    constexpr int TPR = W / 2 < GT ? W / 2 : GT;      // tiles of one tile row inside a chunk
+    constexpr int TR = GT / TPR;                      // tile rows per chunk (2 on 8x8 maps, else 1)
+    constexpr int NR = 2 * TR + 2;                    // input rows of the raw strip
+    constexpr int QPR = TPR / 2;                      // float4 per strip row
+    constexpr int GXW = 2 * TPR + 8;                  // strip row: idx 3 = left halo, 4.. = pixels, 4+2*TPR = right halo
+    constexpr bool HALO = W > 2 * TPR;                // strip narrower than the map: halo columns carry data
+    constexpr int NX4 = 64 * NR * QPR;                // float4 of a strip (<= 1024)
+    constexpr int CPR = (W / 2) / TPR;                // chunks per (group of TR) tile rows
+    constexpr int CPI = (H / 2) / TR * CPR;           // chunks per image
     constexpr int MSZ = 16 * 64 * GT;                 // floats of one dM (or V) buffer
-    constexpr int XSZ = 64 * 4 * GXW;
+    constexpr int XSZ = 64 * NR * GXW;
 
     __shared__ __attribute__((aligned(16))) float lds[4 * MSZ + XSZ];
     float* const Ml = lds;                            // dM[2][k][co][tile]
     float* const Vl = lds + 2 * MSZ;                  // V [2][k][ci][tile]
-    float* const Xl = lds + 4 * MSZ;                  // raw x strip [ci][4 rows][GXW]
+    float* const Xl = lds + 4 * MSZ;                  // raw x strip [ci][NR rows][GXW]
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int cw = wid & 1, ciw = (wid >> 1) & 1, kh = wid >> 2;
@@ -476,16 +482,18 @@ __global__ __launch_bounds__(512, 2) void wino_wgrad_kernel(WinoWgradArgs a) {
 
     // this thread's transform duty: channel tch (a co for dM, a ci for V) and tile tt of the chunk
     const int tch = tid >> 3, tt = tid & 7;
-    // raw x staging duty: 1024 float4 (2 per thread) + 512 halo scalars (1 per thread)
-    //   float4 e in [0,1024): ci = e >> 4, row = (e >> 2) & 3, q = e & 3 ; scalar e: ci = e >> 3, row = (e >> 1) & 3, side = e & 1
+    const int ttr = tt / TPR, ttc = tt % TPR;         // tile row / column inside the chunk
+    const int tsw = tt ^ (((tch >> 4) & 1) << 2);     // LDS slot: 16-B halves swapped on rows 16-31, 48-63 (b128 banks)
+    // raw x staging duty: NX4 float4 (<= 2 per thread), e -> (ci, row, q) = (e / (NR*QPR), (e / QPR) % NR, e % QPR);
+    // with HALO 64*4*2 = 512 halo scalars, one per thread: (ci, row, side) = (tid >> 3, (tid >> 1) & 3, tid & 1)
     float4 xr0, xr1;
     float xh;
     float2 dy0, dy1;
     auto chunk_pos = [&](int c, int& s, int& p, int& q0) {
         s = c / CPI;
         const int r = c - s * CPI;
-        p = r / CPR;                                   // tile row
-        q0 = (r - p * CPR) * GT;                       // first tile column
+        p = (r / CPR) * TR;                            // first tile row
+        q0 = (r % CPR) * TPR;                          // first tile column
     };
     auto load_x = [&](int c) {
         int s, p, q0;
@@ -493,10 +501,10 @@ __global__ __launch_bounds__(512, 2) void wino_wgrad_kernel(WinoWgradArgs a) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int e = tid + 512 * i;
-            const int ci = e >> 4, row = (e >> 2) & 3, q = e & 3;
+            const int ci = e / (NR * QPR), row = (e / QPR) % NR, q = e % QPR;
             const int gy = 2 * p - 1 + row;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ci0 + ci < a.Cin && gy >= 0 && gy < H) {
+            if (e < NX4 && ci0 + ci < a.Cin && gy >= 0 && gy < H) {
                 if (MODE == 2) {
                     const float2 h = *reinterpret_cast<const float2*>(
                         a.x + (((size_t)s * a.Cin + ci0 + ci) * SH + (gy >> 1)) * SW + q0 + 2 * q);
@@ -507,27 +515,32 @@ __global__ __launch_bounds__(512, 2) void wino_wgrad_kernel(WinoWgradArgs a) {
             }
             if (i == 0) xr0 = v; else xr1 = v;
         }
-        const int ci = tid >> 3, row = (tid >> 1) & 3, side = tid & 1;
-        const int gy = 2 * p - 1 + row, gx = side ? 2 * q0 + 16 : 2 * q0 - 1;
-        xh = 0.f;
-        if (ci0 + ci < a.Cin && gy >= 0 && gy < H && gx >= 0 && gx < W)
-            xh = MODE == 2 ? a.x[(((size_t)s * a.Cin + ci0 + ci) * SH + (gy >> 1)) * SW + (gx >> 1)]
-                           : a.x[(((size_t)s * a.Cin + ci0 + ci) * H + gy) * W + gx];
+        if (HALO) {
+            const int ci = tid >> 3, row = (tid >> 1) & 3, side = tid & 1;
+            const int gy = 2 * p - 1 + row, gx = side ? 2 * q0 + 2 * TPR : 2 * q0 - 1;
+            xh = 0.f;
+            if (ci0 + ci < a.Cin && gy >= 0 && gy < H && gx >= 0 && gx < W)
+                xh = MODE == 2 ? a.x[(((size_t)s * a.Cin + ci0 + ci) * SH + (gy >> 1)) * SW + (gx >> 1)]
+                               : a.x[(((size_t)s * a.Cin + ci0 + ci) * H + gy) * W + gx];
+        }
     };
     auto store_x = [&]() {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int e = tid + 512 * i;
-            *reinterpret_cast<float4*>(Xl + (e >> 2) * GXW + 4 + 4 * (e & 3)) = i == 0 ? xr0 : xr1;
+            if (e < NX4) *reinterpret_cast<float4*>(Xl + (e / QPR) * GXW + 4 + 4 * (e % QPR)) = i == 0 ? xr0 : xr1;
         }
-        Xl[(tid >> 1) * GXW + ((tid & 1) ? 20 : 3)] = xh;
+        if (HALO) Xl[(tid >> 1) * GXW + ((tid & 1) ? 4 + 2 * TPR : 3)] = xh;
     };
+    if (!HALO) {                                       // the strip spans the map: both halo columns are padding
+        for (int e = tid; e < 64 * NR * 2; e += 512) Xl[(e >> 1) * GXW + ((e & 1) ? 4 + 2 * TPR : 3)] = 0.f;
+    }
     auto load_dy = [&](int c) {
         int s, p, q0;
         chunk_pos(c, s, p, q0);
         dy0 = dy1 = make_float2(0.f, 0.f);
         if (co0 + tch < a.Cout) {
-            const float* g = a.dy + (((size_t)s * a.Cout + co0 + tch) * H + 2 * p) * W + 2 * (q0 + tt);
+            const float* g = a.dy + (((size_t)s * a.Cout + co0 + tch) * H + 2 * (p + ttr)) * W + 2 * (q0 + ttc);
             dy0 = *reinterpret_cast<const float2*>(g);
             dy1 = *reinterpret_cast<const float2*>(g + W);
         }
@@ -535,7 +548,7 @@ __global__ __launch_bounds__(512, 2) void wino_wgrad_kernel(WinoWgradArgs a) {
     auto xform_dy = [&](int buf) {                     // dM = A dY A^T, A^T = [[1,1,1,0],[0,1,-1,-1]]
         const float r[4][2] = {{dy0.x, dy0.y}, {dy0.x + dy1.x, dy0.y + dy1.y}, {dy0.x - dy1.x, dy0.y - dy1.y},
                                {-dy1.x, -dy1.y}};
-        float* mo = Ml + buf * MSZ + tch * GT + tt;
+        float* mo = Ml + buf * MSZ + tch * GT + tsw;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             mo[(4 * i + 0) * 64 * GT] = r[i][0];
@@ -546,12 +559,12 @@ __global__ __launch_bounds__(512, 2) void wino_wgrad_kernel(WinoWgradArgs a) {
     };
     float d[16];
     auto xform_x_read = [&](int r) {
-        const float* p = Xl + (tch * 4 + r) * GXW + 2 * tt + 3;
+        const float* p = Xl + (tch * NR + 2 * ttr + r) * GXW + 2 * ttc + 3;
 #pragma unroll
         for (int c = 0; c < 4; ++c) d[r * 4 + c] = p[c];
     };
     auto xform_x_write = [&](int r, int buf) {         // V = B^T d B
-        float* vo = Vl + buf * MSZ + tch * GT + tt;
+        float* vo = Vl + buf * MSZ + tch * GT + tsw;
         float t[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -583,8 +596,8 @@ __global__ __launch_bounds__(512, 2) void wino_wgrad_kernel(WinoWgradArgs a) {
         __syncthreads();
     }
 
-    const int aoff = 8 * kh * 64 * GT + (cw * 32 + li) * GT + 4 * lh;
-    const int boff = 8 * kh * 64 * GT + (ciw * 32 + li) * GT + 4 * lh;
+    const int aoff = 8 * kh * 64 * GT + (cw * 32 + li) * GT + 4 * (lh ^ ((li >> 4) & 1));
+    const int boff = 8 * kh * 64 * GT + (ciw * 32 + li) * GT + 4 * (lh ^ ((li >> 4) & 1));
     for (int c = 0; c < n; ++c) {
         const int cur = c & 1, nxt = cur ^ 1;
         const bool has1 = c + 1 < n, has2 = c + 2 < n;
@@ -687,7 +700,7 @@ __global__ __launch_bounds__(256) void wino_wgrad_finish_kernel(const float* __r
 template <int LOGW, int MODE>
 int launch_wino_wgrad(WinoWgradArgs a, float* dw, size_t ws_floats, hipStream_t st) {
     constexpr int W = 1 << LOGW;
-    a.nchunks = a.S * (W / 2) * (W / 2) / GT;
+    a.nchunks = a.S * ((W / 2) * (W / 2) / GT);
     const int nco = a.CoutP / 64, nci = (a.CinQ + 63) / 64;
     const size_t slab_floats = (size_t)16 * a.CoutP * a.CinQ;
     int z = 256 / (nco * nci);
@@ -726,10 +739,10 @@ long vf_wino_wgrad_ws_floats(int S, int Cin, int Cout, int H, int W) {
 }
 
 int vf_wino_wgrad_supported(int H, int W, int mode) {
-    return H == W && (W == 16 || W == 32 || W == 64) && (mode == 0 || mode == 2);
+    return H == W && (W == 8 || W == 16 || W == 32 || W == 64) && (mode == 0 || mode == 2);
 }
 
-// dw[Cout][Cin][3][3] of a stride-1 3x3 conv (H = W = output size in {16, 32, 64}; mode 2: x is stored at half
+// dw[Cout][Cin][3][3] of a stride-1 3x3 conv (H = W = output size in {8, 16, 32, 64}; mode 2: x is stored at half
 // size and nearest-upsampled on read) via Winograd F(2x2,3x3)
 int vf_wino_wgrad(const float* x, const float* dy, float* dw, float* ws, long ws_floats, int S, int Cin, int Cout,
                   int H, int W, int mode, void* stream) {
@@ -742,6 +755,7 @@ int vf_wino_wgrad(const float* x, const float* dy, float* dw, float* ws, long ws
 #define VF_WG(LW) \
     return mode == 2 ? launch_wino_wgrad<LW, 2>(a, dw, (size_t)ws_floats, st) \
                      : launch_wino_wgrad<LW, 0>(a, dw, (size_t)ws_floats, st)
+    if (W == 8) VF_WG(3);
     if (W == 16) VF_WG(4);
     if (W == 32) VF_WG(5);
     VF_WG(6);

@@ -191,7 +191,7 @@ def use_winograd_wgrad(S, Cin, Cout, H, W, KS, m):
     """Weight gradients split over (co, ci, tile range), so the grid fills the chip at any map size."""
     if not (WINOGRAD and WINOGRAD_WGRAD) or KS != 3 or not _lib.load().vf_wino_wgrad_supported(H, W, m):
         return False
-    return FORCE_WINOGRAD or S * (H // 2) * (W // 2) >= 8 * 512
+    return FORCE_WINOGRAD or S * (H // 2) * (W // 2) >= 8 * 128
 
 
 def _packed_wino(layer, force):
