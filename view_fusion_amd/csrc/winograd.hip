@@ -465,7 +465,8 @@ __global__ __launch_bounds__(512, 2) void wino_wgrad_kernel(WinoWgradArgs a) {
     constexpr int CPR = (W / 2) / TPR;                // chunks per (group of TR) tile rows
     constexpr int CPI = (H / 2) / TR * CPR;           // chunks per image
     constexpr int MSZ = 16 * 64 * GT;                 // floats of one dM (or V) buffer
-    constexpr int XSZ = 64 * NR * GXW;
+    constexpr int XCS = NR * GXW + 16;                // strip stride per channel = 16 mod 32 banks: window reads 2-way, not 4-way
+    constexpr int XSZ = 64 * XCS;
 
     __shared__ __attribute__((aligned(16))) float lds[4 * MSZ + XSZ];
     float* const Ml = lds;                            // dM[2][k][co][tile]
@@ -528,12 +529,14 @@ __global__ __launch_bounds__(512, 2) void wino_wgrad_kernel(WinoWgradArgs a) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int e = tid + 512 * i;
-            if (e < NX4) *reinterpret_cast<float4*>(Xl + (e / QPR) * GXW + 4 + 4 * (e % QPR)) = i == 0 ? xr0 : xr1;
+            if (e < NX4)
+                *reinterpret_cast<float4*>(Xl + (e / (NR * QPR)) * XCS + ((e / QPR) % NR) * GXW + 4 + 4 * (e % QPR)) = i == 0 ? xr0 : xr1;
         }
-        if (HALO) Xl[(tid >> 1) * GXW + ((tid & 1) ? 4 + 2 * TPR : 3)] = xh;
+        if (HALO) Xl[(tid >> 3) * XCS + ((tid >> 1) & 3) * GXW + ((tid & 1) ? 4 + 2 * TPR : 3)] = xh;
     };
     if (!HALO) {                                       // the strip spans the map: both halo columns are padding
-        for (int e = tid; e < 64 * NR * 2; e += 512) Xl[(e >> 1) * GXW + ((e & 1) ? 4 + 2 * TPR : 3)] = 0.f;
+        for (int e = tid; e < 64 * NR * 2; e += 512)
+            Xl[(e / (2 * NR)) * XCS + ((e >> 1) % NR) * GXW + ((e & 1) ? 4 + 2 * TPR : 3)] = 0.f;
     }
     auto load_dy = [&](int c) {
         int s, p, q0;
@@ -559,7 +562,7 @@ __global__ __launch_bounds__(512, 2) void wino_wgrad_kernel(WinoWgradArgs a) {
     };
     float d[16];
     auto xform_x_read = [&](int r) {
-        const float* p = Xl + (tch * NR + 2 * ttr + r) * GXW + 2 * ttc + 3;
+        const float* p = Xl + tch * XCS + (2 * ttr + r) * GXW + 2 * ttc + 3;
 #pragma unroll
         for (int c = 0; c < 4; ++c) d[r * 4 + c] = p[c];
     };
