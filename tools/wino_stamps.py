@@ -16,7 +16,7 @@ lib = ctypes.CDLL(so)
 P, I, L = ctypes.c_void_p, ctypes.c_int, ctypes.c_long
 lib.vf_wino_pack_sizes.argtypes = [I, I, ctypes.POINTER(L), ctypes.POINTER(L)]
 lib.vf_wino_pack_weights.argtypes = [P, P, P, I, I, P]
-lib.vf_wino_conv_fwd.argtypes = [P, P, P, P, P, P, I, I, I, I, I, I, P]
+lib.vf_wino_conv_fwd.argtypes = [P, P, P, P, P, P, P, ctypes.c_long, I, I, I, I, I, I, P]
 dev = torch.device("cuda:0")
 w = torch.randn(Cout, Cin, 3, 3, device=dev) / (Cin * 9) ** 0.5
 x = torch.rand(S, Cin, H, H, device=dev); y = torch.empty(S, Cout, H, H, device=dev)
@@ -26,7 +26,7 @@ st = torch.cuda.current_stream().cuda_stream
 lib.vf_wino_pack_weights(w.data_ptr(), uf.data_ptr(), ub.data_ptr(), Cout, Cin, st)
 stamps = torch.zeros(1 << 20, dtype=torch.int64, device=dev)
 for _ in range(3):
-    assert lib.vf_wino_conv_fwd(x.data_ptr(), uf.data_ptr(), None, stamps.data_ptr(), None, y.data_ptr(), S, Cin, Cout, H, H, 0, st) == 0
+    assert lib.vf_wino_conv_fwd(x.data_ptr(), uf.data_ptr(), None, stamps.data_ptr(), None, y.data_ptr(), None, 0, S, Cin, Cout, H, H, 0, st) == 0
 torch.cuda.synchronize()
 a = stamps.cpu().numpy().reshape(-1, 8); a = a[a[:, 2] != 0]; n = len(a)
 wall = (a[:, 7].max() - a[:, 6].min()) / 100e6

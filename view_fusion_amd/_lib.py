@@ -33,7 +33,8 @@ SIGNATURES = {
     "vf_wino_pack_sizes": [_I, _I, ctypes.POINTER(_L), ctypes.POINTER(_L)],
     "vf_wino_pack_weights": [_P, _P, _P, _I, _I, _P],
     "vf_wino_pack_weights_multi": [_P, _I, _L, _P],
-    "vf_wino_conv_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "vf_wino_conv_ws_floats": [_I, _I, _I, _I, _I],
+    "vf_wino_conv_fwd": [_P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P],
     "vf_wino_wgrad_ws_floats": [_I, _I, _I, _I, _I],
     "vf_wino_wgrad_supported": [_I, _I, _I],
     "vf_wino_wgrad": [_P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P],
@@ -54,7 +55,7 @@ SIGNATURES = {
     "vf_compose_mse_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "vf_p_sample_tail": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
 }
-_RESTYPE = {"vf_conv_wgrad_ws_floats": _L, "vf_wino_wgrad_ws_floats": _L, "vf_conv_fwd_ws_floats": _L}
+_RESTYPE = {"vf_conv_wgrad_ws_floats": _L, "vf_wino_conv_ws_floats": _L, "vf_wino_wgrad_ws_floats": _L, "vf_conv_fwd_ws_floats": _L}
 
 _lib = None
 

@@ -31,6 +31,10 @@ struct WinoArgs {
     const float* res;
     float* y;
     int S, Cin, Cout, CinP, CoutP;
+    // tail splitting (small maps): workgroups [0, nfull) compute whole tiles; workgroup nfull + j*tail_split + p
+    // computes the p-th K range of tile nfull + j and leaves a raw partial output in ws (wino_fixup_kernel)
+    int nfull, tail_split;
+    float* ws;
 };
 
 template <int LOGW, int MODE>
@@ -94,20 +98,27 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(WinoArgs a) {
     const int cw = wid & 1, tw = (wid >> 1) & 1, kh = wid >> 2;
     const int li = lane & 31, lh = lane >> 5;
     const int ncot = a.CoutP / WTCO;
-    const unsigned logical = xcd_remap(blockIdx.x, gridDim.x);
+    const bool partial = (int)blockIdx.x >= a.nfull;
+    const int tail_id = partial ? (int)blockIdx.x - a.nfull : 0;
+    const unsigned logical = partial ? a.nfull + tail_id / a.tail_split : xcd_remap(blockIdx.x, a.nfull);
     const int cot = logical % ncot;
     const int wg = logical / ncot;
     const int s = wg / G::WPI;
     const int r0 = (wg % G::WPI) * 2 * G::TR;           // first output row of this workgroup
     const int co0 = cot * WTCO;
-    const int nch = a.CinP / WCK;
+    int c0 = 0, nch = a.CinP / WCK;                     // this workgroup's chunk range [c0, c0 + nch)
+    if (partial) {
+        const int per = (nch + a.tail_split - 1) / a.tail_split;
+        c0 = (tail_id % a.tail_split) * per;
+        nch = max(0, min(nch - c0, per));
+    }
 
 #ifdef VF_CONV_STAMPS   // diagnostic build only (tools/wino_stamps.py)
     long long st_[2] = {clock64(), 0}, rt0_ = wall_clock64();
 #endif
     for (int i = tid; i < 2 * PSZ; i += NT_) Pl[i] = 0.f;    // halo columns stay zero in both buffers
 
-    const float* usrc = a.u + (size_t)cot * nch * USZ;
+    const float* usrc = a.u + ((size_t)cot * (a.CinP / WCK) + c0) * USZ;
     // named registers + macros (not arrays behind lambdas: those end up in scratch memory)
     float4 ur0, ur1, ur2, ur3;
     float4 xr0 = make_float4(0.f, 0.f, 0.f, 0.f), xr1 = xr0;
@@ -134,8 +145,8 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(WinoArgs a) {
     const float* xsrc = a.x + (size_t)s * a.Cin * (G::SH * G::SW);
     auto fetch_x = [&](int i, int c) -> float4 {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (xok[i] && c * WCK + xci[i] < a.Cin) {
-            const float* p = xsrc + (size_t)c * WCK * (G::SH * G::SW) + xgo[i];
+        if (xok[i] && (c0 + c) * WCK + xci[i] < a.Cin) {
+            const float* p = xsrc + (size_t)(c0 + c) * WCK * (G::SH * G::SW) + xgo[i];
             if (MODE == 0) v = *reinterpret_cast<const float4*>(p);
             else { const float2 t = *reinterpret_cast<const float2*>(p); v = make_float4(t.x, t.x, t.y, t.y); }
         }
@@ -283,7 +294,19 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(WinoArgs a) {
             for (int q = 0; q < 4; ++q) xch[(r * 4 + q) * 64 + lane] = part[r][q];
     }
     __syncthreads();
-    if (kh == 0 && s < a.S) {
+    if (kh == 0 && partial) {                            // raw partial tile: ws[tail_id][co 64][tile 64][2x2]
+        const int tl = tw * 32 + li;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int col = cw * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            float4 v;
+            v.x = part[r][0] + xch[(r * 4 + 0) * 64 + lane];
+            v.y = part[r][1] + xch[(r * 4 + 1) * 64 + lane];
+            v.z = part[r][2] + xch[(r * 4 + 2) * 64 + lane];
+            v.w = part[r][3] + xch[(r * 4 + 3) * 64 + lane];
+            *reinterpret_cast<float4*>(a.ws + (((size_t)tail_id * WTCO + col) * WTT + tl) * 4) = v;
+        }
+    } else if (kh == 0 && s < a.S) {
         const int tl = tw * 32 + li;
         const int tr = tl / G::TW, tq = tl % G::TW;
         const int orow = r0 + 2 * tr, ocol = 2 * tq;
@@ -376,11 +399,74 @@ __global__ void wino_pack_multi_kernel(const WPackDesc* __restrict__ desc, int n
 
 inline int rup(int v, int m) { return (v + m - 1) / m * m; }
 
+// Sums the K-range partials of the tail tiles in a fixed order and applies the epilogue
+// (bias + per-view bias + residual).  One thread per (tail tile, co, 2x2 tile).
+template <int LOGW>
+__global__ __launch_bounds__(256) void wino_fixup_kernel(WinoArgs a, int ntail) {
+    using G = WGeo<LOGW, 0>;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int tl = idx % WTT;
+    const int col = (idx / WTT) % WTCO;
+    const int j = idx / (WTT * WTCO);
+    if (j >= ntail) return;
+    const int ncot = a.CoutP / WTCO;
+    const int logical = a.nfull + j;
+    const int cot = logical % ncot, wg = logical / ncot;
+    const int s = wg / G::WPI, r0 = (wg % G::WPI) * 2 * G::TR;
+    const int co = cot * WTCO + col;
+    if (s >= a.S || co >= a.Cout) return;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int p = 0; p < a.tail_split; ++p) {
+        const float4 t = *reinterpret_cast<const float4*>(
+            a.ws + ((((size_t)j * a.tail_split + p) * WTCO + col) * WTT + tl) * 4);
+        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+    }
+    float b = 0.f;
+    if (a.bias) b += a.bias[co];
+    if (a.vbias) b += a.vbias[(size_t)s * a.Cout + co];
+    const int orow = r0 + 2 * (tl / G::TW), ocol = 2 * (tl % G::TW);
+    const size_t o = ((size_t)s * a.Cout + co) * G::HW + (size_t)orow * G::W + ocol;
+    float2 v0 = make_float2(v.x + b, v.y + b), v1 = make_float2(v.z + b, v.w + b);
+    if (a.res) {
+        const float2 q0 = *reinterpret_cast<const float2*>(a.res + o);
+        const float2 q1 = *reinterpret_cast<const float2*>(a.res + o + G::W);
+        v0.x += q0.x; v0.y += q0.y; v1.x += q1.x; v1.y += q1.y;
+    }
+    *reinterpret_cast<float2*>(a.y + o) = v0;
+    *reinterpret_cast<float2*>(a.y + o + G::W) = v1;
+}
+
+constexpr int WINO_SLOTS = 256;       // one 155 KB-LDS workgroup per CU
+
+// how a grid of T equal tiles is finished when T is not a multiple of the slot count: the last
+// T mod 256 tiles are split over K into `split` parts so that the tail round is full too
+inline void wino_tail_plan(int T, int nch, int* nfull, int* split) {
+    *nfull = T;
+    *split = 1;
+    const int R = T % WINO_SLOTS;
+    if (R == 0 || T / WINO_SLOTS >= 3) return;          // tail round costs < 1/4 of the launch: leave it
+    int sp = WINO_SLOTS / R;
+    if (sp > 8) sp = 8;
+    if (sp > nch / 4) sp = nch / 4;                       // at least 4 chunks per part
+    if (sp < 2) return;
+    *nfull = T - R;
+    *split = sp;
+}
+
 template <int LOGW, int MODE>
-int launch_wino(const WinoArgs& a, hipStream_t st) {
+int launch_wino(WinoArgs a, size_t ws_floats, hipStream_t st) {
     using G = WGeo<LOGW, MODE>;
-    const int nblk = a.S * G::WPI * (a.CoutP / WTCO);
-    hipLaunchKernelGGL((wino_conv_kernel<LOGW, MODE>), dim3(nblk), dim3(512), 0, st, a);
+    const int T = a.S * G::WPI * (a.CoutP / WTCO);
+    wino_tail_plan(T, a.CinP / WCK, &a.nfull, &a.tail_split);
+    const int ntail = T - a.nfull;
+    if ((size_t)ntail * a.tail_split * WTCO * WTT * 4 > ws_floats || !a.ws) {   // no room: plain grid
+        a.nfull = T;
+        a.tail_split = 1;
+    }
+    const int nt = T - a.nfull;
+    hipLaunchKernelGGL((wino_conv_kernel<LOGW, MODE>), dim3(a.nfull + nt * a.tail_split), dim3(512), 0, st, a);
+    if (nt > 0)
+        hipLaunchKernelGGL((wino_fixup_kernel<LOGW>), dim3((nt * WTCO * WTT + 255) / 256), dim3(256), 0, st, a, nt);
     VF_RETURN_LAST_ERROR();
 }
 
@@ -410,24 +496,35 @@ int vf_wino_pack_weights_multi(const void* desc, int nlayers, long total_blocks,
     VF_RETURN_LAST_ERROR();
 }
 
-// 1 if vf_wino_conv_fwd supports this (output) size / mode: 3x3 stride 1, H = W in {32, 64}, modes 0 / 2.
+// 1 if vf_wino_conv_fwd supports this (output) size / mode: 3x3 stride 1, H = W in {16, 32, 64}, modes 0 / 2.
 int vf_wino_supported(int H, int W, int mode) {
-    return (H == W && (W == 32 || W == 64) && (mode == 0 || mode == 2)) ? 1 : 0;
+    return (H == W && (W == 16 || W == 32 || W == 64) && (mode == 0 || mode == 2)) ? 1 : 0;
+}
+
+// workspace floats vf_wino_conv_fwd wants for its split tail tiles (0 when the grid divides evenly)
+long vf_wino_conv_ws_floats(int S, int Cin, int Cout, int H, int W) {
+    const int T = S * ((H / 2) * (W / 2) / WTT) * (rup(Cout, WTCO) / WTCO);
+    int nfull, split;
+    wino_tail_plan(T, rup(Cin, WCK) / WCK, &nfull, &split);
+    return (long)(T - nfull) * split * WTCO * WTT * 4;
 }
 
 // y = conv3x3(x) (+bias +view_bias +residual), pad 1, stride 1, via fused Winograd F(2x2,3x3).
 // u_packed from vf_wino_pack_weights (forward pack for the conv, backward pack for its dgrad).
 int vf_wino_conv_fwd(const float* x, const float* u_packed, const float* bias, const float* view_bias,
-                     const float* residual, float* y, int S, int Cin, int Cout, int H, int W, int mode,
-                     void* stream) {
+                     const float* residual, float* y, float* ws, long ws_floats, int S, int Cin, int Cout, int H,
+                     int W, int mode, void* stream) {
     if (S <= 0) return 0;
     if (!vf_wino_supported(H, W, mode)) return (int)hipErrorInvalidValue;
     WinoArgs a;
     a.x = x; a.u = u_packed; a.bias = bias; a.vbias = view_bias; a.res = residual; a.y = y;
     a.S = S; a.Cin = Cin; a.Cout = Cout; a.CinP = rup(Cin, WCK); a.CoutP = rup(Cout, WTCO);
+    a.ws = ws;
     hipStream_t st = (hipStream_t)stream;
-    if (W == 32) return mode == 0 ? launch_wino<5, 0>(a, st) : launch_wino<5, 2>(a, st);
-    return mode == 0 ? launch_wino<6, 0>(a, st) : launch_wino<6, 2>(a, st);
+    const size_t nws = ws ? (size_t)ws_floats : 0;
+    if (W == 16) return mode == 0 ? launch_wino<4, 0>(a, nws, st) : launch_wino<4, 2>(a, nws, st);
+    if (W == 32) return mode == 0 ? launch_wino<5, 0>(a, nws, st) : launch_wino<5, 2>(a, nws, st);
+    return mode == 0 ? launch_wino<6, 0>(a, nws, st) : launch_wino<6, 2>(a, nws, st);
 }
 
 }  // extern "C"

@@ -144,6 +144,15 @@ def _conv_ws(device, S, Cin, Cout, H, W, KS):
     return ws, ws.numel()
 
 
+def _wino_ws(device, S, Cin, Cout, H, W):
+    """Room for the K-split tail tiles of a Winograd launch whose tile count does not divide the CUs."""
+    need = _lib.load().vf_wino_conv_ws_floats(S, Cin, Cout, H, W)
+    if need <= 0:
+        return None, 0
+    ws = _workspace(device, need)
+    return ws, ws.numel()
+
+
 def _packed(layer, force):
     """Packed forward / dgrad weights of a conv layer.
 
@@ -290,8 +299,10 @@ class _Conv2dFn(torch.autograd.Function):
         wino = use_winograd(S, Cout, H, W, KS, m)
         if wino:
             wf, wb = _packed_wino(layer, force=training)
+            ws, nws = _wino_ws(x.device, S, Cin, Cout, H, W)
             _launch("conv_fwd", flops, "vf_wino_conv_fwd", _ptr(x), _ptr(wf), _ptr(bias), _ptr(view_bias),
-                    _ptr(residual), _ptr(y), S, Cin, Cout, H, W, m, _stream(), tag=(Cin, Cout, H, KS, m))
+                    _ptr(residual), _ptr(y), _ptr(ws), nws, S, Cin, Cout, H, W, m, _stream(),
+                    tag=(Cin, Cout, H, KS, m))
         else:
             wf, wb = _packed(layer, force=training)
             ws, nws = _conv_ws(x.device, S, Cin, Cout, H, W, KS)
@@ -316,8 +327,9 @@ class _Conv2dFn(torch.autograd.Function):
         dx = dw = db = dvb = dres = None
         if ctx.needs_input_grad[0] and ctx.wino:      # Winograd dgrad (dy and dx have the conv's output size)
             dfull = torch.empty(S, Cin, H, W, device=x.device, dtype=torch.float32)
+            ws, nws = _wino_ws(x.device, S, Cout, Cin, H, W)
             _launch("conv_dgrad", ctx.flops, "vf_wino_conv_fwd", _ptr(dy), _ptr(ctx.wb), None, None, None,
-                    _ptr(dfull), S, Cout, Cin, H, W, 0, st, tag=ctx.tag)
+                    _ptr(dfull), _ptr(ws), nws, S, Cout, Cin, H, W, 0, st, tag=ctx.tag)
             if m == 2:                                 # upsample + conv: 2x2 sum-pool back to the source size
                 dx = torch.empty_like(x)
                 _lib.call("vf_sumpool2", _ptr(dfull), _ptr(dx), dx.numel(), Wi, st)
