@@ -51,7 +51,7 @@ int vf_conv_wgrad(const float* x, const float* dy, float* dw_oihw, float* ws, lo
                   int Cout, int H, int W, int KS, int mode, void* stream);
 int vf_sumpool2(const float* x, float* y, long n_out, int Wo, void* stream);
 
-/* fused Winograd F(2x2,3x3) path for stride-1 3x3 convs on 16x16 / 32x32 / 64x64 maps (forward and
+/* fused Winograd F(2x2,3x3) path for stride-1 3x3 convs on 8x8 / 16x16 / 32x32 / 64x64 maps (forward and
  * dgrad); modes 0 and 2 as above.  Pack layout differs from the direct kernel's. */
 int vf_wino_supported(int H, int W, int mode);
 int vf_wino_pack_sizes(int Cout, int Cin, long* fwd_floats, long* bwd_floats);
@@ -62,6 +62,8 @@ int vf_wino_pack_weights_multi(const void* desc, int nlayers, long total_blocks,
 /* ws: room for the K-split partial tiles of a grid that does not divide the 256 CUs (vf_wino_conv_ws_floats;
  * NULL / too small = plain grid) */
 long vf_wino_conv_ws_floats(int S, int Cin, int Cout, int H, int W);
+/* expected CU fill in percent under the tail plan (+ the workgroup-tile count): policy input for hosts */
+int vf_wino_conv_fill_pct(int S, int Cin, int Cout, int H, int W, int* tiles_out);
 int vf_wino_conv_fwd(const float* x, const float* u_packed, const float* bias, const float* view_bias,
                      const float* residual, float* y, float* ws, long ws_floats, int S, int Cin, int Cout, int H,
                      int W, int mode, void* stream);

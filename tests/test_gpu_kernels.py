@@ -126,10 +126,22 @@ def test_conv_winograd_path(dev, Cin, Cout, Hin, mode):
         ops.FORCE_WINOGRAD = False
 
 
+@pytest.mark.parametrize("Cin,Cout,Hin,mode,S", [(320, 320, 8, "same", 6), (192, 320, 8, "same", 9), (64, 96, 4, "up2", 5),
+                                                 (192, 192, 16, "same", 4)])
+def test_conv_winograd_small_maps(dev, Cin, Cout, Hin, mode, S):
+    """8x8 maps pack four views into one 64-tile workgroup (ragged last group); all tiles K-split."""
+    from view_fusion_amd import ops
+    ops.FORCE_WINOGRAD = True
+    try:
+        test_conv_fwd_bwd(dev, Cin, Cout, Hin, 3, mode, S)
+    finally:
+        ops.FORCE_WINOGRAD = False
+
+
 def test_conv_large_batch_split_k(dev):
     """S large enough that wgrad runs many pixel tiles per slice; odd S for the 8x8 two-image tiles."""
     from view_fusion_amd import ops
-    for (Cin, Cout, H, S) in [(64, 64, 64, 40), (320, 320, 8, 97)]:
+    for (Cin, Cout, H, S) in [(64, 64, 64, 40), (320, 320, 8, 97), (192, 192, 16, 96)]:
         layer = torch.nn.Conv2d(Cin, Cout, 3, padding=1)
         x, gy = rnd(S, Cin, H, H, seed=1), rnd(S, Cout, H, H, seed=2)
         xc = x.clone().requires_grad_(True)

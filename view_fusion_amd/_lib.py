@@ -34,6 +34,7 @@ SIGNATURES = {
     "vf_wino_pack_weights": [_P, _P, _P, _I, _I, _P],
     "vf_wino_pack_weights_multi": [_P, _I, _L, _P],
     "vf_wino_conv_ws_floats": [_I, _I, _I, _I, _I],
+    "vf_wino_conv_fill_pct": [_I, _I, _I, _I, _I, ctypes.POINTER(_I)],
     "vf_wino_conv_fwd": [_P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P],
     "vf_wino_wgrad_ws_floats": [_I, _I, _I, _I, _I],
     "vf_wino_wgrad_supported": [_I, _I, _I],

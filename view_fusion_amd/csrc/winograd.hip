@@ -42,12 +42,25 @@ struct WGeo {
     static constexpr int W = 1 << LOGW, H = W, HW = W * H, PAD = 1;
     static constexpr int SH = MODE == 2 ? H / 2 : H, SW = MODE == 2 ? W / 2 : W;   // source size
     static constexpr int TW = W / 2;                 // tiles per output row
-    static constexpr int TR = WTT / TW;              // tile rows per workgroup
-    static constexpr int WPI = (H / 2) / TR;         // workgroups per image
-    static constexpr int PH = 2 * TR + 2, PW = W + 8;
-    static constexpr int PS = PH * PW;
+    static constexpr int IPG = TW * TW >= WTT ? 1 : WTT / (TW * TW);   // images per workgroup (4 on 8x8 maps)
+    static constexpr int TR = IPG == 1 ? WTT / TW : TW;                // tile rows per image in a workgroup
+    static constexpr int WPI = IPG == 1 ? (H / 2) / TR : 1;            // workgroups per image (group)
+    static constexpr int RPI = 2 * TR + 2;                             // haloed patch rows per image
+    static constexpr int PH = IPG * RPI;
+    // patch row: idx 3 = left halo, 4.. = pixels, 4+W = right halo.  With several images per workgroup the
+    // row is W+4 wide and the right halo aliases the (never written, zero) idx 0 of the next row.
+    static constexpr int PW = IPG == 1 ? W + 8 : W + 4;
+    static constexpr int PS = PH * PW + (IPG == 1 ? 0 : 4);
     static constexpr int Q = W / 4;
-    static_assert(TR >= 1 && WPI >= 1, "feature map too small for the 64-tile workgroup");
+    static_assert(TR >= 1 && WPI >= 1 && IPG * TR * TW == WTT, "unsupported map size for the 64-tile workgroup");
+    // tile tl of a workgroup -> image in the group, tile row, tile column
+    static __device__ __forceinline__ int t_img(int tl) { return tl / (TW * TR); }
+    static __device__ __forceinline__ int t_row(int tl) { return (tl / TW) % TR; }
+    static __device__ __forceinline__ int t_col(int tl) { return tl % TW; }
+    // workgroup index (tile group) -> first view, first output row
+    static __device__ __forceinline__ int g_view(int wg) { return IPG == 1 ? wg / WPI : wg * IPG; }
+    static __device__ __forceinline__ int g_row(int wg) { return IPG == 1 ? (wg % WPI) * 2 * TR : 0; }
+    static int groups(int S) { return IPG == 1 ? S * WPI : (S + IPG - 1) / IPG; }
 };
 
 // same patch addressing as conv.hip's load_patch4 (modes 0 and 2)
@@ -103,8 +116,8 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(WinoArgs a) {
     const unsigned logical = partial ? a.nfull + tail_id / a.tail_split : xcd_remap(blockIdx.x, a.nfull);
     const int cot = logical % ncot;
     const int wg = logical / ncot;
-    const int s = wg / G::WPI;
-    const int r0 = (wg % G::WPI) * 2 * G::TR;           // first output row of this workgroup
+    const int s = G::g_view(wg);                        // first (for 8x8 maps: of four) view of this workgroup
+    const int r0 = G::g_row(wg);                        // first output row of this workgroup
     const int co0 = cot * WTCO;
     int c0 = 0, nch = a.CinP / WCK;                     // this workgroup's chunk range [c0, c0 + nch)
     if (partial) {
@@ -136,11 +149,12 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(WinoArgs a) {
         const int q = e % G::Q;
         const int t1 = e / G::Q;
         const int pr = t1 % G::PH, ci = t1 / G::PH;
-        const int uy = r0 + pr - 1;
-        xok[i] = i < NXR && e < NX4 && s < a.S && uy >= 0 && uy < G::H;
+        const int img = pr / G::RPI;
+        const int uy = r0 + pr % G::RPI - 1;
+        xok[i] = i < NXR && e < NX4 && s + img < a.S && uy >= 0 && uy < G::H;
         xci[i] = ci;
-        xgo[i] = ci * (G::SH * G::SW) + (MODE == 0 ? uy * G::SW + 4 * q : (uy >> 1) * G::SW + 2 * q);
-        xlo[i] = t1 * G::PW + 4 * q + 4;
+        xgo[i] = (img * a.Cin + ci) * (G::SH * G::SW) + (MODE == 0 ? uy * G::SW + 4 * q : (uy >> 1) * G::SW + 2 * q);
+        xlo[i] = ci * G::PS + pr * G::PW + 4 * q + 4;
     }
     const float* xsrc = a.x + (size_t)s * a.Cin * (G::SH * G::SW);
     auto fetch_x = [&](int i, int c) -> float4 {
@@ -162,7 +176,7 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(WinoArgs a) {
     // input transform of this thread's 4x4 window (B^T d B): 512 windows = 8 channels x 64 tiles
     float d[16];
     const int wtl = tid & 63, wci = tid >> 6;
-    const int wpo = wci * G::PS + (2 * (wtl / G::TW)) * G::PW + 2 * (wtl % G::TW) + 3;
+    const int wpo = wci * G::PS + (G::t_img(wtl) * G::RPI + 2 * G::t_row(wtl)) * G::PW + 2 * G::t_col(wtl) + 3;
     const int wvo = wci * WTT + wtl;
     auto win_read_row = [&](int r, int buf) {
         const float* p = Pl + buf * PSZ + wpo + r * G::PW;
@@ -306,10 +320,10 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(WinoArgs a) {
             v.w = part[r][3] + xch[(r * 4 + 3) * 64 + lane];
             *reinterpret_cast<float4*>(a.ws + (((size_t)tail_id * WTCO + col) * WTT + tl) * 4) = v;
         }
-    } else if (kh == 0 && s < a.S) {
+    } else if (kh == 0 && s + G::t_img(tw * 32 + li) < a.S) {
         const int tl = tw * 32 + li;
-        const int tr = tl / G::TW, tq = tl % G::TW;
-        const int orow = r0 + 2 * tr, ocol = 2 * tq;
+        const int sv = s + G::t_img(tl);
+        const int orow = r0 + 2 * G::t_row(tl), ocol = 2 * G::t_col(tl);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int co = co0 + cw * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -317,9 +331,9 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(WinoArgs a) {
             float b = 0.f;
             if (a.bias) b += a.bias[co];
 #ifndef VF_CONV_STAMPS
-            if (a.vbias) b += a.vbias[(size_t)s * a.Cout + co];
+            if (a.vbias) b += a.vbias[(size_t)sv * a.Cout + co];
 #endif
-            const size_t o = ((size_t)s * a.Cout + co) * G::HW + (size_t)orow * G::W + ocol;
+            const size_t o = ((size_t)sv * a.Cout + co) * G::HW + (size_t)orow * G::W + ocol;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 float2 v = make_float2(part[r][2 * i] + xch[(r * 4 + 2 * i) * 64 + lane] + b,
@@ -412,7 +426,7 @@ __global__ __launch_bounds__(256) void wino_fixup_kernel(WinoArgs a, int ntail) 
     const int ncot = a.CoutP / WTCO;
     const int logical = a.nfull + j;
     const int cot = logical % ncot, wg = logical / ncot;
-    const int s = wg / G::WPI, r0 = (wg % G::WPI) * 2 * G::TR;
+    const int s = G::g_view(wg) + G::t_img(tl), r0 = G::g_row(wg);
     const int co = cot * WTCO + col;
     if (s >= a.S || co >= a.Cout) return;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -424,7 +438,7 @@ __global__ __launch_bounds__(256) void wino_fixup_kernel(WinoArgs a, int ntail) 
     float b = 0.f;
     if (a.bias) b += a.bias[co];
     if (a.vbias) b += a.vbias[(size_t)s * a.Cout + co];
-    const int orow = r0 + 2 * (tl / G::TW), ocol = 2 * (tl % G::TW);
+    const int orow = r0 + 2 * G::t_row(tl), ocol = 2 * G::t_col(tl);
     const size_t o = ((size_t)s * a.Cout + co) * G::HW + (size_t)orow * G::W + ocol;
     float2 v0 = make_float2(v.x + b, v.y + b), v1 = make_float2(v.z + b, v.w + b);
     if (a.res) {
@@ -456,7 +470,7 @@ inline void wino_tail_plan(int T, int nch, int* nfull, int* split) {
 template <int LOGW, int MODE>
 int launch_wino(WinoArgs a, size_t ws_floats, hipStream_t st) {
     using G = WGeo<LOGW, MODE>;
-    const int T = a.S * G::WPI * (a.CoutP / WTCO);
+    const int T = G::groups(a.S) * (a.CoutP / WTCO);
     wino_tail_plan(T, a.CinP / WCK, &a.nfull, &a.tail_split);
     const int ntail = T - a.nfull;
     if ((size_t)ntail * a.tail_split * WTCO * WTT * 4 > ws_floats || !a.ws) {   // no room: plain grid
@@ -496,17 +510,33 @@ int vf_wino_pack_weights_multi(const void* desc, int nlayers, long total_blocks,
     VF_RETURN_LAST_ERROR();
 }
 
-// 1 if vf_wino_conv_fwd supports this (output) size / mode: 3x3 stride 1, H = W in {16, 32, 64}, modes 0 / 2.
+// 1 if vf_wino_conv_fwd supports this (output) size / mode: 3x3 stride 1, H = W in {8, 16, 32, 64}, modes 0 / 2.
 int vf_wino_supported(int H, int W, int mode) {
-    return (H == W && (W == 16 || W == 32 || W == 64) && (mode == 0 || mode == 2)) ? 1 : 0;
+    return (H == W && (W == 8 || W == 16 || W == 32 || W == 64) && (mode == 0 || mode == 2)) ? 1 : 0;
 }
 
 // workspace floats vf_wino_conv_fwd wants for its split tail tiles (0 when the grid divides evenly)
 long vf_wino_conv_ws_floats(int S, int Cin, int Cout, int H, int W) {
-    const int T = S * ((H / 2) * (W / 2) / WTT) * (rup(Cout, WTCO) / WTCO);
+    const int tiles = (H / 2) * (W / 2);
+    const int groups = tiles >= WTT ? S * (tiles / WTT) : (S + WTT / tiles - 1) / (WTT / tiles);
+    const int T = groups * (rup(Cout, WTCO) / WTCO);
     int nfull, split;
     wino_tail_plan(T, rup(Cin, WCK) / WCK, &nfull, &split);
     return (long)(T - nfull) * split * WTCO * WTT * 4;
+}
+
+// Expected CU fill (percent) of vf_wino_conv_fwd at this shape under its tail plan, and the tile count;
+// hosts use it to choose between this path and the direct kernel.
+int vf_wino_conv_fill_pct(int S, int Cin, int Cout, int H, int W, int* tiles_out) {
+    const int tiles = (H / 2) * (W / 2);
+    const int groups = tiles >= WTT ? S * (tiles / WTT) : (S + WTT / tiles - 1) / (WTT / tiles);
+    const int T = groups * (rup(Cout, WTCO) / WTCO);
+    int nfull, split;
+    wino_tail_plan(T, rup(Cin, WCK) / WCK, &nfull, &split);
+    if (tiles_out) *tiles_out = T;
+    if (T <= 0) return 0;
+    const double time = (nfull + WINO_SLOTS - 1) / WINO_SLOTS + (T > nfull ? 1.0 / split : 0.0);
+    return (int)(100.0 * T / WINO_SLOTS / time);
 }
 
 // y = conv3x3(x) (+bias +view_bias +residual), pad 1, stride 1, via fused Winograd F(2x2,3x3).
@@ -522,6 +552,7 @@ int vf_wino_conv_fwd(const float* x, const float* u_packed, const float* bias, c
     a.ws = ws;
     hipStream_t st = (hipStream_t)stream;
     const size_t nws = ws ? (size_t)ws_floats : 0;
+    if (W == 8) return mode == 0 ? launch_wino<3, 0>(a, nws, st) : launch_wino<3, 2>(a, nws, st);
     if (W == 16) return mode == 0 ? launch_wino<4, 0>(a, nws, st) : launch_wino<4, 2>(a, nws, st);
     if (W == 32) return mode == 0 ? launch_wino<5, 0>(a, nws, st) : launch_wino<5, 2>(a, nws, st);
     return mode == 0 ? launch_wino<6, 0>(a, nws, st) : launch_wino<6, 2>(a, nws, st);

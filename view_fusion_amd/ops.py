@@ -188,12 +188,17 @@ FORCE_WINOGRAD = False    # tests: take the Winograd path even when the grid wou
 WINOGRAD_WGRAD = True     # weight gradients of those layers (plain stride-1 ones) through the same transform
 
 
-def use_winograd(S, Cout, H, W, KS, m):
-    """Winograd needs >= one 64-tile workgroup per CU (its kernel runs one workgroup per CU);
-    small batches (sampler) and small maps stay on the direct kernel (+ split-K)."""
+def use_winograd(S, Cin, Cout, H, W, KS, m):
+    """The Winograd kernel runs ONE 64-tile workgroup per CU: take it when its tile count (after the
+    K-split of the tail tiles) keeps >= 65 % of the CUs busy; small batches (sampler) stay on the
+    direct kernel (+ split-K)."""
     if not WINOGRAD or KS != 3 or m not in (0, 2) or not _lib.load().vf_wino_supported(H, W, m):
         return False
-    return FORCE_WINOGRAD or S * (H * W // 256) * ((Cout + 63) // 64) >= 256
+    if FORCE_WINOGRAD:
+        return True
+    tiles = ctypes.c_int(0)
+    fill = _lib.load().vf_wino_conv_fill_pct(S, Cin, Cout, H, W, ctypes.byref(tiles))
+    return tiles.value >= 100 and fill >= 65
 
 
 def use_winograd_wgrad(S, Cin, Cout, H, W, KS, m):
@@ -244,7 +249,8 @@ def pack_all(root, S=None):
         geom = getattr(l, "_vf_geom", None)
         if geom is None or S is None:
             return False
-        return use_winograd(S, l.weight.shape[0], geom[0], geom[0], l.weight.shape[2], _MODES[geom[1]])
+        return use_winograd(S, l.weight.shape[1], l.weight.shape[0], geom[0], geom[0], l.weight.shape[2],
+                            _MODES[geom[1]])
 
     key = tuple((l.weight.data_ptr(), wants_wino(l)) for l in layers)
     if plan is None or plan[1] != key:
@@ -296,7 +302,7 @@ class _Conv2dFn(torch.autograd.Function):
         H, W = (Hi // 2, Wi // 2) if m == 1 else ((Hi * 2, Wi * 2) if m == 2 else (Hi, Wi))
         y = torch.empty(S, Cout, H, W, device=x.device, dtype=torch.float32)
         flops = 2.0 * S * Cout * Cin * KS * KS * H * W
-        wino = use_winograd(S, Cout, H, W, KS, m)
+        wino = use_winograd(S, Cin, Cout, H, W, KS, m)
         if wino:
             wf, wb = _packed_wino(layer, force=training)
             ws, nws = _wino_ws(x.device, S, Cin, Cout, H, W)
