@@ -324,24 +324,35 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(WinoArgs a) {
         const int tl = tw * 32 + li;
         const int sv = s + G::t_img(tl);
         const int orow = r0 + 2 * G::t_row(tl), ocol = 2 * G::t_col(tl);
+        // every epilogue operand is fetched BEFORE the first store: loads and stores retire through one
+        // in-order counter, so a load issued after a store would wait for that store's round trip
+        float eb[16];
+        float2 er[16][2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + cw * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            eb[r] = 0.f;
+            er[r][0] = er[r][1] = make_float2(0.f, 0.f);
+            if (co >= a.Cout) continue;
+            if (a.bias) eb[r] += a.bias[co];
+#ifndef VF_CONV_STAMPS
+            if (a.vbias) eb[r] += a.vbias[(size_t)sv * a.Cout + co];
+#endif
+            if (a.res) {
+                const size_t o = ((size_t)sv * a.Cout + co) * G::HW + (size_t)orow * G::W + ocol;
+                er[r][0] = *reinterpret_cast<const float2*>(a.res + o);
+                er[r][1] = *reinterpret_cast<const float2*>(a.res + o + G::W);
+            }
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int co = co0 + cw * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
             if (co >= a.Cout) continue;
-            float b = 0.f;
-            if (a.bias) b += a.bias[co];
-#ifndef VF_CONV_STAMPS
-            if (a.vbias) b += a.vbias[(size_t)sv * a.Cout + co];
-#endif
             const size_t o = ((size_t)sv * a.Cout + co) * G::HW + (size_t)orow * G::W + ocol;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                float2 v = make_float2(part[r][2 * i] + xch[(r * 4 + 2 * i) * 64 + lane] + b,
-                                       part[r][2 * i + 1] + xch[(r * 4 + 2 * i + 1) * 64 + lane] + b);
-                if (a.res) {
-                    const float2 rr = *reinterpret_cast<const float2*>(a.res + o + i * G::W);
-                    v.x += rr.x; v.y += rr.y;
-                }
+                float2 v = make_float2(part[r][2 * i] + xch[(r * 4 + 2 * i) * 64 + lane] + eb[r] + er[r][i].x,
+                                       part[r][2 * i + 1] + xch[(r * 4 + 2 * i + 1) * 64 + lane] + eb[r] + er[r][i].y);
                 *reinterpret_cast<float2*>(a.y + o + i * G::W) = v;
             }
         }
