@@ -20,10 +20,14 @@ extern "C" {
 int vf_gn_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean /*[S*G]*/,
               float* rstd /*[S*G]*/, int S, int C, int HW, int groups, float eps, int silu, void* stream);
 /* dgamma_part/dbeta_part: [S][C] per-view partials; reduce over S with vf_colsum.
- * addend (like x, or NULL) is added to dx: gradient of a second consumer of x (residual branch). */
+ * addend (like x, or NULL) is added to dx: gradient of a second consumer of x (residual branch).
+ * dx_rowsum ([S][C] or NULL): sum of dx over the map per (view, channel), excluding addend -- the gradient of
+ * the conv bias / embedding bias added in front of this GroupNorm (unet.py:160-177); only filled where
+ * vf_gn_bwd_emits_rowsum() says so. */
+int vf_gn_bwd_emits_rowsum(int C, int HW, int groups);
 int vf_gn_bwd(const float* x, const float* gamma, const float* beta, const float* mean, const float* rstd,
-              const float* dy, const float* addend, float* dx, float* dgamma_part, float* dbeta_part, int S, int C,
-              int HW, int groups, int silu, void* stream);
+              const float* dy, const float* addend, float* dx, float* dgamma_part, float* dbeta_part,
+              float* dx_rowsum, int S, int C, int HW, int groups, int silu, void* stream);
 int vf_rowsum(const float* x, float* out /*[rows]*/, int rows, int len, void* stream);
 /* conv epilogue gradients in one launch: db[C] (|NULL) and dvb[S][C] (|NULL) from dy[S][C][HW] */
 int vf_bias_grad(const float* dy, float* db, float* dvb, int S, int C, int HW, void* stream);

@@ -138,6 +138,38 @@ def test_conv_winograd_small_maps(dev, Cin, Cout, Hin, mode, S):
         ops.FORCE_WINOGRAD = False
 
 
+@pytest.mark.parametrize("C,H", [(64, 64), (128, 32), (192, 16), (320, 16), (96, 32)])
+def test_group_norm_backward_rowsum(dev, C, H):
+    """The GroupNorm backward's closed-form per-(view, channel) sum of dx == the sum of the dx it wrote; a conv
+    whose dY is that tensor takes its bias gradients from it (same result as the rowsum kernels)."""
+    from view_fusion_amd import ops
+    S = 3
+    x, gy = rnd(S, C, H, H, seed=1), rnd(S, C, H, H, seed=2)
+    gamma, beta = (1 + 0.1 * rnd(C, seed=3)).to(dev), (0.1 * rnd(C, seed=4)).to(dev)
+    xg = x.to(dev).requires_grad_(True)
+    ops.ROWSUM_CACHE.clear()
+    y = ops.group_norm(xg, gamma, beta, 32, silu=True)
+    y.backward(gy.to(dev))
+    assert len(ops.ROWSUM_CACHE) == 1
+    (t, rowsum, _), = ops.ROWSUM_CACHE.values()
+    ref = t.double().sum((2, 3))
+    scale = t.double().abs().sum((2, 3)).max().item()
+    assert (rowsum.double() - ref).abs().max().item() < 2e-6 * scale
+    # end to end: conv (bias + per-view bias) -> GN -> loss, bias grads with and without the shortcut
+    layer = torch.nn.Conv2d(C, C, 3, padding=1).to(dev)
+    vb = rnd(S, C, seed=5).to(dev).requires_grad_(True)
+    grads = []
+    for cache in ({}, None):
+        ops.ROWSUM_CACHE = cache
+        layer.zero_grad(); vb.grad = None
+        h = ops.conv2d(x.to(dev), layer, view_bias=vb)
+        ops.group_norm(h, gamma, beta, 32, silu=True).backward(gy.to(dev))
+        grads.append((layer.bias.grad.clone(), vb.grad.clone()))
+    ops.ROWSUM_CACHE = {}
+    for a, b in zip(*grads):
+        assert (a - b).abs().max().item() < 1e-5 * max(1.0, b.abs().max().item()) + 2e-6 * scale
+
+
 def test_conv_large_batch_split_k(dev):
     """S large enough that wgrad runs many pixel tiles per slice; odd S for the 8x8 two-image tiles."""
     from view_fusion_amd import ops

@@ -18,7 +18,8 @@ _P, _I, _L, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
 # name -> argtypes (restype is int unless listed in _RESTYPE)
 SIGNATURES = {
     "vf_gn_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P],
-    "vf_gn_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "vf_gn_bwd_emits_rowsum": [_I, _I, _I],
+    "vf_gn_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "vf_rowsum": [_P, _P, _I, _I, _P],
     "vf_bias_grad": [_P, _P, _P, _I, _I, _I, _P],
     "vf_colsum": [_P, _P, _I, _I, _I, _P],

@@ -184,10 +184,11 @@ __global__ __launch_bounds__(NT) void gn_bwd_fused_kernel(const float* __restric
                                                           const float* __restrict__ rstd,
                                                           const float* __restrict__ addend, float* __restrict__ dx,
                                                           float* __restrict__ dgamma_part,
-                                                          float* __restrict__ dbeta_part, int C, int HW, int cpg,
+                                                          float* __restrict__ dbeta_part,
+                                                          float* __restrict__ dx_rowsum, int C, int HW, int cpg,
                                                           int silu) {
     constexpr int NWV = NT / 64;
-    extern __shared__ float part[];                  // [NWV][cpg][2]
+    extern __shared__ float part[];                  // [NWV][cpg][3]
     const int G = C / cpg;
     const int sg = blockIdx.x;
     const int s = sg / G, g = sg - s * G;
@@ -198,7 +199,7 @@ __global__ __launch_bounds__(NT) void gn_bwd_fused_kernel(const float* __restric
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const float mu = mean[sg], r = rstd[sg];
 
-    for (int i = threadIdx.x; i < NWV * cpg * 2; i += NT) part[i] = 0.f;
+    for (int i = threadIdx.x; i < NWV * cpg * 3; i += NT) part[i] = 0.f;
     __syncthreads();
 
     float4 xv[NV], dv[NV];
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(NT) void gn_bwd_fused_kernel(const float* __restric
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int idx0 = wid * 64 + i * NT;          // wave-uniform first index of this access
-        float a = 0.f, b = 0.f;
+        float a = 0.f, b = 0.f, xsum = 0.f;
         int cl = 0;
         if (idx0 < n4) {
             cl = idx0 / hw4;                         // channel within the group (wave-uniform)
@@ -226,32 +227,42 @@ __global__ __launch_bounds__(NT) void gn_bwd_fused_kernel(const float* __restric
                 if (!ok) dz = 0.f;
                 xs[j] = xh; ds[j] = dz;
                 a += dz; b += dz * xh;
+                xsum += ok ? xh : 0.f;
             }
             xv[i] = make_float4(xs[0], xs[1], xs[2], xs[3]);
             dv[i] = make_float4(ds[0], ds[1], ds[2], ds[3]);
         }
         a = wave_sum(a);
         b = wave_sum(b);
+        if (dx_rowsum) xsum = wave_sum(xsum);
         if (lane == 0 && idx0 < n4) {
-            part[(wid * cpg + cl) * 2 + 0] += a;
-            part[(wid * cpg + cl) * 2 + 1] += b;
+            part[(wid * cpg + cl) * 3 + 0] += a;
+            part[(wid * cpg + cl) * 3 + 1] += b;
+            part[(wid * cpg + cl) * 3 + 2] += xsum;
         }
     }
     __syncthreads();
-    float s1 = 0.f, s2 = 0.f;
+    float s1 = 0.f, s2 = 0.f, myA = 0.f, myX = 0.f;
     for (int c = 0; c < cpg; ++c) {
-        float A = 0.f, B = 0.f;
+        float A = 0.f, B = 0.f, X = 0.f;
 #pragma unroll
-        for (int w = 0; w < NWV; ++w) { A += part[(w * cpg + c) * 2]; B += part[(w * cpg + c) * 2 + 1]; }
+        for (int w = 0; w < NWV; ++w) {
+            A += part[(w * cpg + c) * 3]; B += part[(w * cpg + c) * 3 + 1]; X += part[(w * cpg + c) * 3 + 2];
+        }
         const float ga = gamma[g * cpg + c];
         s1 += ga * A; s2 += ga * B;
         if (threadIdx.x == c) {
             dbeta_part[(size_t)s * C + g * cpg + c] = A;
             dgamma_part[(size_t)s * C + g * cpg + c] = B;
+            myA = ga * A; myX = X;
         }
     }
     const float inv_n = 1.0f / (float)n;
     s1 *= inv_n; s2 *= inv_n;
+    // sum over the map of this channel's dx, in closed form from the sums above (the gradient of a
+    // per-(view, channel) bias added in front of this GroupNorm; excludes `addend`)
+    if (dx_rowsum && threadIdx.x < cpg)
+        dx_rowsum[(size_t)s * C + g * cpg + threadIdx.x] = r * (myA - (float)HW * s1 - s2 * myX);
     float4* o4 = reinterpret_cast<float4*>(dx + base);
     const float4* a4 = addend ? reinterpret_cast<const float4*>(addend + base) : nullptr;
 #pragma unroll
@@ -367,9 +378,15 @@ int vf_gn_fwd(const float* x, const float* gamma, const float* beta, float* y, f
     return (int)hipErrorInvalidValue;
 }
 
+// 1 when vf_gn_bwd fills `dx_rowsum` at this shape (the single-pass kernel; the two-kernel path does not)
+int vf_gn_bwd_emits_rowsum(int C, int HW, int groups) {
+    if (groups <= 0 || C % groups != 0 || (HW & 3)) return 0;
+    return (HW >= 256 && (long)(C / groups) * HW / 4 <= 8192) ? 1 : 0;
+}
+
 int vf_gn_bwd(const float* x, const float* gamma, const float* beta, const float* mean, const float* rstd,
-              const float* dy, const float* addend, float* dx, float* dgamma_part, float* dbeta_part, int S, int C,
-              int HW, int groups, int silu, void* stream) {
+              const float* dy, const float* addend, float* dx, float* dgamma_part, float* dbeta_part,
+              float* dx_rowsum, int S, int C, int HW, int groups, int silu, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (S <= 0) return 0;
     if (C % groups != 0 || (HW & 3)) return (int)hipErrorInvalidValue;
@@ -379,8 +396,9 @@ int vf_gn_bwd(const float* x, const float* gamma, const float* beta, const float
     if (HW >= 256 && n4g <= 8192) {
 #define VF_GNB(NV, NT)                                                                                     \
     {                                                                                                      \
-        hipLaunchKernelGGL((gn_bwd_fused_kernel<NV, NT>), dim3(S * groups), dim3(NT), (NT / 64) * cpg * 2 * 4, st, \
-                           x, dy, gamma, beta, mean, rstd, addend, dx, dgamma_part, dbeta_part, C, HW, cpg, silu); \
+        hipLaunchKernelGGL((gn_bwd_fused_kernel<NV, NT>), dim3(S * groups), dim3(NT), (NT / 64) * cpg * 3 * 4, st, \
+                           x, dy, gamma, beta, mean, rstd, addend, dx, dgamma_part, dbeta_part, dx_rowsum, C, HW, cpg, \
+                           silu);                                                                          \
         VF_RETURN_LAST_ERROR();                                                                            \
     }
         if (n4g <= 256) VF_GNB(1, 256)

@@ -5,6 +5,7 @@ current HIP stream.  PyTorch supplies device memory, streams and the autograd ta
 CPU tensors are rejected -- there is no eager fallback.
 """
 import ctypes
+import os
 import math
 
 import torch
@@ -80,14 +81,45 @@ def _gn_forward(x, gamma, beta, groups, silu):
     return y, mean, rstd
 
 
+# Per-(view, channel) map sums of gradient tensors that a kernel already had in registers, keyed by the
+# tensor's address: the GroupNorm backward knows sum_hw(dx) in closed form, and dx is exactly the dY of the
+# conv in front of it, whose bias / embedding-bias gradients are those sums; a residual 1x1 conv sees the
+# same dY tensor as the 3x3 conv it is added to.  Entries keep the tensor alive (so the address cannot be
+# recycled), are popped on use, bounded, and dropped at the next training forward.  None disables.
+ROWSUM_CACHE = {}
+_ROWSUM_MAX = 8
+
+
+def _rowsum_put(t, rowsum, colsum):
+    if ROWSUM_CACHE is None:
+        return
+    while len(ROWSUM_CACHE) >= _ROWSUM_MAX:
+        ROWSUM_CACHE.pop(next(iter(ROWSUM_CACHE)))
+    ROWSUM_CACHE[t.data_ptr()] = (t, rowsum, colsum)
+
+
+def _rowsum_get(t):
+    if ROWSUM_CACHE is None:
+        return None
+    hit = ROWSUM_CACHE.pop(t.data_ptr(), None)
+    if hit is None or hit[0].shape != t.shape or hit[0]._version != t._version:
+        return None
+    return hit
+
+
 def _gn_backward(ctx, dy, addend):
     x, gamma, beta, mean, rstd = ctx.saved_tensors
     dy = _c(dy)
     S, C, H, W = x.shape
     dx = torch.empty_like(x)
     parts = torch.empty(2, S, C, device=x.device, dtype=torch.float32)
+    rowsum = None
+    if addend is None and ROWSUM_CACHE is not None and _lib.load().vf_gn_bwd_emits_rowsum(C, H * W, ctx.groups):
+        rowsum = torch.empty(S, C, device=x.device, dtype=torch.float32)
     _lib.call("vf_gn_bwd", _ptr(x), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd), _ptr(dy), _ptr(addend),
-              _ptr(dx), _ptr(parts[0]), _ptr(parts[1]), S, C, H * W, ctx.groups, ctx.silu, _stream())
+              _ptr(dx), _ptr(parts[0]), _ptr(parts[1]), _ptr(rowsum), S, C, H * W, ctx.groups, ctx.silu, _stream())
+    if rowsum is not None:
+        _rowsum_put(dx, rowsum, None)
     dgb = torch.empty(2, C, device=x.device, dtype=torch.float32)
     _lib.call("vf_colsum", _ptr(parts), _ptr(dgb), 2, S, C, _stream())
     return dx, dgb[0], dgb[1]
@@ -185,6 +217,8 @@ def _packed(layer, force):
 
 WINOGRAD = True           # fused Winograd F(2x2,3x3) for stride-1 3x3 convs on large maps
 FORCE_WINOGRAD = False    # tests: take the Winograd path even when the grid would not fill the chip
+WINO_MIN_TILES = int(os.environ.get("VF_WINO_MIN_TILES", 100))   # policy thresholds (tuning aid)
+WINO_MIN_FILL = int(os.environ.get("VF_WINO_MIN_FILL", 65))
 WINOGRAD_WGRAD = True     # weight gradients of those layers (plain stride-1 ones) through the same transform
 
 
@@ -198,7 +232,7 @@ def use_winograd(S, Cin, Cout, H, W, KS, m):
         return True
     tiles = ctypes.c_int(0)
     fill = _lib.load().vf_wino_conv_fill_pct(S, Cin, Cout, H, W, ctypes.byref(tiles))
-    return tiles.value >= 100 and fill >= 65
+    return tiles.value >= WINO_MIN_TILES and fill >= WINO_MIN_FILL
 
 
 def use_winograd_wgrad(S, Cin, Cout, H, W, KS, m):
@@ -244,6 +278,8 @@ def pack_all(root, S=None):
     if not layers:
         return
     _check(layers[0].weight.detach())
+    if ROWSUM_CACHE:
+        ROWSUM_CACHE.clear()
 
     def wants_wino(l):
         geom = getattr(l, "_vf_geom", None)
@@ -372,17 +408,26 @@ class _Conv2dFn(torch.autograd.Function):
         hb, hv, hr = ctx.has
         want_b, want_v = hb and ctx.needs_input_grad[2], hv and ctx.needs_input_grad[3]
         if want_b or want_v:
-            db = torch.empty(Cout, device=x.device, dtype=torch.float32) if want_b else None
-            if Cout >= 192:       # one launch, one workgroup per channel (enough channels to fill the chip)
-                dvb = torch.empty(S, Cout, device=x.device, dtype=torch.float32) if want_v else None
-                _lib.call("vf_bias_grad", _ptr(dy), _ptr(db), _ptr(dvb), S, Cout, H * W, st)
-            else:                 # few channels: wave-per-row partial sums, then the column sum
-                dvb = torch.empty(S, Cout, device=x.device, dtype=torch.float32)
-                _lib.call("vf_rowsum", _ptr(dy), _ptr(dvb), S * Cout, H * W, st)
-                if want_b:
-                    _lib.call("vf_colsum", _ptr(dvb), _ptr(db), 1, S, Cout, st)
-                if not want_v:
-                    dvb = None
+            hit = _rowsum_get(dy)
+            db = hit[2] if hit is not None else None
+            dvb = hit[1] if hit is not None else None
+            if (want_v and dvb is None) or (want_b and db is None and dvb is None):
+                if Cout >= 192 and db is None:   # one launch, one workgroup per channel (enough channels to fill the chip)
+                    db = torch.empty(Cout, device=x.device, dtype=torch.float32) if want_b else None
+                    dvb = torch.empty(S, Cout, device=x.device, dtype=torch.float32) if want_v else None
+                    _lib.call("vf_bias_grad", _ptr(dy), _ptr(db), _ptr(dvb), S, Cout, H * W, st)
+                else:                            # few channels: wave-per-row partial sums, then the column sum
+                    dvb = torch.empty(S, Cout, device=x.device, dtype=torch.float32)
+                    _lib.call("vf_rowsum", _ptr(dy), _ptr(dvb), S * Cout, H * W, st)
+            if want_b and db is None:
+                db = torch.empty(Cout, device=x.device, dtype=torch.float32)
+                _lib.call("vf_colsum", _ptr(dvb), _ptr(db), 1, S, Cout, st)
+            if hr and want_b:                    # the residual branch (1x1 conv) receives this very dY
+                _rowsum_put(dy, dvb, db)
+            if not want_b:
+                db = None
+            if not want_v:
+                dvb = None
         if hr and ctx.needs_input_grad[4]:
             dres = dy
         return dx, dw, db, dvb, dres, None, None, None
