@@ -222,9 +222,14 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(WinoArgs a) {
 
     const int uoff = 8 * kh * WTCO * WCK + (cw * 32 + li) * WCK + 4 * (lh ^ ((li >> 4) & 1));
     const int voff = 8 * kh * WCK * WTT + 4 * lh * WTT + tw * 32 + li;
+    // The staging code of chunks c+1..c+3 runs unconditionally with the chunk index clamped to the last one
+    // (the final iterations redo harmless loads / LDS writes that nobody reads): without loop-tail branches
+    // the compiler counts outstanding loads exactly; with them it falls back to s_waitcnt vmcnt(0) in front of
+    // every staging access, i.e. a full load round trip per slice.
+    const int clast = nch - 1;
     for (int c = 0; c < nch; ++c) {
         const int cur = c & 1, nxt = cur ^ 1;
-        const bool has1 = c + 1 < nch, has2 = c + 2 < nch, has3 = c + 3 < nch;
+        constexpr bool has1 = true, has2 = true, has3 = true;
         const float* ub = Ul + cur * USZ + uoff;
         const float* vb = Vl + cur * VSZ + voff;
         float4 a_cur = *reinterpret_cast<const float4*>(ub);
@@ -253,12 +258,12 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(WinoArgs a) {
             }
             if (k == 4 && has2) VF_XSTORE(cur);                           // rows of chunk c+2 -> buffer of chunk c
             if (has2) {
-                if (k == 1) VF_ULOAD(0, c + 2);
-                if (k == 2) VF_ULOAD(1, c + 2);
-                if (k == 3) VF_ULOAD(2, c + 2);
-                if (k == 4) VF_ULOAD(3, c + 2);
+                if (k == 1) VF_ULOAD(0, min(c + 2, clast));
+                if (k == 2) VF_ULOAD(1, min(c + 2, clast));
+                if (k == 3) VF_ULOAD(2, min(c + 2, clast));
+                if (k == 4) VF_ULOAD(3, min(c + 2, clast));
             }
-            if (k == 5 && has3) VF_XLOAD(c + 3);
+            if (k == 5 && has3) VF_XLOAD(min(c + 3, clast));
             __builtin_amdgcn_sched_barrier(0);
             acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.x, b_cur[0], acc[k], 0, 0, 0);
             acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.y, b_cur[1], acc[k], 0, 0, 0);
@@ -326,24 +331,42 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(WinoArgs a) {
         const int orow = r0 + 2 * G::t_row(tl), ocol = 2 * G::t_col(tl);
         // every epilogue operand is fetched BEFORE the first store: loads and stores retire through one
         // in-order counter, so a load issued after a store would wait for that store's round trip
-        float eb[16];
+        float eb[16], ev[16];
         float2 er[16][2];
+        // (one uniform branch per operand kind, the 16 loads of a kind back to back: a branch between two
+        // loads makes the compiler wait for the first before issuing the second)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int co = co0 + cw * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            eb[r] = 0.f;
+            eb[r] = ev[r] = 0.f;
             er[r][0] = er[r][1] = make_float2(0.f, 0.f);
-            if (co >= a.Cout) continue;
-            if (a.bias) eb[r] += a.bias[co];
+        }
+        if (a.bias) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + cw * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                eb[r] = a.bias[min(co, a.Cout - 1)];
+            }
+        }
 #ifndef VF_CONV_STAMPS
-            if (a.vbias) eb[r] += a.vbias[(size_t)sv * a.Cout + co];
+        if (a.vbias) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + cw * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                ev[r] = a.vbias[(size_t)sv * a.Cout + min(co, a.Cout - 1)];
+            }
+        }
 #endif
-            if (a.res) {
+        if (a.res) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = min(co0 + cw * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, a.Cout - 1);
                 const size_t o = ((size_t)sv * a.Cout + co) * G::HW + (size_t)orow * G::W + ocol;
                 er[r][0] = *reinterpret_cast<const float2*>(a.res + o);
                 er[r][1] = *reinterpret_cast<const float2*>(a.res + o + G::W);
             }
         }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) eb[r] += ev[r];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int co = co0 + cw * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -473,6 +496,9 @@ inline void wino_tail_plan(int T, int nch, int* nfull, int* split) {
     int sp = WINO_SLOTS / R;
     if (sp > 8) sp = 8;
     if (sp > nch / 4) sp = nch / 4;                       // at least 4 chunks per part
+    if (sp < 2) return;
+    const int per = (nch + sp - 1) / sp;                  // the kernel gives each part `per` chunks:
+    sp = (nch + per - 1) / per;                           // no part may start beyond the last chunk
     if (sp < 2) return;
     *nfull = T - R;
     *split = sp;
