@@ -255,18 +255,29 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
             }
             continue;
         }
-        float add[16];
+        // one uniform branch per operand kind with its 16 loads back to back (channel index clamped instead of
+        // predicated): a branch between two loads makes the compiler wait for the first before the second
+        float add[16], ad2[16], ad3[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int dco = (r & 3) + 8 * (r >> 2);
-            float v = 0.f;
-            if (cob + dco < a.Cout) {
-                if (a.res) v = a.res[ob + (size_t)dco * G::HW];
-                if (a.bias) v += a.bias[cob + dco];
-                if (a.vbias) v += a.vbias[(size_t)s * a.Cout + cob + dco];
+        for (int r = 0; r < 16; ++r) add[r] = ad2[r] = ad3[r] = 0.f;
+        if (a.res) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int dco = min((r & 3) + 8 * (r >> 2), a.Cout - 1 - cob);
+                add[r] = a.res[ob + (size_t)dco * G::HW];
             }
-            add[r] = v;
         }
+        if (a.bias) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ad2[r] = a.bias[min(cob + (r & 3) + 8 * (r >> 2), a.Cout - 1)];
+        }
+        if (a.vbias) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                ad3[r] = a.vbias[(size_t)s * a.Cout + min(cob + (r & 3) + 8 * (r >> 2), a.Cout - 1)];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) add[r] += ad2[r] + ad3[r];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int dco = (r & 3) + 8 * (r >> 2);
