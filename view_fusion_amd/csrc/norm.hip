@@ -27,27 +27,32 @@ __global__ __launch_bounds__(NT) void gn_fwd_kernel(const float* __restrict__ x,
     const float4* x4 = reinterpret_cast<const float4*>(x + base);
     float4* y4 = reinterpret_cast<float4*>(y + base);
 
+    // Loads are unconditional on clamped indices and issued back to back (data, then the per-channel affine
+    // parameters): a load inside an `if` makes the compiler drain the load queue (s_waitcnt vmcnt(0)) at every
+    // iteration, which serialises the round trips.  Out-of-range slots are zeroed by a select afterwards.
     float4 v[NV];
+    float gam[NV], bet[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = x4[min((int)threadIdx.x + i * NT, n4 - 1)];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = g * cpg + (min((int)threadIdx.x + i * NT, n4 - 1) * 4) / HW;
+        gam[i] = gamma[c];
+        bet[i] = beta[c];
+    }
     float sum = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        const int idx = threadIdx.x + i * NT;
-        if (idx < n4) {
-            v[i] = x4[idx];
-            sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
-        } else {
-            v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        if ((int)threadIdx.x + i * NT >= n4) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
     }
     const float mean = block_sum<NT>(sum, red) / (float)n;
     float sq = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        const int idx = threadIdx.x + i * NT;
-        if (idx < n4) {
-            const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
-            sq += (a * a + b * b) + (c * c + d * d);
-        }
+        const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+        const float q = (a * a + b * b) + (c * c + d * d);
+        sq += (int)threadIdx.x + i * NT < n4 ? q : 0.f;
     }
     const float var = block_sum<NT>(sq, red) / (float)n;
     const float rstd = 1.0f / sqrtf(var + eps);
@@ -59,9 +64,8 @@ __global__ __launch_bounds__(NT) void gn_fwd_kernel(const float* __restrict__ x,
     for (int i = 0; i < NV; ++i) {
         const int idx = threadIdx.x + i * NT;
         if (idx < n4) {
-            const int c = g * cpg + (idx * 4) / HW;
-            const float ga = gamma[c] * rstd;
-            const float be = beta[c] - mean * ga;
+            const float ga = gam[i] * rstd;
+            const float be = bet[i] - mean * ga;
             float4 o;
             o.x = v[i].x * ga + be;
             o.y = v[i].y * ga + be;
@@ -202,12 +206,21 @@ __global__ __launch_bounds__(NT) void gn_bwd_fused_kernel(const float* __restric
     for (int i = threadIdx.x; i < NWV * cpg * 3; i += NT) part[i] = 0.f;
     __syncthreads();
 
+    // unconditional loads on clamped indices, all issued before the first use (see gn_fwd_kernel)
     float4 xv[NV], dv[NV];
+    float gam[NV], bet[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        const int idx = threadIdx.x + i * NT;
-        if (idx < n4) { xv[i] = x4[idx]; dv[i] = d4[idx]; }
-        else { xv[i] = make_float4(0.f, 0.f, 0.f, 0.f); dv[i] = xv[i]; }
+        const int idc = min((int)threadIdx.x + i * NT, n4 - 1);
+        xv[i] = x4[idc];
+        dv[i] = d4[idc];
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        // wave-uniform channel of this access (HW >= 256 on this path): scalar loads, no vector registers
+        const int c = __builtin_amdgcn_readfirstlane(g * cpg + min(wid * 64 + i * NT, n4 - 1) / hw4);
+        gam[i] = gamma[c];
+        bet[i] = beta[c];
     }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -216,7 +229,7 @@ __global__ __launch_bounds__(NT) void gn_bwd_fused_kernel(const float* __restric
         int cl = 0;
         if (idx0 < n4) {
             cl = idx0 / hw4;                         // channel within the group (wave-uniform)
-            const float ga = gamma[g * cpg + cl], be = beta[g * cpg + cl];
+            const float ga = gam[i], be = bet[i];
             float xs[4] = {xv[i].x, xv[i].y, xv[i].z, xv[i].w};
             float ds[4] = {dv[i].x, dv[i].y, dv[i].z, dv[i].w};
             const bool ok = threadIdx.x + i * NT < n4;
@@ -265,19 +278,25 @@ __global__ __launch_bounds__(NT) void gn_bwd_fused_kernel(const float* __restric
         dx_rowsum[(size_t)s * C + g * cpg + threadIdx.x] = r * (myA - (float)HW * s1 - s2 * myX);
     float4* o4 = reinterpret_cast<float4*>(dx + base);
     const float4* a4 = addend ? reinterpret_cast<const float4*>(addend + base) : nullptr;
+    // dx into the dy registers, then the addend (all its loads back to back) into the x registers
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const float ga = gam[i];
+        dv[i].x = r * (dv[i].x * ga - (s1 + xv[i].x * s2));
+        dv[i].y = r * (dv[i].y * ga - (s1 + xv[i].y * s2));
+        dv[i].z = r * (dv[i].z * ga - (s1 + xv[i].z * s2));
+        dv[i].w = r * (dv[i].w * ga - (s1 + xv[i].w * s2));
+    }
+    if (a4) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) xv[i] = a4[min((int)threadIdx.x + i * NT, n4 - 1)];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) { dv[i].x += xv[i].x; dv[i].y += xv[i].y; dv[i].z += xv[i].z; dv[i].w += xv[i].w; }
+    }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int idx = threadIdx.x + i * NT;
-        if (idx < n4) {
-            const float ga = gamma[g * cpg + idx / hw4];
-            float4 o;
-            o.x = r * (dv[i].x * ga - (s1 + xv[i].x * s2));
-            o.y = r * (dv[i].y * ga - (s1 + xv[i].y * s2));
-            o.z = r * (dv[i].z * ga - (s1 + xv[i].z * s2));
-            o.w = r * (dv[i].w * ga - (s1 + xv[i].w * s2));
-            if (a4) { const float4 t = a4[idx]; o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w; }
-            o4[idx] = o;
-        }
+        if (idx < n4) o4[idx] = dv[i];
     }
 }
 
