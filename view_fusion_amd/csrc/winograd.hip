@@ -804,15 +804,16 @@ __global__ __launch_bounds__(512, 2) void wino_wgrad_kernel(WinoWgradArgs a) {
 
     // partial dU of this slice: rows k = 8kh .. 8kh+7
     const int slab = blockIdx.z;
+    // (one 64-bit base per workgroup lane, 32-bit offsets inside the slab: 128 stores without 64-bit multiplies)
+    const int ci = ci0 + ciw * 32 + li;
+    if (ci < a.CinQ) {
+        float* sb = a.ws + (size_t)slab * 16 * a.CoutP * a.CinQ + (size_t)(co0 + cw * 32 + 4 * lh) * a.CinQ + ci;
+        const int kst = a.CoutP * a.CinQ;
 #pragma unroll
-    for (int k = 0; k < 8; ++k)
+        for (int k = 0; k < 8; ++k)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = co0 + cw * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            const int ci = ci0 + ciw * 32 + li;
-            if (ci < a.CinQ)
-                a.ws[(((size_t)slab * 16 + 8 * kh + k) * a.CoutP + co) * a.CinQ + ci] = acc[k][r];
-        }
+            for (int r = 0; r < 16; ++r) sb[(8 * kh + k) * kst + ((r & 3) + 8 * (r >> 2)) * a.CinQ] = acc[k][r];
+    }
 }
 
 // slab sum: one workgroup per (64 consecutive (co,ci) entries, slice k); 4 slab groups per entry, combined
@@ -823,13 +824,24 @@ __global__ __launch_bounds__(256) void wino_wgrad_slabsum_kernel(const float* __
     const int e = threadIdx.x & 63, g = threadIdx.x >> 6, k = blockIdx.y;
     const long off = (long)k * kstride + (long)blockIdx.x * 64 + e;
     const long sstride = 16 * kstride;
-    float a0 = 0.f, a1 = 0.f;
+    // 8 independent loads in flight per thread (fixed summation order: slabs g, g+4, ... in 8 interleaved chains)
+    float acc8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     int s = g;
-    for (; s + 4 < nslab; s += 8) {
-        a0 += ws[s * sstride + off];
-        a1 += ws[(s + 4) * sstride + off];
+    for (; s + 28 < nslab; s += 32) {
+        float t[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = ws[(s + 4 * j) * sstride + off];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc8[j] += t[j];
     }
-    if (s < nslab) a0 += ws[s * sstride + off];
+    {
+        float t[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = s + 4 * j < nslab ? ws[(s + 4 * j) * sstride + off] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc8[j] += t[j];
+    }
+    const float a0 = (acc8[0] + acc8[1]) + (acc8[2] + acc8[3]), a1 = (acc8[4] + acc8[5]) + (acc8[6] + acc8[7]);
     part[g][e] = a0 + a1;
     __syncthreads();
     if (g == 0) out[off] = (part[0][e] + part[1][e]) + (part[2][e] + part[3][e]);
