@@ -508,7 +508,15 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         tap = t / Cout;
         const size_t stride = (size_t)NT * CoutP * CinQ;
         const float* p = ws + ((size_t)tap * CoutP + co) * CinQ + ci;
-        for (int s = sy; s < nslab; s += 4) acc += p[s * stride];
+        float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // 8 slabs in flight per thread, fixed order
+        for (int s = sy; s < nslab; s += 32) {
+            float t[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t[j] = p[(size_t)min(s + 4 * j, nslab - 1) * stride];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a8[j] += s + 4 * j < nslab ? t[j] : 0.f;
+        }
+        acc = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
     }
     red[sy][ox] = acc;
     __syncthreads();

@@ -306,6 +306,29 @@ __global__ void add_inplace_kernel(float4* __restrict__ y, const float4* __restr
     if (i < n4) { float4 v = y[i]; const float4 t = a[i]; v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; y[i] = v; }
 }
 
+// Sum of n4 float4 by one wave (lane partial; caller wave_sums): 8 independent loads in flight per lane, fixed
+// order.  A plain `for { v = p[i]; a += v }` loop compiles to load -> s_waitcnt vmcnt(0) -> add per iteration,
+// i.e. one memory round trip per 1 KB of the row.
+__device__ __forceinline__ float lane_sum_f4(const float4* __restrict__ p, int n4, int lane) {
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int i = lane;
+    for (; i + 7 * 64 < n4; i += 8 * 64) {
+        float4 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = p[i + 64 * j];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+    }
+    if (i < n4) {                                    // tail: same 8 slots, clamped loads, masked adds
+        float4 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = p[min(i + 64 * j, n4 - 1)];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += i + 64 * j < n4 ? (v[j].x + v[j].y) + (v[j].z + v[j].w) : 0.f;
+    }
+    return ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+}
+
 // out[row] = sum_j x[row][j]   (one wave per row; row length multiple of 4)
 __global__ __launch_bounds__(256) void rowsum_kernel(const float* __restrict__ x, float* __restrict__ out,
                                                      int rows, int len) {
@@ -313,12 +336,7 @@ __global__ __launch_bounds__(256) void rowsum_kernel(const float* __restrict__ x
     if (row >= rows) return;
     const int lane = threadIdx.x & 63;
     const float4* x4 = reinterpret_cast<const float4*>(x + (size_t)row * len);
-    float a = 0.f;
-    for (int i = lane; i < (len >> 2); i += 64) {
-        const float4 v = x4[i];
-        a += (v.x + v.y) + (v.z + v.w);
-    }
-    a = wave_sum(a);
+    const float a = wave_sum(lane_sum_f4(x4, len >> 2, lane));
     if (lane == 0) out[row] = a;
 }
 
@@ -332,12 +350,7 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict_
     float tot = 0.f;
     for (int s = wid; s < S; s += 4) {
         const float4* p = reinterpret_cast<const float4*>(dy + ((size_t)s * C + c) * HW);
-        float a = 0.f;
-        for (int i = lane; i < (HW >> 2); i += 64) {
-            const float4 v = p[i];
-            a += (v.x + v.y) + (v.z + v.w);
-        }
-        a = wave_sum(a);
+        const float a = wave_sum(lane_sum_f4(p, HW >> 2, lane));
         if (lane == 0 && dvb) dvb[(size_t)s * C + c] = a;
         tot += a;
     }
@@ -355,8 +368,17 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ p
     const int c = blockIdx.x * 64 + cx;
     const float* p = part + (size_t)blockIdx.y * S * C;
     float a = 0.f;
-    if (c < C)
-        for (int s = ry; s < S; s += 4) a += p[(size_t)s * C + c];
+    if (c < C) {                                     // 8 rows in flight per thread, fixed order
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int s = ry; s < S; s += 32) {
+            float t[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t[j] = p[(size_t)min(s + 4 * j, S - 1) * C + c];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += s + 4 * j < S ? t[j] : 0.f;
+        }
+        a = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    }
     red[ry][cx] = a;
     __syncthreads();
     if (ry == 0 && c < C) out[(size_t)blockIdx.y * C + c] = (red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]);
