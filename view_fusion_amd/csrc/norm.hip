@@ -348,11 +348,29 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict_
     __shared__ float red[4];
     const int c = blockIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     float tot = 0.f;
-    for (int s = wid; s < S; s += 4) {
-        const float4* p = reinterpret_cast<const float4*>(dy + ((size_t)s * C + c) * HW);
-        const float a = wave_sum(lane_sum_f4(p, HW >> 2, lane));
-        if (lane == 0 && dvb) dvb[(size_t)s * C + c] = a;
-        tot += a;
+    const int n4 = HW >> 2;
+    if (n4 <= 64) {                                  // short rows: the rows of 8 views in flight per wave
+        for (int s = wid; s < S; s += 32) {
+            float4 v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                v[j] = reinterpret_cast<const float4*>(dy + ((size_t)min(s + 4 * j, S - 1) * C + c) * HW)[min(lane, n4 - 1)];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float a = wave_sum(lane < n4 ? (v[j].x + v[j].y) + (v[j].z + v[j].w) : 0.f);
+                if (s + 4 * j < S) {
+                    if (lane == 0 && dvb) dvb[(size_t)(s + 4 * j) * C + c] = a;
+                    tot += a;
+                }
+            }
+        }
+    } else {
+        for (int s = wid; s < S; s += 4) {
+            const float4* p = reinterpret_cast<const float4*>(dy + ((size_t)s * C + c) * HW);
+            const float a = wave_sum(lane_sum_f4(p, n4, lane));
+            if (lane == 0 && dvb) dvb[(size_t)s * C + c] = a;
+            tot += a;
+        }
     }
     if (lane == 0) red[wid] = tot;
     __syncthreads();

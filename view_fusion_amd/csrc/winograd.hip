@@ -391,58 +391,77 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(WinoArgs a) {
 
 // OIHW -> transformed + packed forward  U[co tile][ci chunk][k][co 64][ci 8] = (G w G^T)_k
 //        and backward (dgrad)          [ci tile][co chunk][k][ci 64][co 8] of the 180-degree-rotated kernel.
-__device__ __forceinline__ void wino_pack_one(const float* __restrict__ w, float* __restrict__ uf,
-                                              float* __restrict__ ub, int Cout, int Cin, size_t nf, size_t nb,
-                                              size_t idx) {
-    const bool bwd = idx >= nf;
+// One 512-thread workgroup per (tile, chunk) group = 8192 outputs: thread (m, k8) reads the nine taps of one
+// (co, ci) pair once (36 contiguous bytes) and writes its 16 slices, each slice a contiguous 2 KB line of the
+// workgroup.  Groups [0, nf/8192) are the forward pack, the rest the backward pack.
+__device__ __forceinline__ void wino_pack_group(const float* __restrict__ w, float* __restrict__ uf,
+                                                float* __restrict__ ub, int Cout, int Cin, size_t nf, size_t nb,
+                                                size_t group) {
+    const size_t ngf = nf / (16 * WTCO * WCK);
+    const bool bwd = group >= ngf;
     if (bwd) {
-        idx -= nf;
-        if (idx >= nb || !ub) return;
+        group -= ngf;
+        if (group >= nb / (16 * WTCO * WCK) || !ub) return;
     }
     const int M = bwd ? Cin : Cout, K = bwd ? Cout : Cin;
     const int nchunk = (K + WCK - 1) / WCK;
-    const int m = (idx >> 3) & 63;
-    const int k8 = (idx & 7) ^ (((m >> 4) & 1) << 2);    // 16-B halves swapped on rows 16-31, 48-63: conflict-free ds_read_b128
-    size_t t = idx >> 9;
-    const int k = t & 15;
-    t >>= 4;
-    const int chunk = t % nchunk;
-    const int mt = t / nchunk;
+    const int chunk = group % nchunk, mt = group / nchunk;
+    const int t = threadIdx.x;
+    const int m = t >> 3;
+    const int k8 = (t & 7) ^ (((m >> 4) & 1) << 2);    // 16-B halves swapped on rows 16-31, 48-63: conflict-free ds_read_b128
     const int mm = mt * 64 + m, kk = chunk * WCK + k8;
-    float v = 0.f;
+    float g[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) g[i] = 0.f;
     if (mm < M && kk < K) {
         const int co = bwd ? kk : mm, ci = bwd ? mm : kk;
-        const float* g = w + ((size_t)co * Cin + ci) * 9;
-        const float Gm[4][3] = {{1.f, 0.f, 0.f}, {.5f, .5f, .5f}, {.5f, -.5f, .5f}, {0.f, 0.f, 1.f}};
-        const int i = k >> 2, j = k & 3;
+        const float* p = w + ((size_t)co * Cin + ci) * 9;
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
-#pragma unroll
-            for (int q = 0; q < 3; ++q) v += Gm[i][p] * Gm[j][q] * (bwd ? g[(2 - p) * 3 + (2 - q)] : g[p * 3 + q]);
+        for (int i = 0; i < 9; ++i) g[i] = bwd ? p[8 - i] : p[i];
     }
-    (bwd ? ub : uf)[idx] = v;
+    // U = G g G^T, G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
+    float tq[4][3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const float h = 0.5f * (g[q] + g[6 + q]), e = 0.5f * g[3 + q];
+        tq[0][q] = g[q];
+        tq[1][q] = h + e;
+        tq[2][q] = h - e;
+        tq[3][q] = g[6 + q];
+    }
+    float* out = (bwd ? ub : uf) + group * (size_t)(16 * WTCO * WCK) + t;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float h = 0.5f * (tq[i][0] + tq[i][2]), e = 0.5f * tq[i][1];
+        out[(4 * i + 0) * (WTCO * WCK)] = tq[i][0];
+        out[(4 * i + 1) * (WTCO * WCK)] = h + e;
+        out[(4 * i + 2) * (WTCO * WCK)] = h - e;
+        out[(4 * i + 3) * (WTCO * WCK)] = tq[i][2];
+    }
 }
 
-__global__ void wino_pack_kernel(const float* __restrict__ w, float* __restrict__ uf, float* __restrict__ ub,
-                                 int Cout, int Cin, size_t nf, size_t nb) {
-    wino_pack_one(w, uf, ub, Cout, Cin, nf, nb, (size_t)blockIdx.x * blockDim.x + threadIdx.x);
+__global__ __launch_bounds__(512) void wino_pack_kernel(const float* __restrict__ w, float* __restrict__ uf,
+                                                        float* __restrict__ ub, int Cout, int Cin, size_t nf,
+                                                        size_t nb) {
+    wino_pack_group(w, uf, ub, Cout, Cin, nf, nb, blockIdx.x);
 }
 
 struct WPackDesc {
     const float* w;
     float* uf;
     float* ub;
-    long long Cout, Cin, nf, nb, first_block;
+    long long Cout, Cin, nf, nb, first_block;         // first_block in units of 256 outputs (32 per group)
 };
-__global__ void wino_pack_multi_kernel(const WPackDesc* __restrict__ desc, int nlayers) {
+__global__ __launch_bounds__(512) void wino_pack_multi_kernel(const WPackDesc* __restrict__ desc, int nlayers) {
+    const long long vb = (long long)blockIdx.x * 32;
     int lo = 0, hi = nlayers;
     while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
-        if (desc[mid].first_block <= (long long)blockIdx.x) lo = mid; else hi = mid;
+        if (desc[mid].first_block <= vb) lo = mid; else hi = mid;
     }
     const WPackDesc d = desc[lo];
-    const size_t idx = ((size_t)blockIdx.x - (size_t)d.first_block) * blockDim.x + threadIdx.x;
-    wino_pack_one(d.w, d.uf, d.ub, (int)d.Cout, (int)d.Cin, (size_t)d.nf, (size_t)d.nb, idx);
+    wino_pack_group(d.w, d.uf, d.ub, (int)d.Cout, (int)d.Cin, (size_t)d.nf, (size_t)d.nb,
+                    (size_t)((vb - d.first_block) / 32));
 }
 
 inline int rup(int v, int m) { return (v + m - 1) / m * m; }
@@ -534,7 +553,7 @@ int vf_wino_pack_sizes(int Cout, int Cin, long* fwd_floats, long* bwd_floats) {
 int vf_wino_pack_weights(const float* w_oihw, float* u_fwd, float* u_bwd, int Cout, int Cin, void* stream) {
     const size_t nf = 16UL * rup(Cin, WCK) * rup(Cout, WTCO);
     const size_t nb = u_bwd ? 16UL * rup(Cout, WCK) * rup(Cin, WTCO) : 0;
-    hipLaunchKernelGGL(wino_pack_kernel, dim3((unsigned)((nf + nb + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(wino_pack_kernel, dim3((unsigned)((nf + nb) / 8192)), dim3(512), 0, (hipStream_t)stream,
                        w_oihw, u_fwd, u_bwd, Cout, Cin, nf, nb);
     VF_RETURN_LAST_ERROR();
 }
@@ -542,7 +561,7 @@ int vf_wino_pack_weights(const float* w_oihw, float* u_fwd, float* u_bwd, int Co
 // desc: device int64 [nlayers][8] rows {w, u_fwd, u_bwd, Cout, Cin, fwd_floats, bwd_floats, first_block}
 int vf_wino_pack_weights_multi(const void* desc, int nlayers, long total_blocks, void* stream) {
     if (nlayers <= 0 || total_blocks <= 0) return 0;
-    hipLaunchKernelGGL(wino_pack_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(wino_pack_multi_kernel, dim3((unsigned)(total_blocks / 32)), dim3(512), 0, (hipStream_t)stream,
                        (const WPackDesc*)desc, nlayers);
     VF_RETURN_LAST_ERROR();
 }
