@@ -95,22 +95,30 @@ def roofline(trainer, batch, steps=2):
     torch.cuda.synchronize()
     log, ops.KERNEL_LOG = ops.KERNEL_LOG, None
     agg = {}
-    for kind, flops, e0, e1, _tag in log:
-        a = agg.setdefault(kind, [0.0, 0.0, 0])
+    for kind, flops, e0, e1, _tag, name in log:
+        a = agg.setdefault(kind, [0.0, 0.0, 0, 0.0])
         a[0] += flops
         a[1] += e0.elapsed_time(e1) * 1e-3
         a[2] += 1
+        a[3] += flops / 2.25 if name.startswith("vf_wino") else flops     # multiplies the matrix cores execute
     f = agg["conv_fwd"][0] + agg["conv_dgrad"][0]
     s = agg["conv_fwd"][1] + agg["conv_dgrad"][1]
     n = agg["conv_fwd"][2] + agg["conv_dgrad"][2]
-    out = dict(bound="mfma", kernel="conv forward + dgrad launches: wino_conv_kernel<LOGW,MODE> (3x3 on 64x64/32x32 maps) "
-                                   "+ conv_mfma_kernel<KS,LOGW,MODE,NPT> (rest); FLOPs are the algorithmic direct-conv count",
+    x = agg["conv_fwd"][3] + agg["conv_dgrad"][3]
+    out = dict(bound="mfma", kernel="conv forward + dgrad launches: wino_conv_kernel<LOGW,MODE> (fused Winograd F(2x2,3x3): "
+                                   "every stride-1 3x3 layer) + conv_mfma_kernel<KS,LOGW,MODE,NPT> (1x1, stride 2)",
                achieved=f / s / 1e12, peak=PEAK_FP32_MATRIX_TFLOPS, unit="TFLOP/s",
-               frac=f / s / 1e12 / PEAK_FP32_MATRIX_TFLOPS, traffic=pmc_traffic(("wino_conv_kernel", "conv_mfma_kernel")),
+               frac=f / s / 1e12 / PEAK_FP32_MATRIX_TFLOPS,
+               note="achieved = ALGORITHMIC direct-convolution FLOPs (2*S*Cout*Cin*KS^2*H*W) / time; the Winograd "
+                    "launches execute 2.25x fewer multiplies, so the fraction of the fp32 MFMA peak the matrix "
+                    "cores actually sustain is mfma_executed_frac",
+               mfma_executed_tflops=x / s / 1e12, mfma_executed_frac=x / s / 1e12 / PEAK_FP32_MATRIX_TFLOPS,
+               traffic=pmc_traffic(("wino_conv_kernel", "conv_mfma_kernel")),
                launches_per_step=n // steps,
                avg_launch_us=s / n * 1e6, algorithmic_gflop_per_launch=f / n / 1e9)
-    out["other_kernels"] = {k: dict(achieved_tflops=v[0] / v[1] / 1e12, launches_per_step=v[2] // steps,
-                                    avg_launch_us=v[1] / v[2] * 1e6) for k, v in agg.items()}
+    out["other_kernels"] = {k: dict(achieved_tflops=v[0] / v[1] / 1e12, mfma_executed_tflops=v[3] / v[1] / 1e12,
+                                    launches_per_step=v[2] // steps, avg_launch_us=v[1] / v[2] * 1e6)
+                            for k, v in agg.items()}
     return out
 
 

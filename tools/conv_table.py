@@ -22,7 +22,7 @@ for _ in range(steps):
 torch.cuda.synchronize()
 log, ops.KERNEL_LOG = ops.KERNEL_LOG, None
 agg = {}
-for kind, flops, e0, e1, tag in log:
+for kind, flops, e0, e1, tag, _name in log:
     a = agg.setdefault((kind,) + tag, [0.0, 0.0, 0])
     a[0] += flops; a[1] += e0.elapsed_time(e1) * 1e-3; a[2] += 1
 tot = {}

@@ -29,7 +29,7 @@ for it in range(reps + 2):
     y.backward(gy)
 torch.cuda.synchronize()
 agg = {}
-for kind, flops, e0, e1, tag in ops.KERNEL_LOG:
+for kind, flops, e0, e1, tag, _name in ops.KERNEL_LOG:
     a = agg.setdefault(kind, [0.0, 0]); a[0] += e0.elapsed_time(e1) * 1e-3; a[1] += 1
 print(" ".join(f"{k}: {v[0] / v[1] * 1e6:.1f}us {fl / (v[0] / v[1]) / 1e12:.1f}TF" for k, v in agg.items()),
       f"| Cin={Cin} Cout={Cout} H={H} KS={KS} {mode} ablate={os.environ.get('VF_CONV_ABLATE', '0')}")

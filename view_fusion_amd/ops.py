@@ -53,7 +53,7 @@ def _launch(kind, flops, name, *args, tag=None):
     e0.record()
     _lib.call(name, *args)
     e1.record()
-    KERNEL_LOG.append((kind, flops, e0, e1, tag))
+    KERNEL_LOG.append((kind, flops, e0, e1, tag, name))
 
 
 # ---------------------------------------------------------------------------------------------
