@@ -64,7 +64,6 @@ struct ConvArgs {
     const float* res;    // [S][Cout][H][W] or null
     float* y;
     int S, Cin, Cout, CinP, CoutP;
-    int ablate;   // tuning aid (VF_CONV_ABLATE): 1 = stage only the first chunk, 2 = and drop the barriers
     int ksplit;   // > 1: split the K (input-channel) loop over ksplit workgroups, partials go to ws
     float* ws;    // [ksplit][S][Cout][H*W] partial sums (small-batch / sampler regime)
 };
@@ -92,7 +91,10 @@ __device__ __forceinline__ float4 load_patch4(const float* __restrict__ x, int S
     return v;
 }
 
-template <int KS, int LOGW, int MODE, int NPT>
+// NCO > 1 (1x1 convs): the workgroup covers NCO consecutive 64-channel weight tiles, so the activation tile
+// is staged once for 64*NCO output channels -- a 64-channel workgroup of a 1x1 conv needs ~12 B/clk of
+// L2->LDS traffic per CU at full MFMA rate, which is the load path's limit.
+template <int KS, int LOGW, int MODE, int NPT, int NCO = 1>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
     constexpr int TPIX = 64 * NPT;            // each wave: 32 channels x (32*NPT) pixels
     using G = Geo<KS, LOGW, MODE, TPIX>;
@@ -102,20 +104,23 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
     constexpr int NW4 = NG * TCO * 2;         // float4 per weight chunk
     constexpr int NX4 = CK * G::IM * G::PH * G::Q;
 
-    __shared__ __attribute__((aligned(16))) float wl[NG * TCO * WROW];
+    constexpr int WLS = NG * TCO * WROW;      // LDS floats of one weight tile
+    __shared__ __attribute__((aligned(16))) float wl[NCO * WLS];
     __shared__ __attribute__((aligned(16))) float xl[CK * G::PS];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int cw = wid & 1, pw = wid >> 1;
     const int li = lane & 31, lh = lane >> 5;
 
-    const int ncot = a.CoutP / TCO;
+    const int ncot1 = a.CoutP / TCO;                 // 64-channel weight tiles
+    const int ncot = (ncot1 + NCO - 1) / NCO;        // workgroup tiles
     const unsigned logical0 = xcd_remap(blockIdx.x, gridDim.x);
     const int split = logical0 % a.ksplit;
     const unsigned logical = logical0 / a.ksplit;
     const int cot = logical % ncot;
     const int tile = logical / ncot;
-    const int co0 = cot * TCO;
+    const int co0 = cot * NCO * TCO;
+    const int nco_here = min(NCO, ncot1 - cot * NCO);   // weight tiles this workgroup really has
     const int nch = a.CinP / CK;
     const int cbeg = (split * nch / a.ksplit) * CK, cend = ((split + 1) * nch / a.ksplit) * CK;
     const int s0 = G::IM > 1 ? tile * G::IM : tile / G::TPI;
@@ -125,18 +130,29 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
     long long st_[4] = {clock64(), 0, 0, 0}, rt_[2] = {wall_clock64(), 0};
 #endif
     // zero the patch once: the left/right halo columns are never written again
-    for (int i = tid; i < CK * G::PS; i += 256) xl[i] = 0.f;
+    if (KS != 1)                                           // (a 1x1 patch has no halo)
+        for (int i = tid; i < CK * G::PS; i += 256) xl[i] = 0.f;
 
     // Register staging: full 256-wide passes are unconditional and a ragged tail lives in its
     // own scalar so that the arrays are only ever indexed statically (stay in VGPRs).
     constexpr int NWF = NW4 / 256, NXF = NX4 / 256;
     constexpr bool WT = (NW4 % 256) != 0, XT = (NX4 % 256) != 0;
-    float4 wreg[NWF > 0 ? NWF : 1], xreg[NXF > 0 ? NXF : 1];
-    float4 wtail = make_float4(0.f, 0.f, 0.f, 0.f), xtail = make_float4(0.f, 0.f, 0.f, 0.f);
-    // packed weights: [co tile][chunk][group][co 64][ci 8] -> one contiguous block per (tile, chunk)
-    const float* wsrc = a.w + (size_t)cot * (a.CinP / CK) * (NG * TCO * 8);
-    auto load_w = [&](int e, int c0) -> float4 {
-        return *reinterpret_cast<const float4*>(wsrc + (size_t)(c0 / CK) * (NG * TCO * 8) + 4 * e);
+    static_assert(NCO == 1 || !WT, "multi-tile workgroups assume whole 256-wide weight passes");
+    // PD register sets = prefetch distance in chunks.  Measured on the 1x1 layers: distance 2 is not faster than 1
+    // (tools/conv_stamps.py: the K loop is already MFMA-paced; the exposed phases are the first load and the
+    // output store, which every workgroup of a one-round grid reaches at the same time).
+    constexpr int PD = 1;
+    float4 wreg[PD][NCO * (NWF > 0 ? NWF : 1)], xreg[PD][NXF > 0 ? NXF : 1];
+    float4 wtail[PD], xtail[PD];
+#pragma unroll
+    for (int d = 0; d < PD; ++d) wtail[d] = xtail[d] = make_float4(0.f, 0.f, 0.f, 0.f);
+    // packed weights: [co tile][chunk][group][co 64][ci 8] -> one contiguous block per (tile, chunk);
+    // a missing trailing tile (Cout not a multiple of 64*NCO) re-reads the last one and is never used
+    const size_t wtile = (size_t)(a.CinP / CK) * (NG * TCO * 8);
+    const float* wsrc = a.w + (size_t)cot * NCO * wtile;
+    auto load_w = [&](int e, int c0, int j = 0) -> float4 {
+        return *reinterpret_cast<const float4*>(wsrc + (size_t)min(j, nco_here - 1) * wtile +
+                                                (size_t)(c0 / CK) * (NG * TCO * 8) + 4 * e);
     };
     auto load_x = [&](int e, int c0) -> float4 {
         const int q = e % G::Q;
@@ -151,51 +167,65 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
         const int t1 = e / G::Q;                                  // (ci*IM + im)*PH + pr
         *reinterpret_cast<float4*>(xl + t1 * G::PW + 4 * q + (KS == 1 ? 0 : 4)) = v;
     };
-#define VF_LOAD_CHUNK(C0)                                                             \
+#define VF_LOAD_CHUNK(D_, C0)                                                         \
     {                                                                                 \
-        _Pragma("unroll") for (int i = 0; i < NWF; ++i) wreg[i] = load_w(tid + i * 256, (C0)); \
-        if (WT && tid + NWF * 256 < NW4) wtail = load_w(tid + NWF * 256, (C0));        \
-        _Pragma("unroll") for (int i = 0; i < NXF; ++i) xreg[i] = load_x(tid + i * 256, (C0)); \
-        if (XT && tid + NXF * 256 < NX4) xtail = load_x(tid + NXF * 256, (C0));        \
+        _Pragma("unroll") for (int j = 0; j < NCO; ++j)                                \
+            _Pragma("unroll") for (int i = 0; i < NWF; ++i) wreg[D_][j * NWF + i] = load_w(tid + i * 256, (C0), j); \
+        if (WT && tid + NWF * 256 < NW4) wtail[D_] = load_w(tid + NWF * 256, (C0));    \
+        _Pragma("unroll") for (int i = 0; i < NXF; ++i) xreg[D_][i] = load_x(tid + i * 256, (C0)); \
+        if (XT && tid + NXF * 256 < NX4) xtail[D_] = load_x(tid + NXF * 256, (C0));    \
     }
-#define VF_STORE_CHUNK()                                                              \
+#define VF_STORE_CHUNK(D_)                                                            \
     {                                                                                 \
-        _Pragma("unroll") for (int i = 0; i < NWF; ++i)                                \
-            *reinterpret_cast<float4*>(wl + ((tid + i * 256) >> 1) * WROW + 4 * (tid & 1)) = wreg[i]; \
+        _Pragma("unroll") for (int j = 0; j < NCO; ++j)                                \
+            _Pragma("unroll") for (int i = 0; i < NWF; ++i)                            \
+                *reinterpret_cast<float4*>(wl + j * WLS + ((tid + i * 256) >> 1) * WROW + 4 * (tid & 1)) = wreg[D_][j * NWF + i]; \
         if (WT && tid + NWF * 256 < NW4)                                               \
-            *reinterpret_cast<float4*>(wl + ((tid + NWF * 256) >> 1) * WROW + 4 * (tid & 1)) = wtail; \
-        _Pragma("unroll") for (int i = 0; i < NXF; ++i) store_x(tid + i * 256, xreg[i]); \
-        if (XT && tid + NXF * 256 < NX4) store_x(tid + NXF * 256, xtail);              \
+            *reinterpret_cast<float4*>(wl + ((tid + NWF * 256) >> 1) * WROW + 4 * (tid & 1)) = wtail[D_]; \
+        _Pragma("unroll") for (int i = 0; i < NXF; ++i) store_x(tid + i * 256, xreg[D_][i]); \
+        if (XT && tid + NXF * 256 < NX4) store_x(tid + NXF * 256, xtail[D_]);          \
     }
 
-    f32x16 acc[NPT];
+    f32x16 acc[NCO][NPT];
     int xo[NPT];
 #pragma unroll
     for (int nt = 0; nt < NPT; ++nt) {
-        acc[nt] = (f32x16){0};
+#pragma unroll
+        for (int j = 0; j < NCO; ++j) acc[j][nt] = (f32x16){0};
         xo[nt] = 4 * lh * G::PS + G::pix_off(pw * 32 * NPT + nt * 32 + li);
     }
     // k order inside an 8-channel group: MFMA step s pairs channel s (lane half 0) with channel
     // 4+s (half 1), so a lane's four A values are contiguous -> one ds_read_b128 per group.
     const float* wb = wl + (cw * 32 + li) * WROW + 4 * lh;
-    auto frag_a = [&](int g) -> float4 { return *reinterpret_cast<const float4*>(wb + g * TCO * WROW); };
+    auto frag_a = [&](int g, int j = 0) -> float4 {
+        return *reinterpret_cast<const float4*>(wb + j * WLS + g * TCO * WROW);
+    };
     auto frag_b = [&](int g, int nt, int s) -> float {
         const int off = KS == 3 ? (g / 3) * G::PW + (g % 3) + s * G::PS : (8 * g + s) * G::PS;
         return xl[xo[nt] + off];
     };
 
-    VF_LOAD_CHUNK(cbeg);
-    for (int c0 = cbeg; c0 < cend; c0 += CK) {
-        if (a.ablate < 2 || c0 == cbeg) __syncthreads();   // previous chunk's LDS reads (and the zero fill) done
-        if (a.ablate == 0 || c0 == cbeg) VF_STORE_CHUNK();
-        if (a.ablate < 2 || c0 == cbeg) __syncthreads();
+    // chunk loads run unconditionally on clamped chunk indices (the tail re-reads the last chunk): no branch
+    // around a load, so the compiler counts the loads in flight instead of draining the queue
+    const int nchk = (cend - cbeg) / CK;
+#pragma unroll
+    for (int d = 0; d < PD; ++d) VF_LOAD_CHUNK(d, cbeg + min(d, nchk - 1) * CK);
+    for (int cb = 0; cb < nchk; cb += PD)
+#pragma unroll
+    for (int d = 0; d < PD; ++d) {
+        if (PD > 1 && cb + d >= nchk) break;
+        __syncthreads();                                   // previous chunk's LDS reads (and the zero fill) done
+        VF_STORE_CHUNK(d);
+        __syncthreads();
 #ifdef VF_CONV_STAMPS
-        if (c0 == cbeg) st_[1] = clock64();
+        if (cb + d == 0) st_[1] = clock64();
 #endif
-        if (c0 + CK < cend && a.ablate == 0) VF_LOAD_CHUNK(c0 + CK);
+        VF_LOAD_CHUNK(d, cbeg + min(cb + d + PD, nchk - 1) * CK);
         // software pipeline over the groups: fragments of group g+1 are fetched from LDS before
         // the MFMAs of group g are issued (sched_barrier pins that order)
-        float4 a_cur = frag_a(0);
+        float4 a_cur[NCO];
+#pragma unroll
+        for (int j = 0; j < NCO; ++j) a_cur[j] = frag_a(0, j);
         float b_cur[NPT][4];
 #pragma unroll
         for (int nt = 0; nt < NPT; ++nt)
@@ -203,25 +233,33 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
             for (int s = 0; s < 4; ++s) b_cur[nt][s] = frag_b(0, nt, s);
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
-            float4 a_nxt = a_cur;
+            float4 a_nxt[NCO];
             float b_nxt[NPT][4];
+#pragma unroll
+            for (int j = 0; j < NCO; ++j) a_nxt[j] = a_cur[j];
             if (g + 1 < NG) {
-                a_nxt = frag_a(g + 1);
+#pragma unroll
+                for (int j = 0; j < NCO; ++j) a_nxt[j] = frag_a(g + 1, j);
 #pragma unroll
                 for (int nt = 0; nt < NPT; ++nt)
 #pragma unroll
                     for (int s = 0; s < 4; ++s) b_nxt[nt][s] = frag_b(g + 1, nt, s);
             }
             __builtin_amdgcn_sched_barrier(0);
-            const float av[4] = {a_cur.x, a_cur.y, a_cur.z, a_cur.w};
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
+            for (int j = 0; j < NCO; ++j) {
+                if (NCO > 1 && j >= nco_here) continue;            // wave-uniform: trailing tile absent
+                const float av[4] = {a_cur[j].x, a_cur[j].y, a_cur[j].z, a_cur[j].w};
 #pragma unroll
-                for (int nt = 0; nt < NPT; ++nt)
-                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], b_cur[nt][s], acc[nt], 0, 0, 0);
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int nt = 0; nt < NPT; ++nt)
+                        acc[j][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], b_cur[nt][s], acc[j][nt], 0, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
             if (g + 1 < NG) {
-                a_cur = a_nxt;
+#pragma unroll
+                for (int j = 0; j < NCO; ++j) a_cur[j] = a_nxt[j];
 #pragma unroll
                 for (int nt = 0; nt < NPT; ++nt)
 #pragma unroll
@@ -239,19 +277,21 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
     // All loads of a 32x32 tile (residual, biases) are issued before any of its stores so that
     // their latency overlaps instead of forming a load->add->store chain per element.
 #pragma unroll
+    for (int j = 0; j < NCO; ++j)
+#pragma unroll
     for (int nt = 0; nt < NPT; ++nt) {
         const int p = pw * 32 * NPT + nt * 32 + li;
         const int s = G::IM > 1 ? s0 + (p >> (2 * LOGW)) : s0;
         const int pix = G::IM > 1 ? (p & (G::HW - 1)) : r0 * G::W + p;
-        if (s >= a.S) continue;
-        const int cob = co0 + cw * 32 + 4 * lh;
+        if (s >= a.S || j >= nco_here) continue;
+        const int cob = co0 + j * TCO + cw * 32 + 4 * lh;
         const size_t ob = ((size_t)s * a.Cout + cob) * G::HW + pix;
         if (a.ksplit > 1) {            // raw partial sums; bias / residual are added by the reduce kernel
             float* wsp = a.ws + (size_t)split * a.S * a.Cout * G::HW;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int dco = (r & 3) + 8 * (r >> 2);
-                if (cob + dco < a.Cout) wsp[ob + (size_t)dco * G::HW] = acc[nt][r];
+                if (cob + dco < a.Cout) wsp[ob + (size_t)dco * G::HW] = acc[j][nt][r];
             }
             continue;
         }
@@ -281,7 +321,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int dco = (r & 3) + 8 * (r >> 2);
-            if (cob + dco < a.Cout) a.y[ob + (size_t)dco * G::HW] = acc[nt][r] + add[r];
+            if (cob + dco < a.Cout) a.y[ob + (size_t)dco * G::HW] = acc[j][nt][r] + add[r];
         }
     }
 #ifdef VF_CONV_STAMPS
@@ -620,23 +660,23 @@ inline int choose_ksplit(int nblk, int nchunks) {
     return k < nchunks ? k : nchunks;
 }
 
-template <int KS, int LOGW, int MODE, int NPT>
+template <int KS, int LOGW, int MODE, int NPT, int NCO = 1>
 int conv_blocks(const ConvArgs& a) {
     using G = Geo<KS, LOGW, MODE, 64 * NPT>;
     const int ntiles = G::IM > 1 ? (a.S + G::IM - 1) / G::IM : a.S * G::TPI;
-    return ntiles * (a.CoutP / TCO);
+    return ntiles * ((a.CoutP / TCO + NCO - 1) / NCO);
 }
 
-template <int KS, int LOGW, int MODE, int NPT>
+template <int KS, int LOGW, int MODE, int NPT, int NCO = 1>
 int launch_conv_npt(ConvArgs a, hipStream_t st, long ws_floats) {
     constexpr int HW = 1 << (2 * LOGW);
-    const int nblk = conv_blocks<KS, LOGW, MODE, NPT>(a);
+    const int nblk = conv_blocks<KS, LOGW, MODE, NPT, NCO>(a);
     const size_t out_floats = (size_t)a.S * a.Cout * HW;
     int ks = choose_ksplit(nblk, a.CinP / (KS == 3 ? 8 : 32));
     if (a.ws == nullptr) ks = 1;
     while (ks > 1 && (size_t)ks * out_floats > (size_t)ws_floats) --ks;
     a.ksplit = ks;
-    hipLaunchKernelGGL((conv_mfma_kernel<KS, LOGW, MODE, NPT>), dim3(nblk * ks), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((conv_mfma_kernel<KS, LOGW, MODE, NPT, NCO>), dim3(nblk * ks), dim3(256), 0, st, a);
     if (ks > 1) {
         const size_t n4 = out_floats / 4;
         hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st,
@@ -660,9 +700,25 @@ inline int npt_override() {
     return v;
 }
 
+// 1x1 convs.  (A 64*NCO-channel workgroup tile -- NCO = 2, 3 instantiations of conv_mfma_kernel -- was measured:
+// 5-20 % faster on a few 16x16 / 8x8 shapes, 10-100 % slower wherever the grid stops filling the chip, net worse;
+// only NCO = 1 is compiled.)
+template <int LOGW, int NPT>
+int launch_conv_1x1(const ConvArgs& a, hipStream_t st, long ws_floats) {
+    return launch_conv_npt<1, LOGW, 0, NPT, 1>(a, st, ws_floats);
+}
+
 template <int KS, int LOGW, int MODE>
 int launch_conv(const ConvArgs& a, hipStream_t st, long ws_floats) {
     constexpr bool ok1 = LOGW <= 4;                       // 64-pixel tiles
+    if constexpr (KS == 1) {
+        if constexpr (ok1) {
+            const int force = npt_override();
+            if (force == 1 || (force == 0 && conv_blocks<1, LOGW, 0, 2>(a) < CONV_MIN_WGS))
+                return launch_conv_1x1<LOGW, 1>(a, st, ws_floats);
+        }
+        return launch_conv_1x1<LOGW, 2>(a, st, ws_floats);
+    }
     if constexpr (ok1) {
         const int force = npt_override();
         if (force == 1 || (force == 0 && conv_blocks<KS, LOGW, MODE, 2>(a) < CONV_MIN_WGS))
@@ -753,8 +809,6 @@ int vf_conv_fwd(const float* x, const float* w_packed, const float* bias, const 
     a.S = S; a.Cin = Cin; a.Cout = Cout;
     a.CinP = round_up(Cin, KS == 3 ? 8 : 32);
     a.CoutP = round_up(Cout, TCO);
-    static const int ablate = [] { const char* e = getenv("VF_CONV_ABLATE"); return e ? atoi(e) : 0; }();
-    a.ablate = ablate;
     a.ksplit = 1;
     a.ws = ws;
     hipStream_t st = (hipStream_t)stream;
