@@ -143,6 +143,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=16, help="samples per GPU")
     ap.add_argument("--views", type=int, default=6)
+    ap.add_argument("--ragged", action="store_true", help="view_count = randint(1, N+1) per sample (experiment.py:277-279)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-sampler", action="store_true")
@@ -155,7 +156,7 @@ def main():
 
     model = train.build_model(device=str(dev), seed=0)
     trainer = train.Trainer(model, world=world, local_rank=local_rank)
-    batch = train.synthetic_batch(args.batch, args.views, 64, dev, seed=rank)
+    batch = train.synthetic_batch(args.batch, args.views, 64, dev, seed=rank, ragged=args.ragged)
     S = int(batch["view_count"].sum())
 
     def barrier():
@@ -185,7 +186,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "small UNet 64x64 (33.9M params), B=%d/GPU N=%d (S=%d views/GPU), training "
-                                   "iteration fwd+bwd+Adam, linear T=2000 schedule" % (args.batch, args.views, S),
+                                   "iteration fwd+bwd+Adam, linear T=2000 schedule%s" % (args.batch, args.views, S,
+                                                                                     ", ragged view_count" if args.ragged else ""),
                        "global_batch": args.batch * world, "views": args.views,
                        "parallelism": "dp%d" % world},
             "iters_per_sec": args.steps / dt, "loss": loss_val,

@@ -505,22 +505,25 @@ __global__ __launch_bounds__(256) void wino_fixup_kernel(WinoArgs a, int ntail) 
 
 constexpr int WINO_SLOTS = 256;       // one 155 KB-LDS workgroup per CU
 
-// how a grid of T equal tiles is finished when T is not a multiple of the slot count: the last
-// T mod 256 tiles are split over K into `split` parts so that the tail round is full too
+// How a grid of T equal tiles is finished when T is not a multiple of the slot count: the last R = T mod 256
+// tiles are split over K into `split` parts each; the parts run in ceil(R*split/256) rounds of 1/split tile
+// time.  `split` is the value in [1, min(8, nch/4)] that wastes the least CU time (ties: fewer parts).
+inline double wino_tail_time(int R, int sp) { return (double)((R * sp + WINO_SLOTS - 1) / WINO_SLOTS) / sp; }
+
 inline void wino_tail_plan(int T, int nch, int* nfull, int* split) {
     *nfull = T;
     *split = 1;
     const int R = T % WINO_SLOTS;
     if (R == 0 || T / WINO_SLOTS >= 3) return;          // tail round costs < 1/4 of the launch: leave it
-    int sp = WINO_SLOTS / R;
-    if (sp > 8) sp = 8;
-    if (sp > nch / 4) sp = nch / 4;                       // at least 4 chunks per part
-    if (sp < 2) return;
-    const int per = (nch + sp - 1) / sp;                  // the kernel gives each part `per` chunks:
-    sp = (nch + per - 1) / per;                           // no part may start beyond the last chunk
-    if (sp < 2) return;
+    int best = 1;
+    for (int sp = 2; sp <= 8 && sp <= nch / 4; ++sp) {    // at least 4 chunks per part
+        const int per = (nch + sp - 1) / sp;              // the kernel gives each part `per` chunks:
+        if ((nch + per - 1) / per != sp) continue;        // no part may start beyond the last chunk
+        if (wino_tail_time(R, sp) < wino_tail_time(R, best) - 1e-9) best = sp;
+    }
+    if (best < 2) return;
     *nfull = T - R;
-    *split = sp;
+    *split = best;
 }
 
 template <int LOGW, int MODE>
@@ -591,7 +594,7 @@ int vf_wino_conv_fill_pct(int S, int Cin, int Cout, int H, int W, int* tiles_out
     wino_tail_plan(T, rup(Cin, WCK) / WCK, &nfull, &split);
     if (tiles_out) *tiles_out = T;
     if (T <= 0) return 0;
-    const double time = (nfull + WINO_SLOTS - 1) / WINO_SLOTS + (T > nfull ? 1.0 / split : 0.0);
+    const double time = (nfull + WINO_SLOTS - 1) / WINO_SLOTS + (T > nfull ? wino_tail_time(T - nfull, split) : 0.0);
     return (int)(100.0 * T / WINO_SLOTS / time);
 }
 

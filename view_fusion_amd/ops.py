@@ -217,7 +217,7 @@ def _packed(layer, force):
 
 WINOGRAD = True           # fused Winograd F(2x2,3x3) for stride-1 3x3 convs on large maps
 FORCE_WINOGRAD = False    # tests: take the Winograd path even when the grid would not fill the chip
-WINO_MIN_TILES = int(os.environ.get("VF_WINO_MIN_TILES", 100))   # policy thresholds (tuning aid)
+WINO_MIN_TILES = int(os.environ.get("VF_WINO_MIN_TILES", 30))   # policy thresholds (tuning aid)
 WINO_MIN_FILL = int(os.environ.get("VF_WINO_MIN_FILL", 65))
 WINOGRAD_WGRAD = True     # weight gradients of those layers (plain stride-1 ones) through the same transform
 
