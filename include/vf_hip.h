@@ -79,6 +79,16 @@ long vf_wino_wgrad_ws_floats(int S, int Cin, int Cout, int H, int W);
 int vf_wino_wgrad(const float* x, const float* dy, float* dw_oihw, float* ws, long ws_floats, int S, int Cin,
                   int Cout, int H, int W, int mode, void* stream);
 
+/* ---- grouped time-embedding affine: all FeatureWiseAffine Linear(K->C_g) layers of the UNet on the same
+ *      (S,K) embedding in one launch, unet.py:160-177.  desc = device int64 [ngroups][5] rows
+ *      {W_g, b_g, C_g, out_off_g (floats), c_off_g}; out/de = flat buffers of the (S,C_g) matrices; CT = sum C_g ---- */
+int vf_time_affine_fwd(const void* desc, int ngroups, const float* emb, float* out, int S, int K, int CT,
+                       void* stream);
+long vf_time_affine_ws_floats(int S, int K);
+int vf_time_affine_bwd(const void* desc, int ngroups, const float* emb, const float* de, float* dw /*[CT][K]*/,
+                       float* db /*[CT]*/, float* demb /*[S][K] or NULL*/, float* ws, int S, int K, int CT,
+                       void* stream);
+
 /* ---- batched GEMM + softmax : torch.einsum / torch.softmax / nn.Linear,
  *      unet.py:267-274 (attention), :29-31,165 (linears) ---- */
 int vf_bgemm(const float* A, const float* B, float* C, const float* bias /*[N]|NULL*/, int batch, int M, int N,

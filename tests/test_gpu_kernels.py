@@ -170,6 +170,30 @@ def test_group_norm_backward_rowsum(dev, C, H):
         assert (a - b).abs().max().item() < 1e-5 * max(1.0, b.abs().max().item()) + 2e-6 * scale
 
 
+@pytest.mark.parametrize("K,S", [(64, 7), (32, 96)])
+def test_time_affine_grouped(dev, K, S):
+    """All FeatureWiseAffine linears in one grouped launch == the individual nn.Linear layers (fwd, dW, db, demb)."""
+    from view_fusion_amd import ops
+    torch.manual_seed(0)
+    Cs = [64, 128, 6, 320, 192, 64]
+    lin_c = [torch.nn.Linear(K, C) for C in Cs]
+    lin_g = [torch.nn.Linear(K, C).to(dev) for C in Cs]
+    for a, b in zip(lin_c, lin_g):
+        b.load_state_dict(a.state_dict())
+    emb = rnd(S, K, seed=1)
+    gys = [rnd(S, C, seed=10 + i) for i, C in enumerate(Cs)]
+    ec = emb.clone().requires_grad_(True)
+    sum((l(ec) * g).sum() for l, g in zip(lin_c, gys)).backward()
+    eg = emb.to(dev).requires_grad_(True)
+    outs = ops.time_affine_all(eg, lin_g)
+    for o, l in zip(outs, lin_c):
+        assert rel(o, l(emb)) < 1e-5
+    sum((o * g.to(dev)).sum() for o, g in zip(outs, gys)).backward()
+    assert rel(eg.grad, ec.grad) < 2e-5
+    for a, b in zip(lin_c, lin_g):
+        assert rel(b.weight.grad, a.weight.grad) < 2e-5 and rel(b.bias.grad, a.bias.grad) < 2e-5
+
+
 def test_conv_large_batch_split_k(dev):
     """S large enough that wgrad runs many pixel tiles per slice; odd S for the 8x8 two-image tiles."""
     from view_fusion_amd import ops

@@ -484,6 +484,67 @@ def linear(x, weight, bias):
     return _LinearFn.apply(x, weight, bias)
 
 
+# ---------------------------------------------------------------------------------------------
+# All FeatureWiseAffine linears of the UNet (30 x Linear(K -> C_g) on the SAME embedding) as one grouped launch.
+_TA_DESC = {}
+
+
+def _ta_desc(layers, S, device):
+    key = (S, device, tuple(l.weight.data_ptr() for l in layers), tuple(l.bias.data_ptr() for l in layers))
+    hit = _TA_DESC.get(id(layers[0]))
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    rows, coff = [], 0
+    for l in layers:
+        C = l.weight.shape[0]
+        rows.append([l.weight.data_ptr(), l.bias.data_ptr(), C, S * coff, coff])
+        coff += C
+    plan = (torch.tensor(rows, dtype=torch.int64).to(device), [r[2] for r in rows], [r[4] for r in rows], coff)
+    _TA_DESC[id(layers[0])] = (key, plan)
+    return plan
+
+
+class _TimeAffineFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, emb, layers, *params):          # params = (w_0, b_0, w_1, b_1, ...) of `layers`, for autograd
+        _check(emb, *params)
+        S, K = emb.shape
+        desc, Cs, coffs, CT = _ta_desc(layers, S, emb.device)
+        out = torch.empty(S * CT, device=emb.device, dtype=torch.float32)
+        _lib.call("vf_time_affine_fwd", ctypes.c_void_p(desc.data_ptr()), len(Cs), _ptr(emb), _ptr(out), S, K, CT,
+                  _stream())
+        ctx.save_for_backward(emb)
+        ctx.plan = (desc, Cs, coffs, CT)
+        return tuple(out[S * o:S * (o + C)].view(S, C) for C, o in zip(Cs, coffs))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        (emb,) = ctx.saved_tensors
+        desc, Cs, coffs, CT = ctx.plan
+        S, K = emb.shape
+        de = torch.cat([(g if g is not None else emb.new_zeros(S, C)).reshape(-1) for g, C in zip(grads, Cs)])
+        dw = torch.empty(CT, K, device=emb.device, dtype=torch.float32)
+        db = torch.empty(CT, device=emb.device, dtype=torch.float32)
+        demb = ws = None
+        if ctx.needs_input_grad[0]:
+            demb = torch.empty_like(emb)
+            ws = torch.empty(_lib.load().vf_time_affine_ws_floats(S, K), device=emb.device, dtype=torch.float32)
+        _lib.call("vf_time_affine_bwd", ctypes.c_void_p(desc.data_ptr()), len(Cs), _ptr(emb), _ptr(de), _ptr(dw),
+                  _ptr(db), _ptr(demb), _ptr(ws), S, K, CT, _stream())
+        out = [demb, None]
+        for C, o in zip(Cs, coffs):
+            out += [dw[o:o + C], db[o:o + C]]
+        return tuple(out)
+
+
+def time_affine_all(emb, layers):
+    """[Linear_g(emb) for g in layers] (each (S, C_g)) in one launch; `layers` = list of nn.Linear holders."""
+    params = []
+    for l in layers:
+        params += [l.weight, l.bias]
+    return _TimeAffineFn.apply(emb, layers, *params)
+
+
 class _SwishFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):

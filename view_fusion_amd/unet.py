@@ -44,11 +44,11 @@ class _ResBlock(nn.Module):
         self.res_conv = nn.Conv2d(cin, cout, 1) if cin != cout else nn.Identity()
         self.groups = groups
 
-    def forward(self, x, emb):
+    def forward(self, x, e):
+        """e = this block's FeatureWiseAffine Linear(emb), (S,Cout): all blocks' are computed in one grouped
+        launch by UNet.forward."""
         from . import ops
         b1, b2 = self.block1["block"], self.block2["block"]
-        lin = self.noise_func["noise_func"]["0"]
-        e = ops.linear(emb, lin.weight, lin.bias)                                   # (S,Cout)
         # x feeds both the first GroupNorm and the residual branch: the GN op hands x back so that
         # the residual gradient is summed inside its backward kernel
         a, xs = ops.group_norm_skip(x, b1["0"].weight, b1["0"].bias, self.groups, silu=True)
@@ -82,8 +82,8 @@ class _ResAttnBlock(nn.Module):
         if with_attn:
             self.attn = _SelfAttention(cout, groups)
 
-    def forward(self, x, emb):
-        x = self.res_block(x, emb)
+    def forward(self, x, e):
+        x = self.res_block(x, e)
         return self.attn(x) if self.with_attn else x
 
 
@@ -179,6 +179,14 @@ class UNet(nn.Module):
                 mark(layer.conv, res, "up2")
         mark(self.final_conv["block"]["3"], res)
 
+    def _affine_layers(self):
+        lst = getattr(self, "_vf_affine", None)
+        if lst is None:
+            lst = [m.res_block.noise_func["noise_func"]["0"] for m in list(self.downs) + list(self.mid) + list(self.ups)
+                   if isinstance(m, _ResAttnBlock)]
+            object.__setattr__(self, "_vf_affine", lst)
+        return lst
+
     def forward(self, x, angle, time):
         """x (S,Cin,H,W), angle (S,1), time = noise level (S,1)  ->  (S,Cout,H,W)."""
         from . import ops
@@ -188,21 +196,23 @@ class UNet(nn.Module):
         pe = ops.sincos_embedding(time, angle, self.inner_channel)                  # (S,inner)
         emb = ops.linear(pe, mlp["0"].weight, mlp["0"].bias)
         emb = ops.linear(ops.swish(emb), mlp["2"].weight, mlp["2"].bias)            # (S,inner)
+        # FeatureWiseAffine of every residual block (unet.py:160-177) in one grouped launch
+        es = iter(ops.time_affine_all(emb, self._affine_layers()))
 
         feats = []
         for layer in self.downs:
             if isinstance(layer, _ResAttnBlock):
-                x = layer(x, emb)
+                x = layer(x, next(es))
             elif isinstance(layer, _Resample):
                 x = layer(x)
             else:
                 x = ops.conv2d(x, layer)
             feats.append(x)
         for layer in self.mid:
-            x = layer(x, emb)
+            x = layer(x, next(es))
         for layer in self.ups:
             if isinstance(layer, _ResAttnBlock):
-                x = layer(ops.concat_channels(x, feats.pop()), emb)
+                x = layer(ops.concat_channels(x, feats.pop()), next(es))
             else:
                 x = layer(x)
         fc = self.final_conv["block"]
