@@ -15,6 +15,7 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_sh
     torch.cuda.synchronize()
 print(prof.key_averages(group_by_input_shape=False).table(sort_by="cuda_time_total", row_limit=40, max_name_column_width=60))
 rows = [e for e in prof.key_averages(group_by_input_shape=True) if e.key.startswith("aten::")]
-rows.sort(key=lambda e: -e.count)
-for e in rows[:40]:
+rows = [e for e in rows if e.device_time_total > 0]
+rows.sort(key=lambda e: -e.device_time_total)
+for e in rows[:60]:
     print(e.key, e.count, e.input_shapes[:3], round(e.device_time_total, 1))
