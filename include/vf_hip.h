@@ -43,7 +43,9 @@ int vf_conv_pack_weights(const float* w_oihw, float* w_fwd, float* w_bwd /*or NU
  * {w, w_fwd, w_bwd, Cout, Cin, KS, fwd_floats, bwd_floats, first_block}, block = 256 elements */
 int vf_conv_pack_weights_multi(const void* desc, int nlayers, long total_blocks, void* stream);
 /* mode 0 stride-1 | 1 stride-2 (x is 2Hx2W) | 2 nearest-x2 upsampled x (x is H/2xW/2) |
- * 3 zero-dilated x (dgrad of mode 1).  H,W = OUTPUT size, square power of two in [8,128]. */
+ * 4 sub-pixel dgrad of mode 1: x = dY (HxW), y = dX (2Hx2W), every
+ * output parity gets its own taps (no zeros multiplied; w_packed = the dgrad pack; no epilogue operands).
+ * H,W = OUTPUT size (mode 4: the dY size), square power of two in [8,128]. */
 int vf_conv_fwd(const float* x, const float* w_packed, const float* bias /*[Cout]|NULL*/,
                 const float* view_bias /*[S][Cout]|NULL*/, const float* residual /*like y|NULL*/, float* y,
                 float* ws /*|NULL*/, long ws_floats, int S, int Cin, int Cout, int H, int W, int KS, int mode,

@@ -13,7 +13,8 @@
 // * MODE selects how the input patch is addressed, so the same kernel serves
 //     0: stride-1 conv / dgrad          1: stride-2 conv (Downsample)
 //     2: nearest-x2-upsampled input (Upsample conv, no 4x tensor is materialised)
-//     3: zero-dilated input (dgrad of the stride-2 conv)
+//     4: sub-pixel dgrad of the stride-2 conv: x = dY (HxW), y = dX (2Hx2W); each output parity (2i+a, 2j+b)
+//        has its own accumulator set and tap subset, so no zeros are multiplied
 // * Epilogue fuses bias[co] + per-view bias[s][co] (time/angle embedding) + residual.
 // * wgrad: D[co][ci] per tap = sum_pixels dY[co][p] * X[ci][p (+) tap]; split-K over pixel
 //   tiles into slabs, reduced by a second deterministic kernel (no float atomics).
@@ -38,13 +39,13 @@ struct Geo {
     static constexpr int TH = HW >= TPIX ? TPIX / W : H;         // output rows per image per tile
     static constexpr int TPI = HW >= TPIX ? HW / TPIX : 1;       // tiles per image
     static constexpr int PAD = KS / 2;
-    static constexpr int PH = MODE == 1 ? 2 * TH + 1 : TH + 2 * PAD;
-    static constexpr int PW = KS == 1 ? W : (MODE == 1 ? 2 * W + 4 : W + 8);
-    static constexpr int CO = KS == 1 ? 0 : 3;                   // LDS column of patch x = -1
+    static constexpr int PH = MODE == 1 ? 2 * TH + 1 : (MODE == 4 ? TH + 1 : TH + 2 * PAD);
+    static constexpr int PW = KS == 1 ? W : (MODE == 1 ? 2 * W + 4 : (MODE == 4 ? W + 4 : W + 8));
+    static constexpr int CO = (KS == 1 || MODE == 4) ? 0 : 3;    // LDS column of patch x = -1 (MODE 4: no left halo)
     static constexpr int Q = (MODE == 1 ? 2 * W : W) / 4;        // interior float4 per patch row
     static constexpr int PS = IM * PH * PW;                      // floats per channel plane
-    static constexpr int SH = MODE == 1 ? 2 * H : ((MODE == 2 || MODE == 3) ? H / 2 : H);  // source
-    static constexpr int SW = MODE == 1 ? 2 * W : ((MODE == 2 || MODE == 3) ? W / 2 : W);
+    static constexpr int SH = MODE == 1 ? 2 * H : (MODE == 2 ? H / 2 : H);  // source
+    static constexpr int SW = MODE == 1 ? 2 * W : (MODE == 2 ? W / 2 : W);
     // LDS offset (within a channel plane) of the patch element that output pixel p (0..127 of
     // the tile) reads for tap (0,0)
     static __host__ __device__ constexpr int pix_off(int p) {
@@ -81,11 +82,14 @@ __device__ __forceinline__ float4 load_patch4(const float* __restrict__ x, int S
     } else if (MODE == 1) {
         const int gy = 2 * r0 + pr - 1;
         if (gy >= 0 && gy < G::SH) v = *reinterpret_cast<const float4*>(x + plane + gy * G::SW + 4 * q);
+    } else if (MODE == 4) {                       // rows r0 .. r0+TH (one halo row below, zero column on the right)
+        const int gy = r0 + pr;
+        if (gy < G::H) v = *reinterpret_cast<const float4*>(x + plane + gy * G::SW + 4 * q);
     } else {
         const int uy = r0 + pr - G::PAD;
-        if (uy >= 0 && uy < G::H && (MODE == 2 || (uy & 1) == 0)) {
+        if (uy >= 0 && uy < G::H) {
             const float2 t = *reinterpret_cast<const float2*>(x + plane + (uy >> 1) * G::SW + 2 * q);
-            v = MODE == 2 ? make_float4(t.x, t.x, t.y, t.y) : make_float4(t.x, 0.f, t.y, 0.f);
+            v = make_float4(t.x, t.x, t.y, t.y);
         }
     }
     return v;
@@ -165,7 +169,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
     auto store_x = [&](int e, const float4& v) {
         const int q = e % G::Q;
         const int t1 = e / G::Q;                                  // (ci*IM + im)*PH + pr
-        *reinterpret_cast<float4*>(xl + t1 * G::PW + 4 * q + (KS == 1 ? 0 : 4)) = v;
+        *reinterpret_cast<float4*>(xl + t1 * G::PW + 4 * q + ((KS == 1 || MODE == 4) ? 0 : 4)) = v;
     };
 #define VF_LOAD_CHUNK(D_, C0)                                                         \
     {                                                                                 \
@@ -186,12 +190,17 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
         if (XT && tid + NXF * 256 < NX4) store_x(tid + NXF * 256, xtail[D_]);          \
     }
 
-    f32x16 acc[NCO][NPT];
+    // MODE 4 (sub-pixel dgrad of the stride-2 conv): four accumulator sets = the four output parities (2i+a, 2j+b);
+    // tap (kh, kw) feeds exactly one of them, so the 9 MFMA groups of a chunk are the whole work -- a quarter of
+    // what the zero-dilated form (MODE 3) multiplies.
+    constexpr int NACC = MODE == 4 ? 4 : NCO;
+    static_assert(MODE != 4 || NCO == 1, "MODE 4 uses the accumulator sets for the output parities");
+    f32x16 acc[NACC][NPT];
     int xo[NPT];
 #pragma unroll
     for (int nt = 0; nt < NPT; ++nt) {
 #pragma unroll
-        for (int j = 0; j < NCO; ++j) acc[j][nt] = (f32x16){0};
+        for (int j = 0; j < NACC; ++j) acc[j][nt] = (f32x16){0};
         xo[nt] = 4 * lh * G::PS + G::pix_off(pw * 32 * NPT + nt * 32 + li);
     }
     // k order inside an 8-channel group: MFMA step s pairs channel s (lane half 0) with channel
@@ -201,7 +210,10 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
         return *reinterpret_cast<const float4*>(wb + j * WLS + g * TCO * WROW);
     };
     auto frag_b = [&](int g, int nt, int s) -> float {
-        const int off = KS == 3 ? (g / 3) * G::PW + (g % 3) + s * G::PS : (8 * g + s) * G::PS;
+        // MODE 4: packed tap g holds w[kh][kw] with kh = 2 - g/3, kw = 2 - g%3 (dgrad pack = flipped taps); it
+        // reads dy one row down / one column right iff kh == 0 / kw == 0
+        const int off = MODE == 4 ? (g / 3 == 2 ? G::PW : 0) + (g % 3 == 2 ? 1 : 0) + s * G::PS
+                                  : (KS == 3 ? (g / 3) * G::PW + (g % 3) + s * G::PS : (8 * g + s) * G::PS);
         return xl[xo[nt] + off];
     };
 
@@ -250,11 +262,13 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
             for (int j = 0; j < NCO; ++j) {
                 if (NCO > 1 && j >= nco_here) continue;            // wave-uniform: trailing tile absent
                 const float av[4] = {a_cur[j].x, a_cur[j].y, a_cur[j].z, a_cur[j].w};
+                // output parity of tap g in MODE 4: a = (kh != 1), b = (kw != 1)
+                const int ja = MODE == 4 ? 2 * (g / 3 != 1) + (g % 3 != 1) : j;
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
 #pragma unroll
                     for (int nt = 0; nt < NPT; ++nt)
-                        acc[j][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], b_cur[nt][s], acc[j][nt], 0, 0, 0);
+                        acc[ja][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], b_cur[nt][s], acc[ja][nt], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
             if (g + 1 < NG) {
@@ -274,6 +288,28 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
 #ifdef VF_CONV_STAMPS
     st_[2] = clock64();
 #endif
+    if constexpr (MODE == 4) {        // dx (S, Cout, 2H, 2W): pixel (i, j) of the tile -> the 2x2 block (2i+a, 2j+b)
+#pragma unroll
+        for (int nt = 0; nt < NPT; ++nt) {
+            const int p = pw * 32 * NPT + nt * 32 + li;
+            const int s = G::IM > 1 ? s0 + (p >> (2 * LOGW)) : s0;
+            const int pix = G::IM > 1 ? (p & (G::HW - 1)) : r0 * G::W + p;
+            if (s >= a.S) continue;
+            const int pi = pix >> LOGW, pj = pix & (G::W - 1);
+            const int cob = co0 + cw * 32 + 4 * lh;
+            float* ob = a.y + ((size_t)s * a.Cout + cob) * (4 * G::HW) + (size_t)(2 * pi) * (2 * G::W) + 2 * pj;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int dco = (r & 3) + 8 * (r >> 2);
+                if (cob + dco < a.Cout) {
+                    float* o = ob + (size_t)dco * (4 * G::HW);
+                    *reinterpret_cast<float2*>(o) = make_float2(acc[0][nt][r], acc[1][nt][r]);
+                    *reinterpret_cast<float2*>(o + 2 * G::W) = make_float2(acc[2][nt][r], acc[3][nt][r]);
+                }
+            }
+        }
+        return;
+    }
     // All loads of a 32x32 tile (residual, biases) are issued before any of its stores so that
     // their latency overlaps instead of forming a load->add->store chain per element.
 #pragma unroll
@@ -795,7 +831,8 @@ int vf_conv_pack_weights_multi(const void* desc, int nlayers, long total_blocks,
 // y[S][Cout][H][W] = conv(x) (+bias +view_bias +residual).  H == W == power of two in [8,128]
 // is the OUTPUT size.  `w_packed` comes from vf_conv_pack_weights.
 // mode 0: x is [S][Cin][H][W]; 1: stride 2, x is [S][Cin][2H][2W]; 2: x is [S][Cin][H/2][W/2]
-// nearest-upsampled on the fly; 3: x is [S][Cin][H/2][W/2] zero-dilated on the fly.
+// nearest-upsampled on the fly; 4: x = dY [S][Cin][H][W] of a stride-2 conv, y = dX [S][Cout][2H][2W] (w_packed =
+// the dgrad pack, no epilogue operands).
 // ws / ws_floats: optional split-K workspace (see vf_conv_fwd_ws_floats); NULL disables split-K.
 int vf_conv_fwd(const float* x, const float* w_packed, const float* bias, const float* view_bias,
                 const float* residual, float* y, float* ws, long ws_floats, int S, int Cin, int Cout, int H,
@@ -817,7 +854,7 @@ int vf_conv_fwd(const float* x, const float* w_packed, const float* bias, const 
     VF_CASE(3, 3, 0) VF_CASE(3, 4, 0) VF_CASE(3, 5, 0) VF_CASE(3, 6, 0) VF_CASE(3, 7, 0)
     VF_CASE(3, 3, 1) VF_CASE(3, 4, 1) VF_CASE(3, 5, 1) VF_CASE(3, 6, 1)
     VF_CASE(3, 4, 2) VF_CASE(3, 5, 2) VF_CASE(3, 6, 2) VF_CASE(3, 7, 2)
-    VF_CASE(3, 4, 3) VF_CASE(3, 5, 3) VF_CASE(3, 6, 3) VF_CASE(3, 7, 3)
+    VF_CASE(3, 3, 4) VF_CASE(3, 4, 4) VF_CASE(3, 5, 4) VF_CASE(3, 6, 4)
     VF_CASE(1, 3, 0) VF_CASE(1, 4, 0) VF_CASE(1, 5, 0) VF_CASE(1, 6, 0) VF_CASE(1, 7, 0)
 #undef VF_CASE
     return (int)hipErrorInvalidValue;

@@ -383,10 +383,10 @@ class _Conv2dFn(torch.autograd.Function):
                 ws, nws = _conv_ws(x.device, S, Cout, Cin, H, W, KS)
                 _launch("conv_dgrad", ctx.flops, "vf_conv_fwd", _ptr(dy), _ptr(ctx.wb), None, None, None, _ptr(dx),
                         _ptr(ws), nws, S, Cout, Cin, H, W, KS, 0, st, tag=ctx.tag)
-            elif m == 1:      # stride-2 conv: transposed conv = conv over the zero-dilated dy
+            elif m == 1:      # stride-2 conv: sub-pixel transposed conv (each output parity gets its own taps)
                 dx = torch.empty_like(x)
                 _launch("conv_dgrad", ctx.flops, "vf_conv_fwd", _ptr(dy), _ptr(ctx.wb), None, None, None, _ptr(dx),
-                        None, 0, S, Cout, Cin, Hi, Wi, KS, 3, st, tag=ctx.tag)
+                        None, 0, S, Cout, Cin, H, W, KS, 4, st, tag=ctx.tag)
             else:             # upsample + conv: dgrad at the upsampled size, then 2x2 sum-pool
                 dup = torch.empty(S, Cin, H, W, device=x.device, dtype=torch.float32)
                 _launch("conv_dgrad", ctx.flops, "vf_conv_fwd", _ptr(dy), _ptr(ctx.wb), None, None, None, _ptr(dup),
