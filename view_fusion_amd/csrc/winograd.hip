@@ -131,6 +131,7 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(WinoArgs a) {
 #endif
     for (int i = tid; i < 2 * PSZ; i += NT_) Pl[i] = 0.f;    // halo columns stay zero in both buffers
 
+    const int clast = max(nch - 1, 0);
     const float* usrc = a.u + ((size_t)cot * (a.CinP / WCK) + c0) * USZ;
     // named registers + macros (not arrays behind lambdas: those end up in scratch memory)
     float4 ur0, ur1, ur2, ur3;
@@ -201,23 +202,25 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(WinoArgs a) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) acc[k] = (f32x16){0};
 
-    // ---- prologue: U(0), rows(0), rows(1) staged; V(0) transformed; U(1), rows(2) in flight
+    // ---- prologue: U(0), rows(0), rows(1) staged; V(0) transformed; U(1), rows(2) in flight.  All three first
+    // loads are issued together (one round trip instead of two) and the next ones right after their registers are
+    // free, so they overlap the first input transform.
     VF_ULOAD_ALL(0);
     VF_XLOAD(0);
+    float4 yr0 = fetch_x(0, min(1, clast)), yr1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (NXR > 1) yr1 = fetch_x(1, min(1, clast));
     __syncthreads();                                      // zero fill done
     VF_USTORE_ALL(0);
     VF_XSTORE(0);
-    if (nch > 1) {
-        VF_XLOAD(1);
-        VF_XSTORE(1);
-    }
+    if (tid < NX4) *reinterpret_cast<float4*>(Pl + PSZ + xlo[0]) = yr0;
+    if (NXR > 1 && tid + NT_ < NX4) *reinterpret_cast<float4*>(Pl + PSZ + xlo[1]) = yr1;
+    VF_ULOAD_ALL(min(1, clast));
+    VF_XLOAD(min(2, clast));
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < 4; ++r) win_read_row(r, 0);
 #pragma unroll
     for (int r = 0; r < 4; ++r) win_write_row(r, 0);
-    if (nch > 1) VF_ULOAD_ALL(1);
-    if (nch > 2) VF_XLOAD(2);
     __syncthreads();
 
     const int uoff = 8 * kh * WTCO * WCK + (cw * 32 + li) * WCK + 4 * (lh ^ ((li >> 4) & 1));
@@ -226,7 +229,6 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(WinoArgs a) {
     // (the final iterations redo harmless loads / LDS writes that nobody reads): without loop-tail branches
     // the compiler counts outstanding loads exactly; with them it falls back to s_waitcnt vmcnt(0) in front of
     // every staging access, i.e. a full load round trip per slice.
-    const int clast = nch - 1;
     for (int c = 0; c < nch; ++c) {
         const int cur = c & 1, nxt = cur ^ 1;
         constexpr bool has1 = true, has2 = true, has3 = true;
