@@ -129,8 +129,6 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(WinoArgs a) {
 #ifdef VF_CONV_STAMPS   // diagnostic build only (tools/wino_stamps.py)
     long long st_[2] = {clock64(), 0}, rt0_ = wall_clock64();
 #endif
-    for (int i = tid; i < 2 * PSZ; i += NT_) Pl[i] = 0.f;    // halo columns stay zero in both buffers
-
     const int clast = max(nch - 1, 0);
     const float* usrc = a.u + ((size_t)cot * (a.CinP / WCK) + c0) * USZ;
     // named registers + macros (not arrays behind lambdas: those end up in scratch memory)
@@ -209,6 +207,7 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(WinoArgs a) {
     VF_XLOAD(0);
     float4 yr0 = fetch_x(0, min(1, clast)), yr1 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (NXR > 1) yr1 = fetch_x(1, min(1, clast));
+    for (int i = tid; i < 2 * PSZ; i += NT_) Pl[i] = 0.f;    // halo columns stay zero in both buffers (under the loads)
     __syncthreads();                                      // zero fill done
     VF_USTORE_ALL(0);
     VF_XSTORE(0);
