@@ -43,19 +43,29 @@ __global__ __launch_bounds__(L >= 128 ? 256 : 128) void attn_fwd_kernel(const fl
 #pragma unroll
     for (int t = 0; t < NKT; ++t) acc[t] = (f32x16){0};
 
+    // K / Q chunk staging: all loads of a chunk are issued together into registers, one chunk ahead of their use
+    // (a `*lds = *global` loop compiles to load -> wait -> store per element: six serial round trips per chunk)
+    constexpr int NK4 = CKA * L / 4 / NTH, NQ4 = CKA * QW / 4 / NTH;
+    static_assert(NK4 * NTH * 4 == CKA * L && NQ4 * NTH * 4 == CKA * QW, "whole passes");
+    // (named registers: the array form of these staging sets is not promoted out of scratch memory)
+    float4 kr0, kr1, kr2, kr3, qr0, qr1;
+    kr0 = kr1 = kr2 = kr3 = qr0 = qr1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    static_assert(NK4 <= 4 && NQ4 <= 2, "staging register sets");
+#define VF_AT_LK(I, C0) if constexpr ((I) < NK4) { const int e = tid + (I) * NTH;                          \
+        kr##I = *reinterpret_cast<const float4*>(kb + (size_t)((C0) + e / (L / 4)) * L + 4 * (e % (L / 4))); }
+#define VF_AT_LQ(I, C0) if constexpr ((I) < NQ4) { const int e = tid + (I) * NTH;                          \
+        qr##I = *reinterpret_cast<const float4*>(qb + (size_t)((C0) + e / (QW / 4)) * L + q0 + 4 * (e % (QW / 4))); }
+#define VF_AT_SK(I) if constexpr ((I) < NK4) { const int e = tid + (I) * NTH;                               \
+        *reinterpret_cast<float4*>(Kl + (e / (L / 4)) * L + 4 * (e % (L / 4))) = kr##I; }
+#define VF_AT_SQ(I) if constexpr ((I) < NQ4) { const int e = tid + (I) * NTH;                               \
+        *reinterpret_cast<float4*>(Ql + (e / (QW / 4)) * QW + 4 * (e % (QW / 4))) = qr##I; }
+#define VF_AT_LOAD(C0) { VF_AT_LK(0, C0) VF_AT_LK(1, C0) VF_AT_LK(2, C0) VF_AT_LK(3, C0) VF_AT_LQ(0, C0) VF_AT_LQ(1, C0) }
+    VF_AT_LOAD(0);
     for (int c0 = 0; c0 < C; c0 += CKA) {
         __syncthreads();
-        for (int e = tid; e < CKA * L / 4; e += NTH) {
-            const int row = e / (L / 4), q4 = e % (L / 4);
-            *reinterpret_cast<float4*>(Kl + row * L + 4 * q4) =
-                *reinterpret_cast<const float4*>(kb + (size_t)(c0 + row) * L + 4 * q4);
-        }
-        for (int e = tid; e < CKA * QW / 4; e += NTH) {
-            const int row = e / (QW / 4), q4 = e % (QW / 4);
-            *reinterpret_cast<float4*>(Ql + row * QW + 4 * q4) =
-                *reinterpret_cast<const float4*>(qb + (size_t)(c0 + row) * L + q0 + 4 * q4);
-        }
+        VF_AT_SK(0) VF_AT_SK(1) VF_AT_SK(2) VF_AT_SK(3) VF_AT_SQ(0) VF_AT_SQ(1)
         __syncthreads();
+        VF_AT_LOAD(min(c0 + CKA, C - CKA));              // next chunk (clamped: the last one is re-read, unused)
 #pragma unroll
         for (int s = 0; s < CKA / 2; ++s) {
             const float bq = Ql[(2 * s + lh) * QW + wid * 32 + li];
@@ -66,6 +76,23 @@ __global__ __launch_bounds__(L >= 128 ? 256 : 128) void attn_fwd_kernel(const fl
             }
         }
     }
+#undef VF_AT_LOAD
+#undef VF_AT_LK
+#undef VF_AT_LQ
+#undef VF_AT_SK
+#undef VF_AT_SQ
+    // first V chunk: requested now, lands while the softmax is computed
+    constexpr int NV4 = 32 * L / 4 / NTH;
+    static_assert(NV4 * NTH * 4 == 32 * L, "whole passes");
+    static_assert(NV4 <= 8, "staging register set");
+    float4 vr0, vr1, vr2, vr3, vr4, vr5, vr6, vr7;
+    vr0 = vr1 = vr2 = vr3 = vr4 = vr5 = vr6 = vr7 = make_float4(0.f, 0.f, 0.f, 0.f);
+#define VF_AT_LV(I, C0) if constexpr ((I) < NV4) { const int e = tid + (I) * NTH;                          \
+        vr##I = *reinterpret_cast<const float4*>(vb + (size_t)((C0) + e / (L / 4)) * L + 4 * (e % (L / 4))); }
+#define VF_AT_SV(I) if constexpr ((I) < NV4) { const int e = tid + (I) * NTH;                               \
+        *reinterpret_cast<float4*>(Vl + (e / (L / 4)) * RSV + 4 * (e % (L / 4))) = vr##I; }
+#define VF_AT_LOADV(C0) { VF_AT_LV(0, C0) VF_AT_LV(1, C0) VF_AT_LV(2, C0) VF_AT_LV(3, C0) VF_AT_LV(4, C0) VF_AT_LV(5, C0) VF_AT_LV(6, C0) VF_AT_LV(7, C0) }
+    VF_AT_LOADV(0);
 
     // softmax over keys: this lane's query, keys in registers (+ the other lane half)
     float mx = -INFINITY;
@@ -103,12 +130,9 @@ __global__ __launch_bounds__(L >= 128 ? 256 : 128) void attn_fwd_kernel(const fl
 
     for (int c0 = 0; c0 < C; c0 += 32) {
         __syncthreads();
-        for (int e = tid; e < 32 * L / 4; e += NTH) {
-            const int row = e / (L / 4), q4 = e % (L / 4);
-            *reinterpret_cast<float4*>(Vl + row * RSV + 4 * q4) =
-                *reinterpret_cast<const float4*>(vb + (size_t)(c0 + row) * L + 4 * q4);
-        }
+        VF_AT_SV(0) VF_AT_SV(1) VF_AT_SV(2) VF_AT_SV(3) VF_AT_SV(4) VF_AT_SV(5) VF_AT_SV(6) VF_AT_SV(7)
         __syncthreads();
+        VF_AT_LOADV(min(c0 + 32, C - 32));               // next chunk, issued before this chunk's output stores
         f32x16 o = {0};
 #pragma unroll
         for (int t = 0; t < NKT; ++t)
@@ -126,6 +150,9 @@ __global__ __launch_bounds__(L >= 128 ? 256 : 128) void attn_fwd_kernel(const fl
             out[((size_t)b * C + c) * L + qi] = o[r];
         }
     }
+#undef VF_AT_LOADV
+#undef VF_AT_LV
+#undef VF_AT_SV
 }
 
 }  // namespace
