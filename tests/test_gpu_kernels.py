@@ -138,7 +138,7 @@ def test_conv_winograd_small_maps(dev, Cin, Cout, Hin, mode, S):
         ops.FORCE_WINOGRAD = False
 
 
-@pytest.mark.parametrize("C,H", [(64, 64), (128, 32), (192, 16), (320, 16), (96, 32)])
+@pytest.mark.parametrize("C,H", [(64, 64), (128, 32), (192, 16), (320, 16), (96, 32), (320, 8), (640, 8), (96, 8)])
 def test_group_norm_backward_rowsum(dev, C, H):
     """The GroupNorm backward's closed-form per-(view, channel) sum of dx == the sum of the dx it wrote; a conv
     whose dY is that tensor takes its bias gradients from it (same result as the rowsum kernels)."""

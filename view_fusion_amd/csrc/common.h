@@ -18,6 +18,14 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// sum over aligned segments of SEG lanes (SEG a power of two <= 64); every lane of a segment gets the sum
+template <int SEG>
+__device__ __forceinline__ float seg_sum(float v) {
+#pragma unroll
+    for (int o = SEG / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, VF_WAVE);
+    return v;
+}
+
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, VF_WAVE));

@@ -180,7 +180,9 @@ __global__ __launch_bounds__(256) void gn_bwd_dx_kernel(const float* __restrict_
 // slot in a fixed order (deterministic), combined after one barrier.
 // Optional `addend` (same shape as x) is added to dx: fuses the gradient of a second use of x
 // (residual / skip branch) that autograd would otherwise sum with a separate kernel.
-template <int NV, int NT>
+// SEG = lanes that share a channel in one 64-lane access: 64 when a channel row has >= 64 float4 (HW >= 256),
+// 16 on 8x8 maps (HW = 64: four channels per access, reduced per 16-lane segment).
+template <int NV, int NT, int SEG = 64>
 __global__ __launch_bounds__(NT) void gn_bwd_fused_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                           const float* __restrict__ gamma,
                                                           const float* __restrict__ beta,
@@ -217,18 +219,23 @@ __global__ __launch_bounds__(NT) void gn_bwd_fused_kernel(const float* __restric
     }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        // wave-uniform channel of this access (HW >= 256 on this path): scalar loads, no vector registers
-        const int c = __builtin_amdgcn_readfirstlane(g * cpg + min(wid * 64 + i * NT, n4 - 1) / hw4);
-        gam[i] = gamma[c];
-        bet[i] = beta[c];
+        if (SEG == 64) {   // wave-uniform channel of this access: scalar loads, no vector registers
+            const int c = __builtin_amdgcn_readfirstlane(g * cpg + min(wid * 64 + i * NT, n4 - 1) / hw4);
+            gam[i] = gamma[c];
+            bet[i] = beta[c];
+        } else {
+            const int c = g * cpg + min((int)threadIdx.x + i * NT, n4 - 1) / hw4;
+            gam[i] = gamma[c];
+            bet[i] = beta[c];
+        }
     }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        const int idx0 = wid * 64 + i * NT;          // wave-uniform first index of this access
+        const int idx0 = wid * 64 + i * NT + (SEG == 64 ? 0 : (lane & ~(SEG - 1)));   // first index of this lane's segment
         float a = 0.f, b = 0.f, xsum = 0.f;
         int cl = 0;
         if (idx0 < n4) {
-            cl = idx0 / hw4;                         // channel within the group (wave-uniform)
+            cl = idx0 / hw4;                         // channel within the group (uniform over the segment)
             const float ga = gam[i], be = bet[i];
             float xs[4] = {xv[i].x, xv[i].y, xv[i].z, xv[i].w};
             float ds[4] = {dv[i].x, dv[i].y, dv[i].z, dv[i].w};
@@ -245,10 +252,10 @@ __global__ __launch_bounds__(NT) void gn_bwd_fused_kernel(const float* __restric
             xv[i] = make_float4(xs[0], xs[1], xs[2], xs[3]);
             dv[i] = make_float4(ds[0], ds[1], ds[2], ds[3]);
         }
-        a = wave_sum(a);
-        b = wave_sum(b);
-        if (dx_rowsum) xsum = wave_sum(xsum);
-        if (lane == 0 && idx0 < n4) {
+        a = seg_sum<SEG>(a);
+        b = seg_sum<SEG>(b);
+        if (dx_rowsum) xsum = seg_sum<SEG>(xsum);
+        if ((lane & (SEG - 1)) == 0 && idx0 < n4) {
             part[(wid * cpg + cl) * 3 + 0] += a;
             part[(wid * cpg + cl) * 3 + 1] += b;
             part[(wid * cpg + cl) * 3 + 2] += xsum;
@@ -440,7 +447,8 @@ int vf_gn_fwd(const float* x, const float* gamma, const float* beta, float* y, f
 // 1 when vf_gn_bwd fills `dx_rowsum` at this shape (the single-pass kernel; the two-kernel path does not)
 int vf_gn_bwd_emits_rowsum(int C, int HW, int groups) {
     if (groups <= 0 || C % groups != 0 || (HW & 3)) return 0;
-    return (HW >= 256 && (long)(C / groups) * HW / 4 <= 8192) ? 1 : 0;
+    const long n4g = (long)(C / groups) * HW / 4;
+    return ((HW >= 256 && n4g <= 8192) || (HW == 64 && n4g <= 1024)) ? 1 : 0;
 }
 
 int vf_gn_bwd(const float* x, const float* gamma, const float* beta, const float* mean, const float* rstd,
@@ -452,6 +460,18 @@ int vf_gn_bwd(const float* x, const float* gamma, const float* beta, const float
     const int cpg = C / groups;
     const int rows = S * C;
     const long n4g = (long)cpg * HW / 4;
+    if (HW == 64 && n4g <= 1024) {       // 8x8 maps: 16-lane channel segments
+#define VF_GNB16(NV)                                                                                       \
+    {                                                                                                      \
+        hipLaunchKernelGGL((gn_bwd_fused_kernel<NV, 256, 16>), dim3(S * groups), dim3(256), 4 * cpg * 3 * 4, st, x, dy, \
+                           gamma, beta, mean, rstd, addend, dx, dgamma_part, dbeta_part, dx_rowsum, C, HW, cpg, silu); \
+        VF_RETURN_LAST_ERROR();                                                                            \
+    }
+        if (n4g <= 256) VF_GNB16(1)
+        if (n4g <= 512) VF_GNB16(2)
+        VF_GNB16(4)
+#undef VF_GNB16
+    }
     if (HW >= 256 && n4g <= 8192) {
 #define VF_GNB(NV, NT)                                                                                     \
     {                                                                                                      \
