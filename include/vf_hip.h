@@ -28,6 +28,15 @@ int vf_gn_bwd_emits_rowsum(int C, int HW, int groups);
 int vf_gn_bwd(const float* x, const float* gamma, const float* beta, const float* mean, const float* rstd,
               const float* dy, const float* addend, float* dx, float* dgamma_part, float* dbeta_part,
               float* dx_rowsum, int S, int C, int HW, int groups, int silu, void* stream);
+/* same on the never-materialised channel concatenation [x (C1 channels) | x2 (C - C1)] of two NCHW tensors
+ * (decoder skip connections, unet.py:134); the second-consumer gradients and dx are split the same way.
+ * x2 == NULL: plain.  Backward: single-pass shapes only (vf_gn_bwd_emits_rowsum). */
+int vf_gn_cat_fwd(const float* x, const float* x2, int C1, const float* gamma, const float* beta, float* y, float* mean,
+                  float* rstd, int S, int C, int HW, int groups, float eps, int silu, void* stream);
+int vf_gn_cat_bwd(const float* x, const float* x2, int C1, const float* gamma, const float* beta, const float* mean,
+                  const float* rstd, const float* dy, const float* addend, const float* addend2, float* dx, float* dx2,
+                  float* dgamma_part, float* dbeta_part, float* dx_rowsum, int S, int C, int HW, int groups, int silu,
+                  void* stream);
 int vf_rowsum(const float* x, float* out /*[rows]*/, int rows, int len, void* stream);
 /* conv epilogue gradients in one launch: db[C] (|NULL) and dvb[S][C] (|NULL) from dy[S][C][HW] */
 int vf_bias_grad(const float* dy, float* db, float* dvb, int S, int C, int HW, void* stream);
@@ -52,6 +61,14 @@ int vf_conv_fwd(const float* x, const float* w_packed, const float* bias /*[Cout
                 void* stream);
 /* split-K workspace the call above wants at this shape (0 when the natural grid fills the chip) */
 long vf_conv_fwd_ws_floats(int S, int Cin, int Cout, int H, int W, int KS);
+/* 1x1 conv on the channel concatenation [x1 (C1 channels, multiple of 64) | x2] (residual conv of the decoder
+ * blocks, unet.py:134,238): forward, dgrad into two tensors, wgrad */
+int vf_conv1x1_cat_fwd(const float* x1, const float* x2, int C1, const float* w_packed, const float* bias, float* y,
+                       float* ws, long ws_floats, int S, int Cin, int Cout, int H, int W, void* stream);
+int vf_conv1x1_cat_dgrad(const float* dy, const float* w_packed_bwd, float* dx1, float* dx2, int C1, int S, int Cin,
+                         int Cout, int H, int W, void* stream);
+int vf_conv1x1_cat_wgrad(const float* x1, const float* x2, int C1, const float* dy, float* dw_oihw, float* ws,
+                         long ws_floats, int S, int Cin, int Cout, int H, int W, void* stream);
 long vf_conv_wgrad_ws_floats(int S, int Cin, int Cout, int H, int W, int KS);
 int vf_conv_wgrad(const float* x, const float* dy, float* dw_oihw, float* ws, long ws_floats, int S, int Cin,
                   int Cout, int H, int W, int KS, int mode, void* stream);

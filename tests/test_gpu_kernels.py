@@ -194,6 +194,37 @@ def test_time_affine_grouped(dev, K, S):
         assert rel(b.weight.grad, a.weight.grad) < 2e-5 and rel(b.bias.grad, a.bias.grad) < 2e-5
 
 
+@pytest.mark.parametrize("C1,C2,H,Cout,S", [(64, 64, 64, 64, 3), (192, 128, 32, 128, 3), (320, 192, 8, 320, 6),
+                                             (128, 64, 16, 192, 5), (320, 320, 8, 320, 2)])
+def test_cat_free_decoder_ops(dev, C1, C2, H, Cout, S):
+    """GroupNorm(+Swish) and the residual 1x1 conv on cat(x1, x2) without building the concatenation:
+    forward and every gradient vs the materialised torch reference (groups straddle the split at C = 320)."""
+    from view_fusion_amd import ops
+    torch.manual_seed(0)
+    C = C1 + C2
+    x1, x2 = rnd(S, C1, H, H, seed=1), rnd(S, C2, H, H, seed=2)
+    gamma, beta = 1 + 0.1 * rnd(C, seed=3), 0.1 * rnd(C, seed=4)
+    ga, gr = rnd(S, C, H, H, seed=5), rnd(S, Cout, H, H, seed=6)
+    conv_c = torch.nn.Conv2d(C, Cout, 1)
+    conv_g = torch.nn.Conv2d(C, Cout, 1).to(dev)
+    conv_g.load_state_dict(conv_c.state_dict())
+    x1c, x2c, gc, bc = (t.clone().requires_grad_(True) for t in (x1, x2, gamma, beta))
+    xc = torch.cat([x1c, x2c], 1)
+    ac = F.silu(F.group_norm(xc, 32, gc, bc, 1e-5))
+    rc = conv_c(xc)
+    ((ac * ga).sum() + (rc * gr).sum()).backward()
+    x1g, x2g, gg, bg = (t.to(dev).requires_grad_(True) for t in (x1, x2, gamma, beta))
+    assert ops.cat_fusable(C1, C, H * H, 32)
+    ag, t1, t2 = ops.group_norm_cat_skip(x1g, x2g, gg, bg, 32, True)
+    rg = ops.conv1x1_cat(t1, t2, conv_g)
+    assert rel(ag, ac) < 1e-5 and rel(rg, rc) < 2e-5
+    ((ag * ga.to(dev)).sum() + (rg * gr.to(dev)).sum()).backward()
+    for a, b in ((x1g, x1c), (x2g, x2c), (gg, gc), (bg, bc)):
+        assert rel(a.grad, b.grad) < 3e-5
+    assert rel(conv_g.weight.grad, conv_c.weight.grad) < 1e-4
+    assert rel(conv_g.bias.grad, conv_c.bias.grad) < 2e-5
+
+
 def test_conv_large_batch_split_k(dev):
     """S large enough that wgrad runs many pixel tiles per slice; odd S for the 8x8 two-image tiles."""
     from view_fusion_amd import ops

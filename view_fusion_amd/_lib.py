@@ -19,6 +19,11 @@ _P, _I, _L, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
 SIGNATURES = {
     "vf_gn_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P],
     "vf_gn_bwd_emits_rowsum": [_I, _I, _I],
+    "vf_gn_cat_fwd": [_P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P],
+    "vf_gn_cat_bwd": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "vf_conv1x1_cat_fwd": [_P, _P, _I, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _P],
+    "vf_conv1x1_cat_dgrad": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "vf_conv1x1_cat_wgrad": [_P, _P, _I, _P, _P, _P, _L, _I, _I, _I, _I, _I, _P],
     "vf_gn_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "vf_rowsum": [_P, _P, _I, _I, _P],
     "vf_bias_grad": [_P, _P, _P, _I, _I, _I, _P],

@@ -67,6 +67,11 @@ struct ConvArgs {
     int S, Cin, Cout, CinP, CoutP;
     int ksplit;   // > 1: split the K (input-channel) loop over ksplit workgroups, partials go to ws
     float* ws;    // [ksplit][S][Cout][H*W] partial sums (small-batch / sampler regime)
+    // 1x1 convs on a never-materialised channel concatenation (decoder skip connections): input channels
+    // [0, C1) come from x, [C1, Cin) from x2 (x2 == null: plain); output channels [0, C1o) go to y, the rest to y2
+    const float* x2;
+    float* y2;
+    int C1, C1o;
 };
 
 // Global -> register load of one float4 of the input patch (zero outside the image / tensor).
@@ -164,6 +169,11 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
         const int pr = t1 % G::PH;
         const int t2 = t1 / G::PH;
         const int im = t2 % G::IM, ci = t2 / G::IM;
+        if (KS == 1 && a.x2) {                                    // concatenated input: chunk-uniform source
+            const bool second = c0 >= a.C1;
+            return load_patch4<G, MODE>(second ? a.x2 : a.x, a.S, second ? a.Cin - a.C1 : a.C1, s0 + im,
+                                        second ? c0 - a.C1 + ci : c0 + ci, r0, pr, q);
+        }
         return load_patch4<G, MODE>(a.x, a.S, a.Cin, s0 + im, c0 + ci, r0, pr, q);
     };
     auto store_x = [&](int e, const float4& v) {
@@ -321,7 +331,11 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
         const int pix = G::IM > 1 ? (p & (G::HW - 1)) : r0 * G::W + p;
         if (s >= a.S || j >= nco_here) continue;
         const int cob = co0 + j * TCO + cw * 32 + 4 * lh;
-        const size_t ob = ((size_t)s * a.Cout + cob) * G::HW + pix;
+        // split output (dgrad of a conv on concatenated inputs): whole 64-channel tiles go to y or to y2
+        const bool second = a.y2 && co0 + j * TCO >= a.C1o;
+        float* const yout = second ? a.y2 : a.y;
+        const size_t ob = second ? ((size_t)s * (a.Cout - a.C1o) + (cob - a.C1o)) * G::HW + pix
+                                 : ((size_t)s * (a.y2 ? a.C1o : a.Cout) + cob) * G::HW + pix;
         if (a.ksplit > 1) {            // raw partial sums; bias / residual are added by the reduce kernel
             float* wsp = a.ws + (size_t)split * a.S * a.Cout * G::HW;
 #pragma unroll
@@ -357,7 +371,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int dco = (r & 3) + 8 * (r >> 2);
-            if (cob + dco < a.Cout) a.y[ob + (size_t)dco * G::HW] = acc[j][nt][r] + add[r];
+            if (cob + dco < a.Cout) yout[ob + (size_t)dco * G::HW] = acc[j][nt][r] + add[r];
         }
     }
 #ifdef VF_CONV_STAMPS
@@ -382,6 +396,8 @@ struct WgradArgs {
     float* ws;       // [slab][tap][CoutP][CinQ]
     int S, Cin, Cout, CoutP, CinQ;   // CoutP multiple of 64, CinQ multiple of 32
     int ntiles, tiles_per_slice;
+    const float* x2;                 // 1x1 on a channel concatenation: input channels [C1, Cin) live here
+    int C1;
 };
 
 // BIG = true : 64 co x 64 ci tile, waves = 2 (co) x 2 (ci), ONE workgroup per CU with the whole
@@ -451,6 +467,11 @@ __global__ __launch_bounds__(256, BIG ? 1 : 2) void conv_wgrad_kernel(WgradArgs 
         const int pr = t1 % G::PH;
         const int t2 = t1 / G::PH;
         const int im = t2 % G::IM, ci = t2 / G::IM;
+        if (KS == 1 && a.x2) {                                    // concatenated input: tile-uniform source
+            const bool second = ci0 >= a.C1;
+            return load_patch4<G, MODE>(second ? a.x2 : a.x, a.S, second ? a.Cin - a.C1 : a.C1, s0 + im,
+                                        second ? ci0 - a.C1 + ci : ci0 + ci, r0, pr, q);
+        }
         return load_patch4<G, MODE>(a.x, a.S, a.Cin, s0 + im, ci0 + ci, r0, pr, q);
     };
     auto store_x = [&](int e, const float4& v) {
@@ -834,15 +855,20 @@ int vf_conv_pack_weights_multi(const void* desc, int nlayers, long total_blocks,
 // nearest-upsampled on the fly; 4: x = dY [S][Cin][H][W] of a stride-2 conv, y = dX [S][Cout][2H][2W] (w_packed =
 // the dgrad pack, no epilogue operands).
 // ws / ws_floats: optional split-K workspace (see vf_conv_fwd_ws_floats); NULL disables split-K.
-int vf_conv_fwd(const float* x, const float* w_packed, const float* bias, const float* view_bias,
-                const float* residual, float* y, float* ws, long ws_floats, int S, int Cin, int Cout, int H,
-                int W, int KS, int mode, void* stream) {
+static int conv_fwd_impl(const float* x, const float* x2, int C1, const float* w_packed, const float* bias,
+                         const float* view_bias, const float* residual, float* y, float* y2, int C1o, float* ws,
+                         long ws_floats, int S, int Cin, int Cout, int H, int W, int KS, int mode, void* stream) {
     if (S <= 0) return 0;
     const int lw = ilog2_exact(W);
     if (H != W || lw < 3 || lw > 7 || (KS != 1 && KS != 3)) return (int)hipErrorInvalidValue;
     if (KS == 1 && mode != 0) return (int)hipErrorInvalidValue;
+    if ((x2 || y2) && KS != 1) return (int)hipErrorInvalidValue;
+    if (x2 && (C1 <= 0 || C1 >= Cin || C1 % 32 != 0)) return (int)hipErrorInvalidValue;     // chunk-aligned split
+    if (y2 && (C1o <= 0 || C1o >= Cout || C1o % TCO != 0)) return (int)hipErrorInvalidValue; // tile-aligned split
     ConvArgs a;
     a.x = x; a.w = w_packed; a.bias = bias; a.vbias = view_bias; a.res = residual; a.y = y;
+    a.x2 = x2; a.C1 = C1; a.y2 = y2; a.C1o = C1o;
+    if (y2) ws = nullptr;                                 // (the split-K reduce writes one destination)
     a.S = S; a.Cin = Cin; a.Cout = Cout;
     a.CinP = round_up(Cin, KS == 3 ? 8 : 32);
     a.CoutP = round_up(Cout, TCO);
@@ -858,6 +884,29 @@ int vf_conv_fwd(const float* x, const float* w_packed, const float* bias, const 
     VF_CASE(1, 3, 0) VF_CASE(1, 4, 0) VF_CASE(1, 5, 0) VF_CASE(1, 6, 0) VF_CASE(1, 7, 0)
 #undef VF_CASE
     return (int)hipErrorInvalidValue;
+}
+
+int vf_conv_fwd(const float* x, const float* w_packed, const float* bias, const float* view_bias,
+                const float* residual, float* y, float* ws, long ws_floats, int S, int Cin, int Cout, int H,
+                int W, int KS, int mode, void* stream) {
+    return conv_fwd_impl(x, nullptr, Cin, w_packed, bias, view_bias, residual, y, nullptr, Cout, ws, ws_floats, S, Cin,
+                         Cout, H, W, KS, mode, stream);
+}
+
+// 1x1 conv whose input is the never-materialised channel concatenation [x1 (C1 channels) | x2 (Cin - C1)]
+// (decoder skip connections, reference unet.py:134 + 238): forward, dgrad (two destinations) and wgrad.
+// C1 must be a multiple of 64.
+int vf_conv1x1_cat_fwd(const float* x1, const float* x2, int C1, const float* w_packed, const float* bias, float* y,
+                       float* ws, long ws_floats, int S, int Cin, int Cout, int H, int W, void* stream) {
+    return conv_fwd_impl(x1, x2, C1, w_packed, bias, nullptr, nullptr, y, nullptr, Cout, ws, ws_floats, S, Cin, Cout, H, W,
+                         1, 0, stream);
+}
+
+// dx1 [S][C1][H][W], dx2 [S][Cin-C1][H][W] from dy [S][Cout][H][W]; w_packed_bwd = the dgrad pack of the layer
+int vf_conv1x1_cat_dgrad(const float* dy, const float* w_packed_bwd, float* dx1, float* dx2, int C1, int S, int Cin,
+                         int Cout, int H, int W, void* stream) {
+    return conv_fwd_impl(dy, nullptr, Cout, w_packed_bwd, nullptr, nullptr, nullptr, dx1, dx2, C1, nullptr, 0, S, Cout, Cin,
+                         H, W, 1, 0, stream);
 }
 
 // Workspace floats vf_conv_fwd wants for its split-K path at this shape (0: no split-K, the
@@ -886,14 +935,15 @@ long vf_conv_wgrad_ws_floats(int S, int Cin, int Cout, int H, int W, int KS) {
 
 // dw[Cout][Cin][KS][KS] = sum_{s,p} dy[s][co][p] * x_as_seen_by_the_conv[s][ci][p (+) tap]
 // (H, W = OUTPUT size = dy size; mode as in vf_conv_fwd, 0..2).
-int vf_conv_wgrad(const float* x, const float* dy, float* dw, float* ws, long ws_floats, int S, int Cin,
-                  int Cout, int H, int W, int KS, int mode, void* stream) {
+static int conv_wgrad_impl(const float* x, const float* x2, int C1, const float* dy, float* dw, float* ws,
+                           long ws_floats, int S, int Cin, int Cout, int H, int W, int KS, int mode, void* stream) {
     if (S <= 0) return 0;
     const int lw = ilog2_exact(W);
     if (H != W || lw < 3 || lw > 7 || (KS != 1 && KS != 3)) return (int)hipErrorInvalidValue;
     if (KS == 1 && mode != 0) return (int)hipErrorInvalidValue;
+    if (x2 && (KS != 1 || C1 <= 0 || C1 >= Cin || C1 % 64 != 0)) return (int)hipErrorInvalidValue;
     WgradArgs a;
-    a.x = x; a.dy = dy; a.ws = ws; a.S = S; a.Cin = Cin; a.Cout = Cout;
+    a.x = x; a.x2 = x2; a.C1 = C1; a.dy = dy; a.ws = ws; a.S = S; a.Cin = Cin; a.Cout = Cout;
     a.CoutP = round_up(Cout, TCO);
     a.CinQ = round_up(Cin, 32);
     hipStream_t st = (hipStream_t)stream;
@@ -905,6 +955,16 @@ int vf_conv_wgrad(const float* x, const float* dy, float* dw, float* ws, long ws
     VF_CASE(1, 3, 0) VF_CASE(1, 4, 0) VF_CASE(1, 5, 0) VF_CASE(1, 6, 0) VF_CASE(1, 7, 0)
 #undef VF_CASE
     return (int)hipErrorInvalidValue;
+}
+
+int vf_conv_wgrad(const float* x, const float* dy, float* dw, float* ws, long ws_floats, int S, int Cin,
+                  int Cout, int H, int W, int KS, int mode, void* stream) {
+    return conv_wgrad_impl(x, nullptr, Cin, dy, dw, ws, ws_floats, S, Cin, Cout, H, W, KS, mode, stream);
+}
+
+int vf_conv1x1_cat_wgrad(const float* x1, const float* x2, int C1, const float* dy, float* dw, float* ws,
+                         long ws_floats, int S, int Cin, int Cout, int H, int W, void* stream) {
+    return conv_wgrad_impl(x1, x2, C1, dy, dw, ws, ws_floats, S, Cin, Cout, H, W, 1, 0, stream);
 }
 
 int vf_sumpool2(const float* x, float* y, long n_out, int Wo, void* stream) {

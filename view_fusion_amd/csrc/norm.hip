@@ -11,8 +11,17 @@
 
 namespace {
 
+// "cat" inputs: the normalised tensor is the channel concatenation [x1 (C1 channels) | x2 (C - C1)] of two
+// contiguous NCHW tensors (the decoder's skip connections, reference unet.py:134) that is never materialised.
+// float4 index i4 of group (s, g) -> its address in whichever tensor holds that channel.
+__device__ __forceinline__ const float4* cat_ptr(const float* x1, const float* x2, int C1, int C, int s, int c,
+                                                 int HW) {
+    return reinterpret_cast<const float4*>(c < C1 ? x1 + ((size_t)s * C1 + c) * HW
+                                                  : x2 + ((size_t)s * (C - C1) + (c - C1)) * HW);
+}
+
 template <int NV, int NT>
-__global__ __launch_bounds__(NT) void gn_fwd_kernel(const float* __restrict__ x,
+__global__ __launch_bounds__(NT) void gn_fwd_kernel(const float* __restrict__ x, const float* __restrict__ x2, int C1,
                                                     const float* __restrict__ gamma,
                                                     const float* __restrict__ beta,
                                                     float* __restrict__ y, float* __restrict__ mean_out,
@@ -32,8 +41,16 @@ __global__ __launch_bounds__(NT) void gn_fwd_kernel(const float* __restrict__ x,
     // iteration, which serialises the round trips.  Out-of-range slots are zeroed by a select afterwards.
     float4 v[NV];
     float gam[NV], bet[NV];
+    if (x2) {              // concatenated input: per-access source tensor
 #pragma unroll
-    for (int i = 0; i < NV; ++i) v[i] = x4[min((int)threadIdx.x + i * NT, n4 - 1)];
+        for (int i = 0; i < NV; ++i) {
+            const int idc = min((int)threadIdx.x + i * NT, n4 - 1), hw4 = HW >> 2;
+            v[i] = cat_ptr(x, x2, C1, C, s, g * cpg + idc / hw4, HW)[idc % hw4];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] = x4[min((int)threadIdx.x + i * NT, n4 - 1)];
+    }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int c = g * cpg + (min((int)threadIdx.x + i * NT, n4 - 1) * 4) / HW;
@@ -183,12 +200,15 @@ __global__ __launch_bounds__(256) void gn_bwd_dx_kernel(const float* __restrict_
 // SEG = lanes that share a channel in one 64-lane access: 64 when a channel row has >= 64 float4 (HW >= 256),
 // 16 on 8x8 maps (HW = 64: four channels per access, reduced per 16-lane segment).
 template <int NV, int NT, int SEG = 64>
-__global__ __launch_bounds__(NT) void gn_bwd_fused_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+__global__ __launch_bounds__(NT) void gn_bwd_fused_kernel(const float* __restrict__ x, const float* __restrict__ x2,
+                                                          int C1, const float* __restrict__ dy,
                                                           const float* __restrict__ gamma,
                                                           const float* __restrict__ beta,
                                                           const float* __restrict__ mean,
                                                           const float* __restrict__ rstd,
-                                                          const float* __restrict__ addend, float* __restrict__ dx,
+                                                          const float* __restrict__ addend,
+                                                          const float* __restrict__ addend2, float* __restrict__ dx,
+                                                          float* __restrict__ dx2,
                                                           float* __restrict__ dgamma_part,
                                                           float* __restrict__ dbeta_part,
                                                           float* __restrict__ dx_rowsum, int C, int HW, int cpg,
@@ -211,11 +231,20 @@ __global__ __launch_bounds__(NT) void gn_bwd_fused_kernel(const float* __restric
     // unconditional loads on clamped indices, all issued before the first use (see gn_fwd_kernel)
     float4 xv[NV], dv[NV];
     float gam[NV], bet[NV];
+    if (x2) {              // concatenated input (see cat_ptr): per-access source tensor
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int idc = min((int)threadIdx.x + i * NT, n4 - 1);
-        xv[i] = x4[idc];
-        dv[i] = d4[idc];
+        for (int i = 0; i < NV; ++i) {
+            const int idc = min((int)threadIdx.x + i * NT, n4 - 1);
+            xv[i] = cat_ptr(x, x2, C1, C, s, g * cpg + idc / hw4, HW)[idc % hw4];
+            dv[i] = d4[idc];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idc = min((int)threadIdx.x + i * NT, n4 - 1);
+            xv[i] = x4[idc];
+            dv[i] = d4[idc];
+        }
     }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -293,6 +322,24 @@ __global__ __launch_bounds__(NT) void gn_bwd_fused_kernel(const float* __restric
         dv[i].y = r * (dv[i].y * ga - (s1 + xv[i].y * s2));
         dv[i].z = r * (dv[i].z * ga - (s1 + xv[i].z * s2));
         dv[i].w = r * (dv[i].w * ga - (s1 + xv[i].w * s2));
+    }
+    if (x2) {              // cat: the second-consumer gradients and dx live in two tensors like the input
+        if (addend) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int idc = min((int)threadIdx.x + i * NT, n4 - 1);
+                xv[i] = cat_ptr(addend, addend2, C1, C, s, g * cpg + idc / hw4, HW)[idc % hw4];
+            }
+#pragma unroll
+            for (int i = 0; i < NV; ++i) { dv[i].x += xv[i].x; dv[i].y += xv[i].y; dv[i].z += xv[i].z; dv[i].w += xv[i].w; }
+        }
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = threadIdx.x + i * NT;
+            if (idx < n4)
+                const_cast<float4*>(cat_ptr(dx, dx2, C1, C, s, g * cpg + idx / hw4, HW))[idx % hw4] = dv[i];
+        }
+        return;
     }
     if (a4) {
 #pragma unroll
@@ -410,9 +457,9 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ p
 }
 
 template <int NV, int NT>
-int launch_gn_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
-                  int S, int C, int HW, int cpg, float eps, int silu, hipStream_t st) {
-    hipLaunchKernelGGL((gn_fwd_kernel<NV, NT>), dim3(S * (C / cpg)), dim3(NT), 0, st, x, gamma, beta, y, mean,
+int launch_gn_fwd(const float* x, const float* x2, int C1, const float* gamma, const float* beta, float* y, float* mean,
+                  float* rstd, int S, int C, int HW, int cpg, float eps, int silu, hipStream_t st) {
+    hipLaunchKernelGGL((gn_fwd_kernel<NV, NT>), dim3(S * (C / cpg)), dim3(NT), 0, st, x, x2, C1, gamma, beta, y, mean,
                        rstd, C, HW, cpg, eps, silu);
     VF_RETURN_LAST_ERROR();
 }
@@ -421,14 +468,14 @@ int launch_gn_fwd(const float* x, const float* gamma, const float* beta, float* 
 
 extern "C" {
 
-int vf_gn_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, int S,
-              int C, int HW, int groups, float eps, int silu, void* stream) {
+int vf_gn_cat_fwd(const float* x, const float* x2, int C1, const float* gamma, const float* beta, float* y, float* mean,
+                  float* rstd, int S, int C, int HW, int groups, float eps, int silu, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (S <= 0) return 0;
-    if (C % groups != 0 || (HW & 3)) return (int)hipErrorInvalidValue;
+    if (C % groups != 0 || (HW & 3) || (x2 && (C1 <= 0 || C1 >= C))) return (int)hipErrorInvalidValue;
     const int cpg = C / groups;
     const long n4 = (long)cpg * HW / 4;
-#define VF_GN(NV, NT) return launch_gn_fwd<NV, NT>(x, gamma, beta, y, mean, rstd, S, C, HW, cpg, eps, silu, st)
+#define VF_GN(NV, NT) return launch_gn_fwd<NV, NT>(x, x2, C1, gamma, beta, y, mean, rstd, S, C, HW, cpg, eps, silu, st)
     if (n4 <= 64) VF_GN(1, 64);
     if (n4 <= 256) VF_GN(1, 256);
     if (n4 <= 512) VF_GN(2, 256);
@@ -444,6 +491,11 @@ int vf_gn_fwd(const float* x, const float* gamma, const float* beta, float* y, f
     return (int)hipErrorInvalidValue;
 }
 
+int vf_gn_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, int S,
+              int C, int HW, int groups, float eps, int silu, void* stream) {
+    return vf_gn_cat_fwd(x, nullptr, C, gamma, beta, y, mean, rstd, S, C, HW, groups, eps, silu, stream);
+}
+
 // 1 when vf_gn_bwd fills `dx_rowsum` at this shape (the single-pass kernel; the two-kernel path does not)
 int vf_gn_bwd_emits_rowsum(int C, int HW, int groups) {
     if (groups <= 0 || C % groups != 0 || (HW & 3)) return 0;
@@ -451,20 +503,23 @@ int vf_gn_bwd_emits_rowsum(int C, int HW, int groups) {
     return ((HW >= 256 && n4g <= 8192) || (HW == 64 && n4g <= 1024)) ? 1 : 0;
 }
 
-int vf_gn_bwd(const float* x, const float* gamma, const float* beta, const float* mean, const float* rstd,
-              const float* dy, const float* addend, float* dx, float* dgamma_part, float* dbeta_part,
-              float* dx_rowsum, int S, int C, int HW, int groups, int silu, void* stream) {
+int vf_gn_cat_bwd(const float* x, const float* x2, int C1, const float* gamma, const float* beta, const float* mean,
+                  const float* rstd, const float* dy, const float* addend, const float* addend2, float* dx, float* dx2,
+                  float* dgamma_part, float* dbeta_part, float* dx_rowsum, int S, int C, int HW, int groups, int silu,
+                  void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (S <= 0) return 0;
     if (C % groups != 0 || (HW & 3)) return (int)hipErrorInvalidValue;
+    if (x2 && (C1 <= 0 || C1 >= C || !dx2 || (addend && !addend2) || !vf_gn_bwd_emits_rowsum(C, HW, groups)))
+        return (int)hipErrorInvalidValue;                // cat inputs: single-pass kernels only
     const int cpg = C / groups;
     const int rows = S * C;
     const long n4g = (long)cpg * HW / 4;
     if (HW == 64 && n4g <= 1024) {       // 8x8 maps: 16-lane channel segments
 #define VF_GNB16(NV)                                                                                       \
     {                                                                                                      \
-        hipLaunchKernelGGL((gn_bwd_fused_kernel<NV, 256, 16>), dim3(S * groups), dim3(256), 4 * cpg * 3 * 4, st, x, dy, \
-                           gamma, beta, mean, rstd, addend, dx, dgamma_part, dbeta_part, dx_rowsum, C, HW, cpg, silu); \
+        hipLaunchKernelGGL((gn_bwd_fused_kernel<NV, 256, 16>), dim3(S * groups), dim3(256), 4 * cpg * 3 * 4, st, x, x2, C1, dy, \
+                           gamma, beta, mean, rstd, addend, addend2, dx, dx2, dgamma_part, dbeta_part, dx_rowsum, C, HW, cpg, silu); \
         VF_RETURN_LAST_ERROR();                                                                            \
     }
         if (n4g <= 256) VF_GNB16(1)
@@ -476,8 +531,8 @@ int vf_gn_bwd(const float* x, const float* gamma, const float* beta, const float
 #define VF_GNB(NV, NT)                                                                                     \
     {                                                                                                      \
         hipLaunchKernelGGL((gn_bwd_fused_kernel<NV, NT>), dim3(S * groups), dim3(NT), (NT / 64) * cpg * 3 * 4, st, \
-                           x, dy, gamma, beta, mean, rstd, addend, dx, dgamma_part, dbeta_part, dx_rowsum, C, HW, cpg, \
-                           silu);                                                                          \
+                           x, x2, C1, dy, gamma, beta, mean, rstd, addend, addend2, dx, dx2, dgamma_part, dbeta_part, \
+                           dx_rowsum, C, HW, cpg, silu);                                                   \
         VF_RETURN_LAST_ERROR();                                                                            \
     }
         if (n4g <= 256) VF_GNB(1, 256)
@@ -502,6 +557,13 @@ int vf_gn_bwd(const float* x, const float* gamma, const float* beta, const float
                            (const float4*)addend, t4);
     }
     VF_RETURN_LAST_ERROR();
+}
+
+int vf_gn_bwd(const float* x, const float* gamma, const float* beta, const float* mean, const float* rstd,
+              const float* dy, const float* addend, float* dx, float* dgamma_part, float* dbeta_part,
+              float* dx_rowsum, int S, int C, int HW, int groups, int silu, void* stream) {
+    return vf_gn_cat_bwd(x, nullptr, C, gamma, beta, mean, rstd, dy, addend, nullptr, dx, nullptr, dgamma_part,
+                         dbeta_part, dx_rowsum, S, C, HW, groups, silu, stream);
 }
 
 int vf_rowsum(const float* x, float* out, int rows, int len, void* stream) {

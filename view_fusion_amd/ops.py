@@ -154,6 +154,56 @@ class _GroupNormSkipFn(torch.autograd.Function):
         return (*_gn_backward(ctx, dy, None if dskip is None else _c(dskip)), None, None)
 
 
+class _GroupNormCatSkipFn(torch.autograd.Function):
+    """GroupNorm over the channel concatenation [x1 | x2] that is never materialised (decoder skip connections,
+    reference unet.py:134): returns (GN(cat), x1, x2); the gradients of the second consumers of x1 / x2 (the
+    residual 1x1 conv) are added inside the backward kernel, which writes dx1 and dx2 separately."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, gamma, beta, groups, silu):
+        _check(x1, x2, gamma, beta)
+        S, C1, H, W = x1.shape
+        C = C1 + x2.shape[1]
+        y = torch.empty(S, C, H, W, device=x1.device, dtype=torch.float32)
+        mean = torch.empty(S * groups, device=x1.device, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        _lib.call("vf_gn_cat_fwd", _ptr(x1), _ptr(x2), C1, _ptr(gamma), _ptr(beta), _ptr(y), _ptr(mean), _ptr(rstd), S,
+                  C, H * W, groups, 1e-5, int(silu), _stream())
+        ctx.save_for_backward(x1, x2, gamma, beta, mean, rstd)
+        ctx.groups, ctx.silu = groups, int(silu)
+        return y, x1.view_as(x1), x2.view_as(x2)
+
+    @staticmethod
+    def backward(ctx, dy, d1, d2):
+        x1, x2, gamma, beta, mean, rstd = ctx.saved_tensors
+        dy = _c(dy)
+        S, C1, H, W = x1.shape
+        C = C1 + x2.shape[1]
+        if (d1 is None) != (d2 is None):          # one second consumer only: give the other a zero gradient
+            d1 = torch.zeros_like(x1) if d1 is None else d1
+            d2 = torch.zeros_like(x2) if d2 is None else d2
+        d1 = None if d1 is None else _c(d1)
+        d2 = None if d2 is None else _c(d2)
+        dx1, dx2 = torch.empty_like(x1), torch.empty_like(x2)
+        parts = torch.empty(2, S, C, device=x1.device, dtype=torch.float32)
+        _lib.call("vf_gn_cat_bwd", _ptr(x1), _ptr(x2), C1, _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd), _ptr(dy),
+                  _ptr(d1), _ptr(d2), _ptr(dx1), _ptr(dx2), _ptr(parts[0]), _ptr(parts[1]), None, S, C, H * W,
+                  ctx.groups, ctx.silu, _stream())
+        dgb = torch.empty(2, C, device=x1.device, dtype=torch.float32)
+        _lib.call("vf_colsum", _ptr(parts), _ptr(dgb), 2, S, C, _stream())
+        return dx1, dx2, dgb[0], dgb[1], None, None
+
+
+def cat_fusable(C1, C, HW, groups):
+    """The concat-free decoder path needs the single-pass GroupNorm backward and 64-aligned split points."""
+    return C1 % 64 == 0 and bool(_lib.load().vf_gn_bwd_emits_rowsum(C, HW, groups))
+
+
+def group_norm_cat_skip(x1, x2, weight, bias, groups, silu):
+    """-> (GroupNorm(cat(x1, x2)), x1', x2') without building the concatenation; see _GroupNormCatSkipFn."""
+    return _GroupNormCatSkipFn.apply(x1, x2, weight, bias, groups, silu)
+
+
 def group_norm(x, weight, bias, groups, silu):
     """GroupNorm(groups, C, eps=1e-5) [+ x*sigmoid(x)] on (S,C,H,W)."""
     return _GroupNormFn.apply(x, weight, bias, groups, silu)
@@ -431,6 +481,61 @@ class _Conv2dFn(torch.autograd.Function):
         if hr and ctx.needs_input_grad[4]:
             dres = dy
         return dx, dw, db, dvb, dres, None, None, None
+
+
+class _Conv1x1CatFn(torch.autograd.Function):
+    """1x1 conv (bias only) on the never-materialised channel concatenation [x1 | x2]: the residual conv of the
+    decoder blocks (reference unet.py:134, 238)."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, weight, bias, layer, training):
+        _check(x1, x2, bias)
+        S, C1, H, W = x1.shape
+        Cout, Cin = weight.shape[0], weight.shape[1]
+        y = torch.empty(S, Cout, H, W, device=x1.device, dtype=torch.float32)
+        wf, wb = _packed(layer, force=training)
+        ws, nws = _conv_ws(x1.device, S, Cin, Cout, H, W, 1)
+        _launch("conv_fwd", 2.0 * S * Cout * Cin * H * W, "vf_conv1x1_cat_fwd", _ptr(x1), _ptr(x2), C1, _ptr(wf),
+                _ptr(bias), _ptr(y), _ptr(ws), nws, S, Cin, Cout, H, W, _stream(), tag=(Cin, Cout, H, 1, 0))
+        ctx.save_for_backward(x1, x2)
+        ctx.wb, ctx.dims, ctx.has_bias = wb, (Cin, Cout), bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x1, x2 = ctx.saved_tensors
+        dy = _c(dy)
+        S, C1, H, W = x1.shape
+        Cin, Cout = ctx.dims
+        st = _stream()
+        flops, tag = 2.0 * S * Cout * Cin * H * W, (Cin, Cout, H, 1, 0)
+        dx1 = dx2 = dw = db = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            dx1, dx2 = torch.empty_like(x1), torch.empty_like(x2)
+            _launch("conv_dgrad", flops, "vf_conv1x1_cat_dgrad", _ptr(dy), _ptr(ctx.wb), _ptr(dx1), _ptr(dx2), C1, S,
+                    Cin, Cout, H, W, st, tag=tag)
+        if ctx.needs_input_grad[2]:
+            ws = _workspace(x1.device, _lib.load().vf_conv_wgrad_ws_floats(S, Cin, Cout, H, W, 1))
+            dw = torch.empty(Cout, Cin, 1, 1, device=x1.device, dtype=torch.float32)
+            _launch("conv_wgrad", flops, "vf_conv1x1_cat_wgrad", _ptr(x1), _ptr(x2), C1, _ptr(dy), _ptr(dw), _ptr(ws),
+                    ws.numel(), S, Cin, Cout, H, W, st, tag=tag)
+        if ctx.has_bias and ctx.needs_input_grad[3]:
+            hit = _rowsum_get(dy)                     # the 3x3 conv this output is added to has summed this dY
+            db = hit[2] if hit is not None else None
+            if db is None:
+                dvb = hit[1] if hit is not None else None
+                if dvb is None:
+                    dvb = torch.empty(S, Cout, device=x1.device, dtype=torch.float32)
+                    _lib.call("vf_rowsum", _ptr(dy), _ptr(dvb), S * Cout, H * W, st)
+                db = torch.empty(Cout, device=x1.device, dtype=torch.float32)
+                _lib.call("vf_colsum", _ptr(dvb), _ptr(db), 1, S, Cout, st)
+        return dx1, dx2, dw, db, None, None
+
+
+def conv1x1_cat(x1, x2, layer):
+    """layer(cat(x1, x2)) for a 1x1 `layer` with bias, without building the concatenation."""
+    training = torch.is_grad_enabled() and layer.weight.requires_grad
+    return _Conv1x1CatFn.apply(x1, x2, layer.weight, layer.bias, layer, training)
 
 
 def conv2d(x, layer, view_bias=None, residual=None, mode="same"):

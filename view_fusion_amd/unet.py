@@ -44,11 +44,22 @@ class _ResBlock(nn.Module):
         self.res_conv = nn.Conv2d(cin, cout, 1) if cin != cout else nn.Identity()
         self.groups = groups
 
-    def forward(self, x, e):
+    def forward(self, x, e, skip=None):
         """e = this block's FeatureWiseAffine Linear(emb), (S,Cout): all blocks' are computed in one grouped
-        launch by UNet.forward."""
+        launch by UNet.forward.  skip (decoder blocks): the encoder feature map that the reference concatenates
+        to x (unet.py:134); when the shapes allow, the concatenation is never built -- the first GroupNorm and the
+        residual 1x1 conv read both tensors."""
         from . import ops
         b1, b2 = self.block1["block"], self.block2["block"]
+        if skip is not None:
+            C1, C = x.shape[1], x.shape[1] + skip.shape[1]
+            if not (isinstance(self.res_conv, nn.Conv2d) and ops.cat_fusable(C1, C, x.shape[2] * x.shape[3], self.groups)):
+                x, skip = ops.concat_channels(x, skip), None
+        if skip is not None:
+            a, x1, x2 = ops.group_norm_cat_skip(x, skip, b1["0"].weight, b1["0"].bias, self.groups, silu=True)
+            h = ops.conv2d(a, b1["3"], view_bias=e)
+            a = ops.group_norm(h, b2["0"].weight, b2["0"].bias, self.groups, silu=True)
+            return ops.conv2d(a, b2["3"], residual=ops.conv1x1_cat(x1, x2, self.res_conv))
         # x feeds both the first GroupNorm and the residual branch: the GN op hands x back so that
         # the residual gradient is summed inside its backward kernel
         a, xs = ops.group_norm_skip(x, b1["0"].weight, b1["0"].bias, self.groups, silu=True)
@@ -82,8 +93,8 @@ class _ResAttnBlock(nn.Module):
         if with_attn:
             self.attn = _SelfAttention(cout, groups)
 
-    def forward(self, x, e):
-        x = self.res_block(x, e)
+    def forward(self, x, e, skip=None):
+        x = self.res_block(x, e, skip)
         return self.attn(x) if self.with_attn else x
 
 
@@ -212,7 +223,7 @@ class UNet(nn.Module):
             x = layer(x, next(es))
         for layer in self.ups:
             if isinstance(layer, _ResAttnBlock):
-                x = layer(ops.concat_channels(x, feats.pop()), next(es))
+                x = layer(x, next(es), feats.pop())
             else:
                 x = layer(x)
         fc = self.final_conv["block"]
