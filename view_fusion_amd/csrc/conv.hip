@@ -621,6 +621,141 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         dw[((size_t)co * Cin + ci) * NT + tap] = (red[0][ox] + red[1][ox]) + (red[2][ox] + red[3][ox]);
 }
 
+// ----------------------------------------------------------------------------------------------
+// 1x1 weight gradient: dW[co][ci] = sum_{s,p} dY[s][co][p] X[s][ci][p] -- a plain GEMM with K = S*H*W.
+// A 64x64 output tile loads 2 bytes per MAC-row and is bound by the per-CU load path (measured 45-69 TF,
+// ~4 TB/s of L2->LDS traffic); this kernel uses 128 co x 128 ci tiles (half the bytes per flop): four waves,
+// each 64 x 64 outputs = 2x2 MFMA blocks, K in steps of 64 pixels, both operands read from [channel][pixel]
+// LDS images with ds_read_b128 (k order inside 8 pixels: MFMA step e pairs pixel e | 4+e), next step's global
+// loads in registers while the current one is multiplied, two workgroups per CU.  Split-K over pixel steps into
+// slabs summed by wgrad_reduce_kernel in fixed order.  x may be the never-materialised concatenation [x | x2].
+struct Wgrad1Args {
+    const float* x;
+    const float* x2;
+    const float* dy;
+    float* ws;                    // [slab][CoutP][CinQ]
+    int S, Cin, Cout, CoutP, CinQ, C1, HW;
+    int nsteps, steps_per_slice;
+};
+
+// TM x TN = output channels x input channels per workgroup (64 or 128 each): waves 2 x 2, each (TM/2) x (TN/2)
+template <int TM, int TN>
+__global__ __launch_bounds__(256, 2) void conv1x1_wgrad_kernel(Wgrad1Args a) {
+    constexpr int KP = 64, RS = KP + 4;                 // pixels per step, LDS row stride (4*odd: conflict-free b128)
+    constexpr int NI = TM / 64, NJ = TN / 64;           // 32x32 MFMA blocks per wave
+    constexpr int ND = TM * 16 / 256, NX = TN * 16 / 256;   // float4 per thread per step (4 or 8 each)
+    __shared__ __attribute__((aligned(16))) float Dl[TM * RS];
+    __shared__ __attribute__((aligned(16))) float Xl[TN * RS];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int cw = wid & 1, ciw = wid >> 1, li = lane & 31, lh = lane >> 5;
+    const int co0 = blockIdx.x * TM, ci0 = blockIdx.y * TN;
+    const int t_begin = blockIdx.z * a.steps_per_slice;
+    const int t_end = min(a.nsteps, t_begin + a.steps_per_slice);
+    const int spv = a.HW / KP;                            // steps per view
+
+    // staging: row = channel, 16 float4 per row.  Rows beyond the tensor re-read its last channel: their
+    // products land in slab rows / columns that are never reduced.
+    const int srow = tid >> 4, sq = tid & 15;
+    size_t doff[8], xoff[8];
+    const float* xb[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = srow + 16 * i;
+        doff[i] = (size_t)min(co0 + row, a.Cout - 1) * a.HW + 4 * sq;
+        const int ci = min(ci0 + row, a.Cin - 1);
+        const bool second = a.x2 && ci >= a.C1;
+        xb[i] = second ? a.x2 : a.x;
+        xoff[i] = (size_t)(second ? ci - a.C1 : ci) * a.HW + 4 * sq;
+    }
+    const int xC = a.x2 ? a.C1 : a.Cin, x2C = a.Cin - a.C1;
+    float4 dr0, dr1, dr2, dr3, dr4, dr5, dr6, dr7, xr0, xr1, xr2, xr3, xr4, xr5, xr6, xr7;
+    dr0 = dr1 = dr2 = dr3 = dr4 = dr5 = dr6 = dr7 = xr0 = xr1 = xr2 = xr3 = xr4 = xr5 = xr6 = xr7 =
+        make_float4(0.f, 0.f, 0.f, 0.f);
+#define VF_W1_LD(I, T_)                                                                                   \
+    {                                                                                                     \
+        const int sv = (T_) / spv, p0 = ((T_) % spv) * KP;                                                 \
+        if constexpr ((I) < ND)                                                                           \
+            dr##I = *reinterpret_cast<const float4*>(a.dy + (size_t)sv * a.Cout * a.HW + doff[I] + p0);    \
+        if constexpr ((I) < NX)                                                                           \
+            xr##I = *reinterpret_cast<const float4*>(xb[I] + (size_t)sv * (xb[I] == a.x ? xC : x2C) * a.HW + xoff[I] + p0); \
+    }
+#define VF_W1_ST(I)                                                                                       \
+    {                                                                                                     \
+        if constexpr ((I) < ND) *reinterpret_cast<float4*>(Dl + (srow + 16 * (I)) * RS + 4 * sq) = dr##I;   \
+        if constexpr ((I) < NX) *reinterpret_cast<float4*>(Xl + (srow + 16 * (I)) * RS + 4 * sq) = xr##I;   \
+    }
+#define VF_W1_LOAD(T_) { VF_W1_LD(0, T_) VF_W1_LD(1, T_) VF_W1_LD(2, T_) VF_W1_LD(3, T_) VF_W1_LD(4, T_) VF_W1_LD(5, T_) VF_W1_LD(6, T_) VF_W1_LD(7, T_) }
+#define VF_W1_STORE() { VF_W1_ST(0) VF_W1_ST(1) VF_W1_ST(2) VF_W1_ST(3) VF_W1_ST(4) VF_W1_ST(5) VF_W1_ST(6) VF_W1_ST(7) }
+
+    f32x16 acc[NI][NJ];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x16){0};
+    const float* ab = Dl + (cw * (TM / 2) + li) * RS + 4 * lh;
+    const float* bb = Xl + (ciw * (TN / 2) + li) * RS + 4 * lh;
+
+    if (t_begin < t_end) {
+        VF_W1_LOAD(t_begin);
+        for (int t = t_begin; t < t_end; ++t) {
+            __syncthreads();
+            VF_W1_STORE();
+            __syncthreads();
+            VF_W1_LOAD(min(t + 1, t_end - 1));            // unconditional (clamped): the loads stay countable
+            float4 fa[NI], fb[NJ];
+#pragma unroll
+            for (int i = 0; i < NI; ++i) fa[i] = *reinterpret_cast<const float4*>(ab + 32 * i * RS);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) fb[j] = *reinterpret_cast<const float4*>(bb + 32 * j * RS);
+#pragma unroll
+            for (int g = 0; g < KP / 8; ++g) {
+                float4 na[NI], nb[NJ];
+#pragma unroll
+                for (int i = 0; i < NI; ++i) na[i] = fa[i];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) nb[j] = fb[j];
+                if (g + 1 < KP / 8) {
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) na[i] = *reinterpret_cast<const float4*>(ab + 32 * i * RS + 8 * (g + 1));
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) nb[j] = *reinterpret_cast<const float4*>(bb + 32 * j * RS + 8 * (g + 1));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < NI; ++i) fa[i] = na[i];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) fb[j] = nb[j];
+            }
+        }
+    }
+#undef VF_W1_LD
+#undef VF_W1_ST
+#undef VF_W1_LOAD
+#undef VF_W1_STORE
+    float* sb = a.ws + (size_t)blockIdx.z * a.CoutP * a.CinQ;
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int ci = ci0 + ciw * (TN / 2) + j * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + cw * (TM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                sb[(size_t)co * a.CinQ + ci] = acc[i][j][r];
+            }
+        }
+}
+
 // OIHW -> packed forward  [co tile][ci chunk][group][co 64][ci 8]   (M = Cout, K = Cin x taps)
 //      and packed backward [ci tile][co chunk][group][ci 64][co 8]   (dgrad: M = Cin, K = Cout x flipped taps)
 // group = tap for 3x3 (chunk = 8 channels), = 8-channel sub-chunk for 1x1 (chunk = 32 channels).
@@ -808,6 +943,10 @@ int launch_wgrad(WgradArgs a, float* dw, size_t ws_floats, hipStream_t st) {
     VF_RETURN_LAST_ERROR();
 }
 
+// 1x1 wgrad tile side for a channel count: 128 unless the padding to 128 costs more than 20 %
+inline int round_up(int v, int m);
+inline int wgrad1_tile(int C) { return 5 * ((C + 127) / 128 * 128) <= 6 * ((C + 63) / 64 * 64) ? 128 : 64; }
+
 inline int ilog2_exact(int v) {
     for (int l = 0; l < 31; ++l)
         if ((1 << l) == v) return l;
@@ -924,6 +1063,15 @@ long vf_conv_fwd_ws_floats(int S, int Cin, int Cout, int H, int W, int KS) {
 // Workspace floats needed by vf_conv_wgrad for the preferred split (a smaller workspace is
 // accepted down to 1 slab and just reduces the split-K factor).
 long vf_conv_wgrad_ws_floats(int S, int Cin, int Cout, int H, int W, int KS) {
+    if (KS == 1) {
+        const int tm = wgrad1_tile(Cout), tn = wgrad1_tile(Cin);
+        const long slab1 = (long)round_up(Cout, tm) * round_up(Cin, tn);
+        long z1 = WGRAD_TARGET_WGS / ((round_up(Cout, tm) / tm) * (round_up(Cin, tn) / tn));
+        const long nsteps = (long)S * (H * W / 64);
+        if (z1 > nsteps / 4) z1 = nsteps / 4;
+        if (z1 < 1) z1 = 1;
+        return z1 * slab1;
+    }
     const long slab = (long)KS * KS * round_up(Cout, TCO) * round_up(Cin, 32);
     const int nco = round_up(Cout, TCO) / TCO, nci = round_up(Cin, 32) / 32;
     long z = (WGRAD_TARGET_WGS + nco * nci - 1) / (nco * nci);
@@ -942,6 +1090,32 @@ static int conv_wgrad_impl(const float* x, const float* x2, int C1, const float*
     if (H != W || lw < 3 || lw > 7 || (KS != 1 && KS != 3)) return (int)hipErrorInvalidValue;
     if (KS == 1 && mode != 0) return (int)hipErrorInvalidValue;
     if (x2 && (KS != 1 || C1 <= 0 || C1 >= Cin || C1 % 64 != 0)) return (int)hipErrorInvalidValue;
+    if (KS == 1) {                                        // plain GEMM: the large-tile kernel
+        Wgrad1Args g;
+        g.x = x; g.x2 = x2; g.dy = dy; g.ws = ws; g.S = S; g.Cin = Cin; g.Cout = Cout; g.C1 = C1; g.HW = H * W;
+        const int tm = wgrad1_tile(Cout), tn = wgrad1_tile(Cin);
+        g.CoutP = round_up(Cout, tm); g.CinQ = round_up(Cin, tn);
+        g.nsteps = S * (H * W / 64);
+        const int nco = g.CoutP / tm, nci = g.CinQ / tn;
+        const size_t slab = (size_t)g.CoutP * g.CinQ;
+        int z = WGRAD_TARGET_WGS / (nco * nci);
+        if (z > g.nsteps / 4) z = g.nsteps / 4;           // >= 4 steps per slice: slab traffic vs fill on 8x8 maps
+        if (z < 1) z = 1;
+        if ((size_t)ws_floats < slab) return (int)hipErrorInvalidValue;
+        if ((size_t)z > (size_t)ws_floats / slab) z = (int)((size_t)ws_floats / slab);
+        g.steps_per_slice = (g.nsteps + z - 1) / z;
+        z = (g.nsteps + g.steps_per_slice - 1) / g.steps_per_slice;
+        hipStream_t st1 = (hipStream_t)stream;
+        const dim3 grid(nco, nci, z);
+        if (tm == 128 && tn == 128) hipLaunchKernelGGL((conv1x1_wgrad_kernel<128, 128>), grid, dim3(256), 0, st1, g);
+        else if (tm == 128) hipLaunchKernelGGL((conv1x1_wgrad_kernel<128, 64>), grid, dim3(256), 0, st1, g);
+        else if (tn == 128) hipLaunchKernelGGL((conv1x1_wgrad_kernel<64, 128>), grid, dim3(256), 0, st1, g);
+        else hipLaunchKernelGGL((conv1x1_wgrad_kernel<64, 64>), grid, dim3(256), 0, st1, g);
+        const int total = Cout * Cin;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 63) / 64), dim3(256), 0, st1, ws, dw, z, 1, Cout, Cin,
+                           g.CoutP, g.CinQ);
+        VF_RETURN_LAST_ERROR();
+    }
     WgradArgs a;
     a.x = x; a.x2 = x2; a.C1 = C1; a.dy = dy; a.ws = ws; a.S = S; a.Cin = Cin; a.Cout = Cout;
     a.CoutP = round_up(Cout, TCO);
@@ -952,7 +1126,6 @@ static int conv_wgrad_impl(const float* x, const float* x2, int C1, const float*
     VF_CASE(3, 3, 0) VF_CASE(3, 4, 0) VF_CASE(3, 5, 0) VF_CASE(3, 6, 0) VF_CASE(3, 7, 0)
     VF_CASE(3, 3, 1) VF_CASE(3, 4, 1) VF_CASE(3, 5, 1) VF_CASE(3, 6, 1)
     VF_CASE(3, 4, 2) VF_CASE(3, 5, 2) VF_CASE(3, 6, 2) VF_CASE(3, 7, 2)
-    VF_CASE(1, 3, 0) VF_CASE(1, 4, 0) VF_CASE(1, 5, 0) VF_CASE(1, 6, 0) VF_CASE(1, 7, 0)
 #undef VF_CASE
     return (int)hipErrorInvalidValue;
 }
