@@ -132,15 +132,20 @@ def test_small_train_step_vs_oracle(dev, winograd):
         ops.FORCE_WINOGRAD = False
 
 
-def _small_train_step(dev):
+def test_small_train_step_natural_policy(dev):
+    """Same check at S = 13 ragged views with the kernel-selection policy left alone: Winograd layers with every
+    tile K-split (fewer tiles than CUs), direct kernels on the 8x8 maps, concat-free decoder blocks."""
+    _small_train_step(dev, B=5, N=4, vc=[3, 1, 4, 2, 3], t=[1500, 3, 700, 1999, 42])
+
+
+def _small_train_step(dev, B=2, N=2, vc=(2, 1), t=(1500, 3)):
     from oracle import unet_ref, view_fusion_ref as vfr
     vf = make_vf(SMALL, SCHED_TRAIN, dev, True)
     g = torch.Generator().manual_seed(0)
-    B, N = 2, 2
     y_0, y_cond = torch.rand(B, 3, 64, 64, generator=g), torch.rand(B, N, 3, 64, 64, generator=g)
     angle = 2 * np.pi / 24 * torch.randint(0, 24, (B, 1), generator=g).float()
-    noise, t, u = torch.randn(B, 3, 64, 64, generator=g), torch.tensor([1500, 3]), torch.rand(B, 1, generator=g)
-    vc = torch.tensor([2, 1])
+    noise, t, u = torch.randn(B, 3, 64, 64, generator=g), torch.tensor(list(t)), torch.rand(B, 1, generator=g)
+    vc = torch.tensor(list(vc))
     loss = vf(y_cond=y_cond.to(dev), view_count=vc, angle=angle.to(dev), y_0=y_0.to(dev), noise=noise.to(dev),
               t=t.to(dev), u=u.to(dev))
     loss.backward()
