@@ -95,7 +95,8 @@ int vf_wino_conv_fwd(const float* x, const float* u_packed, const float* bias, c
  * slabs that are summed in a fixed order, then dW = G^T dU G */
 int vf_wino_wgrad_supported(int H, int W, int mode);
 long vf_wino_wgrad_ws_floats(int S, int Cin, int Cout, int H, int W);
-int vf_wino_wgrad(const float* x, const float* dy, float* dw_oihw, float* ws, long ws_floats, int S, int Cin,
+/* db (or NULL): also the bias gradient sum_{s,p} dY -- the kernel reads every dY tile anyway */
+int vf_wino_wgrad(const float* x, const float* dy, float* dw_oihw, float* db, float* ws, long ws_floats, int S, int Cin,
                   int Cout, int H, int W, int mode, void* stream);
 
 /* ---- grouped time-embedding affine: all FeatureWiseAffine Linear(K->C_g) layers of the UNet on the same

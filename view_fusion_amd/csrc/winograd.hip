@@ -635,6 +635,7 @@ struct WinoWgradArgs {
     const float* x;
     const float* dy;
     float* ws;                        // [slab][k 16][CoutP][CinQ]
+    float* bsum;                      // [slab][CoutP] per-slice sums of dY per output channel (bias gradient), or null
     int S, Cin, Cout, CoutP, CinQ;
     int nchunks, chunks_per_slice;
 };
@@ -736,7 +737,9 @@ __global__ __launch_bounds__(512, 2) void wino_wgrad_kernel(WinoWgradArgs a) {
             dy1 = *reinterpret_cast<const float2*>(g + W);
         }
     };
+    float bias_acc = 0.f;                              // sum of this thread's dY tiles (the bias gradient rides along)
     auto xform_dy = [&](int buf) {                     // dM = A dY A^T, A^T = [[1,1,1,0],[0,1,-1,-1]]
+        bias_acc += (dy0.x + dy0.y) + (dy1.x + dy1.y);
         const float r[4][2] = {{dy0.x, dy0.y}, {dy0.x + dy1.x, dy0.y + dy1.y}, {dy0.x - dy1.x, dy0.y - dy1.y},
                                {-dy1.x, -dy1.y}};
         float* mo = Ml + buf * MSZ + tch * GT + tsw;
@@ -827,6 +830,13 @@ __global__ __launch_bounds__(512, 2) void wino_wgrad_kernel(WinoWgradArgs a) {
 
     // partial dU of this slice: rows k = 8kh .. 8kh+7
     const int slab = blockIdx.z;
+    if (a.bsum && blockIdx.y == 0) {                   // bias gradient partial: the 8 tile lanes of a channel, fixed order
+        float b = bias_acc;
+        b += __shfl_xor(b, 1, 64);
+        b += __shfl_xor(b, 2, 64);
+        b += __shfl_xor(b, 4, 64);
+        if (tt == 0) a.bsum[(size_t)slab * a.CoutP + co0 + tch] = b;
+    }
     // (one 64-bit base per workgroup lane, 32-bit offsets inside the slab: 128 stores without 64-bit multiplies)
     const int ci = ci0 + ciw * 32 + li;
     if (ci < a.CinQ) {
@@ -872,7 +882,28 @@ __global__ __launch_bounds__(256) void wino_wgrad_slabsum_kernel(const float* __
 
 // dW[co][ci][p][q] = sum_{i,j} G[i][p] G[j][q] dU[4i+j][co][ci]
 __global__ __launch_bounds__(256) void wino_wgrad_finish_kernel(const float* __restrict__ du, float* __restrict__ dw,
-                                                                int Cout, int Cin, int CoutP, int CinQ) {
+                                                                int Cout, int Cin, int CoutP, int CinQ,
+                                                                const float* __restrict__ bsum, float* __restrict__ db,
+                                                                int nslab, int nmain) {
+    if ((int)blockIdx.x >= nmain) {      // trailing blocks: db[co] = sum over the slices' dY sums (64 channels x 4
+        __shared__ float red[4][64];     // slice groups per block, 8 loads in flight, fixed order)
+        const int cx = threadIdx.x & 63, g = threadIdx.x >> 6;
+        const int co = ((int)blockIdx.x - nmain) * 64 + cx;
+        float acc8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (co < Cout) {
+            for (int z = g; z < nslab; z += 32) {
+                float t[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) t[j] = bsum[(size_t)min(z + 4 * j, nslab - 1) * CoutP + co];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc8[j] += z + 4 * j < nslab ? t[j] : 0.f;
+            }
+        }
+        red[g][cx] = ((acc8[0] + acc8[1]) + (acc8[2] + acc8[3])) + ((acc8[4] + acc8[5]) + (acc8[6] + acc8[7]));
+        __syncthreads();
+        if (g == 0 && co < Cout) db[co] = (red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]);
+        return;
+    }
     const int idx = blockIdx.x * 256 + threadIdx.x;           // over (co, ci), ci fastest
     if (idx >= Cout * Cin) return;
     const int ci = idx % Cin, co = idx / Cin;
@@ -901,7 +932,7 @@ __global__ __launch_bounds__(256) void wino_wgrad_finish_kernel(const float* __r
 }
 
 template <int LOGW, int MODE>
-int launch_wino_wgrad(WinoWgradArgs a, float* dw, size_t ws_floats, hipStream_t st) {
+int launch_wino_wgrad(WinoWgradArgs a, float* dw, float* db, size_t ws_floats, hipStream_t st) {
     constexpr int W = 1 << LOGW;
     a.nchunks = a.S * ((W / 2) * (W / 2) / GT);
     const int nco = a.CoutP / 64, nci = (a.CinQ + 63) / 64;
@@ -909,20 +940,23 @@ int launch_wino_wgrad(WinoWgradArgs a, float* dw, size_t ws_floats, hipStream_t 
     int z = 256 / (nco * nci);
     if (z < 1) z = 1;
     if (z > a.nchunks) z = a.nchunks;
-    if (ws_floats < 2 * slab_floats) return (int)hipErrorInvalidValue;
-    const size_t zmax = ws_floats / slab_floats - 1;
+    if (ws_floats < 2 * slab_floats + 256 * (size_t)a.CoutP) return (int)hipErrorInvalidValue;
+    const size_t zmax = (ws_floats - 256 * (size_t)a.CoutP) / slab_floats - 1;
     if ((size_t)z > zmax) z = (int)zmax;
     a.chunks_per_slice = (a.nchunks + z - 1) / z;
     z = (a.nchunks + a.chunks_per_slice - 1) / a.chunks_per_slice;
-    hipLaunchKernelGGL((wino_wgrad_kernel<LOGW, MODE>), dim3(nco, nci, z), dim3(512), 0, st, a);
-    // the summed dU goes behind the slabs (vf_wino_wgrad_ws_floats reserves one extra slab)
+    // the summed dU goes behind the slabs (vf_wino_wgrad_ws_floats reserves one extra slab), the per-slice dY sums
+    // behind that
     float* du = a.ws + (size_t)z * slab_floats;
+    a.bsum = db ? du + slab_floats : nullptr;
+    hipLaunchKernelGGL((wino_wgrad_kernel<LOGW, MODE>), dim3(nco, nci, z), dim3(512), 0, st, a);
     const long kstride = (long)a.CoutP * a.CinQ;
     hipLaunchKernelGGL(wino_wgrad_slabsum_kernel, dim3((unsigned)(kstride / 64), 16), dim3(256), 0, st, a.ws, du, z,
                        kstride);
     const int total = a.Cout * a.Cin;
-    hipLaunchKernelGGL(wino_wgrad_finish_kernel, dim3((total + 255) / 256), dim3(256), 0, st, du, dw, a.Cout, a.Cin,
-                       a.CoutP, a.CinQ);
+    const int nmain = (total + 255) / 256, nbias = db ? (a.Cout + 63) / 64 : 0;
+    hipLaunchKernelGGL(wino_wgrad_finish_kernel, dim3(nmain + nbias), dim3(256), 0, st, du, dw, a.Cout, a.Cin, a.CoutP,
+                       a.CinQ, a.bsum, db, z, nmain);
     VF_RETURN_LAST_ERROR();
 }
 
@@ -938,7 +972,7 @@ long vf_wino_wgrad_ws_floats(int S, int Cin, int Cout, int H, int W) {
     if (z < 1) z = 1;
     const long nchunks = (long)S * (H / 2) * (W / 2) / GT;
     if (z > nchunks) z = nchunks;
-    return (z + 1) * slab;
+    return (z + 1) * slab + 256L * rup(Cout, 64);
 }
 
 int vf_wino_wgrad_supported(int H, int W, int mode) {
@@ -947,8 +981,9 @@ int vf_wino_wgrad_supported(int H, int W, int mode) {
 
 // dw[Cout][Cin][3][3] of a stride-1 3x3 conv (H = W = output size in {8, 16, 32, 64}; mode 2: x is stored at half
 // size and nearest-upsampled on read) via Winograd F(2x2,3x3)
-int vf_wino_wgrad(const float* x, const float* dy, float* dw, float* ws, long ws_floats, int S, int Cin, int Cout,
-                  int H, int W, int mode, void* stream) {
+// db (or NULL): also the bias gradient sum_{s,p} dY[s][co][p] -- the kernel reads every dY tile anyway
+int vf_wino_wgrad(const float* x, const float* dy, float* dw, float* db, float* ws, long ws_floats, int S, int Cin,
+                  int Cout, int H, int W, int mode, void* stream) {
     if (S <= 0) return 0;
     if (!vf_wino_wgrad_supported(H, W, mode)) return (int)hipErrorInvalidValue;
     WinoWgradArgs a;
@@ -956,8 +991,8 @@ int vf_wino_wgrad(const float* x, const float* dy, float* dw, float* ws, long ws
     a.CoutP = rup(Cout, 64); a.CinQ = rup(Cin, 32);
     hipStream_t st = (hipStream_t)stream;
 #define VF_WG(LW) \
-    return mode == 2 ? launch_wino_wgrad<LW, 2>(a, dw, (size_t)ws_floats, st) \
-                     : launch_wino_wgrad<LW, 0>(a, dw, (size_t)ws_floats, st)
+    return mode == 2 ? launch_wino_wgrad<LW, 2>(a, dw, db, (size_t)ws_floats, st) \
+                     : launch_wino_wgrad<LW, 0>(a, dw, db, (size_t)ws_floats, st)
     if (W == 8) VF_WG(3);
     if (W == 16) VF_WG(4);
     if (W == 32) VF_WG(5);

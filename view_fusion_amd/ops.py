@@ -443,24 +443,30 @@ class _Conv2dFn(torch.autograd.Function):
                         None, 0, S, Cout, Cin, H, W, KS, 0, st, tag=ctx.tag)
                 dx = torch.empty_like(x)
                 _lib.call("vf_sumpool2", _ptr(dup), _ptr(dx), dx.numel(), Wi, st)
+        hb, hv, hr = ctx.has
+        want_b, want_v = hb and ctx.needs_input_grad[2], hv and ctx.needs_input_grad[3]
+        hit = _rowsum_get(dy) if (want_b or want_v) else None
+        if hit is not None:
+            dvb, db = hit[1], hit[2]
         if ctx.needs_input_grad[1] and use_winograd_wgrad(S, Cin, Cout, H, W, KS, m):
             need = _lib.load().vf_wino_wgrad_ws_floats(S, Cin, Cout, H, W)
             ws = _workspace(x.device, need)
             dw = torch.empty(Cout, Cin, 3, 3, device=x.device, dtype=torch.float32)
-            _launch("conv_wgrad", ctx.flops, "vf_wino_wgrad", _ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), ws.numel(), S,
-                    Cin, Cout, H, W, m, st, tag=ctx.tag)
+            if want_b and not want_v and db is None and dvb is None:
+                # bias-only layer with no cached sums: the wgrad kernel reads every dY tile anyway
+                db = torch.empty(Cout, device=x.device, dtype=torch.float32)
+                db_here = db
+            else:
+                db_here = None
+            _launch("conv_wgrad", ctx.flops, "vf_wino_wgrad", _ptr(x), _ptr(dy), _ptr(dw), _ptr(db_here), _ptr(ws),
+                    ws.numel(), S, Cin, Cout, H, W, m, st, tag=ctx.tag)
         elif ctx.needs_input_grad[1]:
             need = _lib.load().vf_conv_wgrad_ws_floats(S, Cin, Cout, H, W, KS)
             ws = _workspace(x.device, need)
             dw = torch.empty(Cout, Cin, KS, KS, device=x.device, dtype=torch.float32)
             _launch("conv_wgrad", ctx.flops, "vf_conv_wgrad", _ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), ws.numel(), S,
                     Cin, Cout, H, W, KS, m, st, tag=ctx.tag)
-        hb, hv, hr = ctx.has
-        want_b, want_v = hb and ctx.needs_input_grad[2], hv and ctx.needs_input_grad[3]
         if want_b or want_v:
-            hit = _rowsum_get(dy)
-            db = hit[2] if hit is not None else None
-            dvb = hit[1] if hit is not None else None
             if (want_v and dvb is None) or (want_b and db is None and dvb is None):
                 if Cout >= 192 and db is None:   # one launch, one workgroup per channel (enough channels to fill the chip)
                     db = torch.empty(Cout, device=x.device, dtype=torch.float32) if want_b else None
