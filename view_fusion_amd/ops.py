@@ -452,8 +452,8 @@ class _Conv2dFn(torch.autograd.Function):
             need = _lib.load().vf_wino_wgrad_ws_floats(S, Cin, Cout, H, W)
             ws = _workspace(x.device, need)
             dw = torch.empty(Cout, Cin, 3, 3, device=x.device, dtype=torch.float32)
-            if want_b and not want_v and db is None and dvb is None:
-                # bias-only layer with no cached sums: the wgrad kernel reads every dY tile anyway
+            if want_b and db is None:
+                # the wgrad kernel reads every dY tile anyway: the bias gradient (sum over views and pixels) rides along
                 db = torch.empty(Cout, device=x.device, dtype=torch.float32)
                 db_here = db
             else:
@@ -468,10 +468,11 @@ class _Conv2dFn(torch.autograd.Function):
                     Cin, Cout, H, W, KS, m, st, tag=ctx.tag)
         if want_b or want_v:
             if (want_v and dvb is None) or (want_b and db is None and dvb is None):
-                if Cout >= 192 and db is None:   # one launch, one workgroup per channel (enough channels to fill the chip)
-                    db = torch.empty(Cout, device=x.device, dtype=torch.float32) if want_b else None
+                if Cout >= 192:                  # one launch, one workgroup per channel (enough channels to fill the chip)
+                    db_new = torch.empty(Cout, device=x.device, dtype=torch.float32) if (want_b and db is None) else None
                     dvb = torch.empty(S, Cout, device=x.device, dtype=torch.float32) if want_v else None
-                    _lib.call("vf_bias_grad", _ptr(dy), _ptr(db), _ptr(dvb), S, Cout, H * W, st)
+                    _lib.call("vf_bias_grad", _ptr(dy), _ptr(db_new), _ptr(dvb), S, Cout, H * W, st)
+                    db = db_new if db_new is not None else db
                 else:                            # few channels: wave-per-row partial sums, then the column sum
                     dvb = torch.empty(S, Cout, device=x.device, dtype=torch.float32)
                     _lib.call("vf_rowsum", _ptr(dy), _ptr(dvb), S * Cout, H * W, st)
