@@ -30,7 +30,8 @@ int vf_gn_bwd(const float* x, const float* gamma, const float* beta, const float
               float* dx_rowsum, int S, int C, int HW, int groups, int silu, void* stream);
 /* same on the never-materialised channel concatenation [x (C1 channels) | x2 (C - C1)] of two NCHW tensors
  * (decoder skip connections, unet.py:134); the second-consumer gradients and dx are split the same way.
- * x2 == NULL: plain.  Backward: single-pass shapes only (vf_gn_bwd_emits_rowsum). */
+ * x2 == NULL: plain input; then addend2 (or NULL) is a second full-size tensor added to dx (gradient of a third
+ * consumer of x).  Backward with x2: single-pass shapes only (vf_gn_bwd_emits_rowsum). */
 int vf_gn_cat_fwd(const float* x, const float* x2, int C1, const float* gamma, const float* beta, float* y, float* mean,
                   float* rstd, int S, int C, int HW, int groups, float eps, int silu, void* stream);
 int vf_gn_cat_bwd(const float* x, const float* x2, int C1, const float* gamma, const float* beta, const float* mean,

@@ -347,6 +347,13 @@ __global__ __launch_bounds__(NT) void gn_bwd_fused_kernel(const float* __restric
 #pragma unroll
         for (int i = 0; i < NV; ++i) { dv[i].x += xv[i].x; dv[i].y += xv[i].y; dv[i].z += xv[i].z; dv[i].w += xv[i].w; }
     }
+    if (addend2) {         // plain input: gradient of a third consumer of x (the decoder's skip connection)
+        const float4* b4 = reinterpret_cast<const float4*>(addend2 + base);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) xv[i] = b4[min((int)threadIdx.x + i * NT, n4 - 1)];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) { dv[i].x += xv[i].x; dv[i].y += xv[i].y; dv[i].z += xv[i].z; dv[i].w += xv[i].w; }
+    }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int idx = threadIdx.x + i * NT;
@@ -551,11 +558,13 @@ int vf_gn_cat_bwd(const float* x, const float* x2, int C1, const float* gamma, c
     if (chunks < 1) chunks = 1;
     hipLaunchKernelGGL(gn_bwd_dx_kernel, dim3(S * groups, chunks), dim3(256), 0, st, x, dy, gamma, beta, mean,
                        rstd, dbeta_part, dgamma_part, dx, C, HW, cpg, silu);
-    if (addend) {
-        const size_t t4 = (size_t)S * C * HW / 4;
+    const size_t t4 = (size_t)S * C * HW / 4;
+    if (addend)
         hipLaunchKernelGGL(add_inplace_kernel, dim3((unsigned)((t4 + 255) / 256)), dim3(256), 0, st, (float4*)dx,
                            (const float4*)addend, t4);
-    }
+    if (addend2)
+        hipLaunchKernelGGL(add_inplace_kernel, dim3((unsigned)((t4 + 255) / 256)), dim3(256), 0, st, (float4*)dx,
+                           (const float4*)addend2, t4);
     VF_RETURN_LAST_ERROR();
 }
 

@@ -107,7 +107,7 @@ def _rowsum_get(t):
     return hit
 
 
-def _gn_backward(ctx, dy, addend):
+def _gn_backward(ctx, dy, addend, addend2=None):
     x, gamma, beta, mean, rstd = ctx.saved_tensors
     dy = _c(dy)
     S, C, H, W = x.shape
@@ -116,8 +116,11 @@ def _gn_backward(ctx, dy, addend):
     rowsum = None
     if addend is None and ROWSUM_CACHE is not None and _lib.load().vf_gn_bwd_emits_rowsum(C, H * W, ctx.groups):
         rowsum = torch.empty(S, C, device=x.device, dtype=torch.float32)
-    _lib.call("vf_gn_bwd", _ptr(x), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd), _ptr(dy), _ptr(addend),
-              _ptr(dx), _ptr(parts[0]), _ptr(parts[1]), _ptr(rowsum), S, C, H * W, ctx.groups, ctx.silu, _stream())
+    if addend is None and addend2 is not None:
+        addend, addend2 = addend2, None
+    _lib.call("vf_gn_cat_bwd", _ptr(x), None, C, _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd), _ptr(dy), _ptr(addend),
+              _ptr(addend2), _ptr(dx), None, _ptr(parts[0]), _ptr(parts[1]), _ptr(rowsum), S, C, H * W, ctx.groups,
+              ctx.silu, _stream())
     if rowsum is not None:
         _rowsum_put(dx, rowsum, None)
     dgb = torch.empty(2, C, device=x.device, dtype=torch.float32)
@@ -139,19 +142,22 @@ class _GroupNormFn(torch.autograd.Function):
 
 
 class _GroupNormSkipFn(torch.autograd.Function):
-    """(GN(x), x): the second output is x itself for a residual / skip consumer, so that its
-    gradient is added inside the GroupNorm backward kernel instead of by a separate autograd add."""
+    """(GN(x), x, x): the extra outputs are x itself for a residual consumer and for the decoder's skip
+    connection, so that their gradients are added inside the GroupNorm backward kernel instead of by separate
+    autograd adds."""
 
     @staticmethod
     def forward(ctx, x, gamma, beta, groups, silu):
         y, mean, rstd = _gn_forward(x, gamma, beta, groups, silu)
         ctx.save_for_backward(x, gamma, beta, mean, rstd)
         ctx.groups, ctx.silu = groups, int(silu)
-        return y, x.view_as(x)
+        ctx.set_materialize_grads(False)          # an unused handle must not cost a zero tensor + an add
+        return y, x.view_as(x), x.view_as(x)
 
     @staticmethod
-    def backward(ctx, dy, dskip):
-        return (*_gn_backward(ctx, dy, None if dskip is None else _c(dskip)), None, None)
+    def backward(ctx, dy, dskip, dtap):
+        return (*_gn_backward(ctx, dy, None if dskip is None else _c(dskip), None if dtap is None else _c(dtap)),
+                None, None)
 
 
 class _GroupNormCatSkipFn(torch.autograd.Function):
@@ -209,11 +215,13 @@ def group_norm(x, weight, bias, groups, silu):
     return _GroupNormFn.apply(x, weight, bias, groups, silu)
 
 
-def group_norm_skip(x, weight, bias, groups, silu):
-    """-> (GroupNorm(x), x_for_the_residual_branch); see _GroupNormSkipFn."""
+def group_norm_skip(x, weight, bias, groups, silu, tap=False):
+    """-> (GroupNorm(x), x_for_the_residual_branch[, x_for_the_decoder_skip]); see _GroupNormSkipFn."""
     if not (torch.is_grad_enabled() and x.requires_grad):
-        return _GroupNormFn.apply(x, weight, bias, groups, silu), x
-    return _GroupNormSkipFn.apply(x, weight, bias, groups, silu)
+        y = _GroupNormFn.apply(x, weight, bias, groups, silu)
+        return (y, x, x) if tap else (y, x)
+    out = _GroupNormSkipFn.apply(x, weight, bias, groups, silu)
+    return out if tap else out[:2]
 
 
 # ---------------------------------------------------------------------------------------------

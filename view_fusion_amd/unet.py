@@ -44,8 +44,10 @@ class _ResBlock(nn.Module):
         self.res_conv = nn.Conv2d(cin, cout, 1) if cin != cout else nn.Identity()
         self.groups = groups
 
-    def forward(self, x, e, skip=None):
-        """e = this block's FeatureWiseAffine Linear(emb), (S,Cout): all blocks' are computed in one grouped
+    def forward(self, x, e, skip=None, tap=False):
+        """tap=True (encoder blocks): also return a handle on the INPUT x for the decoder's skip connection, whose
+        gradient is then added inside this block's GroupNorm backward instead of by an autograd add.
+        e = this block's FeatureWiseAffine Linear(emb), (S,Cout): all blocks' are computed in one grouped
         launch by UNet.forward.  skip (decoder blocks): the encoder feature map that the reference concatenates
         to x (unet.py:134); when the shapes allow, the concatenation is never built -- the first GroupNorm and the
         residual 1x1 conv read both tensors."""
@@ -62,11 +64,12 @@ class _ResBlock(nn.Module):
             return ops.conv2d(a, b2["3"], residual=ops.conv1x1_cat(x1, x2, self.res_conv))
         # x feeds both the first GroupNorm and the residual branch: the GN op hands x back so that
         # the residual gradient is summed inside its backward kernel
-        a, xs = ops.group_norm_skip(x, b1["0"].weight, b1["0"].bias, self.groups, silu=True)
+        a, xs, xt = ops.group_norm_skip(x, b1["0"].weight, b1["0"].bias, self.groups, silu=True, tap=True)
         h = ops.conv2d(a, b1["3"], view_bias=e)
         a = ops.group_norm(h, b2["0"].weight, b2["0"].bias, self.groups, silu=True)
         skip = xs if isinstance(self.res_conv, nn.Identity) else ops.conv2d(xs, self.res_conv)
-        return ops.conv2d(a, b2["3"], residual=skip)
+        y = ops.conv2d(a, b2["3"], residual=skip)
+        return (y, xt) if tap else y
 
 
 class _SelfAttention(nn.Module):
@@ -93,9 +96,14 @@ class _ResAttnBlock(nn.Module):
         if with_attn:
             self.attn = _SelfAttention(cout, groups)
 
-    def forward(self, x, e, skip=None):
-        x = self.res_block(x, e, skip)
-        return self.attn(x) if self.with_attn else x
+    def forward(self, x, e, skip=None, tap=False):
+        xt = None
+        if tap:
+            x, xt = self.res_block(x, e, skip, tap=True)
+        else:
+            x = self.res_block(x, e, skip)
+        x = self.attn(x) if self.with_attn else x
+        return (x, xt) if tap else x
 
 
 class _Resample(nn.Module):
@@ -210,17 +218,26 @@ class UNet(nn.Module):
         # FeatureWiseAffine of every residual block (unet.py:160-177) in one grouped launch
         es = iter(ops.time_affine_all(emb, self._affine_layers()))
 
+        # feats[i] feeds the next encoder layer AND the decoder: where that next layer is a residual block, the
+        # decoder takes the block's handle on its input instead (see _ResBlock.forward, tap)
         feats = []
         for layer in self.downs:
             if isinstance(layer, _ResAttnBlock):
-                x = layer(x, next(es))
+                x, xin = layer(x, next(es), tap=True)
+                if feats:
+                    feats[-1] = xin
             elif isinstance(layer, _Resample):
                 x = layer(x)
             else:
                 x = ops.conv2d(x, layer)
             feats.append(x)
+        first = True
         for layer in self.mid:
-            x = layer(x, next(es))
+            if first:
+                x, feats[-1] = layer(x, next(es), tap=True)
+                first = False
+            else:
+                x = layer(x, next(es))
         for layer in self.ups:
             if isinstance(layer, _ResAttnBlock):
                 x = layer(x, next(es), feats.pop())
