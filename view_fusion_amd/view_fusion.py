@@ -93,7 +93,7 @@ class ViewFusion(nn.Module):
     def generate(self, y_cond, view_count, angle, y_t=None, sample_num=8, z_seq=None, use_graph=None):
         """Reverse diffusion over all T steps (reference view_fusion.py:179-214).
 
-        use_graph (default: on for GPU tensors with S <= 8 stacked views): one reverse step -- level gather, re-stack of
+        use_graph (default: on for GPU tensors with S <= 16 stacked views): one reverse step -- level gather, re-stack of
         y_t, the whole UNet forward and the fused compose/posterior tail (~260 launches) -- is
         captured once into a HIP graph and replayed T times, so the loop is not launch-bound at
         small S.  Per step the host only refreshes the step index and the noise buffer.
@@ -110,7 +110,7 @@ class ViewFusion(nn.Module):
         w_on = bool(self.weighting_inference)
         sched = self._sched()
         if use_graph is None:                             # measured: replay wins while the step is launch-bound
-            use_graph = y.is_cuda and S <= 8
+            use_graph = y.is_cuda and S <= 16   # (at S = 12 replay and eager tie, but replay is immune to host jitter)
         t = torch.full((b,), self.num_timesteps - 1, device=dev, dtype=torch.long)
         z = torch.zeros_like(y)
         y_cond = y_cond.contiguous()
