@@ -96,9 +96,10 @@ int vf_wino_conv_fwd(const float* x, const float* u_packed, const float* bias, c
  * slabs that are summed in a fixed order, then dW = G^T dU G */
 int vf_wino_wgrad_supported(int H, int W, int mode);
 long vf_wino_wgrad_ws_floats(int S, int Cin, int Cout, int H, int W);
-/* db (or NULL): also the bias gradient sum_{s,p} dY -- the kernel reads every dY tile anyway */
-int vf_wino_wgrad(const float* x, const float* dy, float* dw_oihw, float* db, float* ws, long ws_floats, int S, int Cin,
-                  int Cout, int H, int W, int mode, void* stream);
+/* db (or NULL): also the bias gradient sum_{s,p} dY -- the kernel reads every dY tile anyway; db_copies (1|2) rows
+ * of [Cout] are filled (a layer sharing this dY, the residual 1x1 conv, gets its own tensor) */
+int vf_wino_wgrad(const float* x, const float* dy, float* dw_oihw, float* db, int db_copies, float* ws, long ws_floats,
+                  int S, int Cin, int Cout, int H, int W, int mode, void* stream);
 
 /* ---- grouped time-embedding affine: all FeatureWiseAffine Linear(K->C_g) layers of the UNet on the same
  *      (S,K) embedding in one launch, unet.py:160-177.  desc = device int64 [ngroups][5] rows

@@ -456,18 +456,18 @@ class _Conv2dFn(torch.autograd.Function):
         hit = _rowsum_get(dy) if (want_b or want_v) else None
         if hit is not None:
             dvb, db = hit[1], hit[2]
+        db_here, db_twin = None, None
         if ctx.needs_input_grad[1] and use_winograd_wgrad(S, Cin, Cout, H, W, KS, m):
             need = _lib.load().vf_wino_wgrad_ws_floats(S, Cin, Cout, H, W)
             ws = _workspace(x.device, need)
             dw = torch.empty(Cout, Cin, 3, 3, device=x.device, dtype=torch.float32)
             if want_b and db is None:
-                # the wgrad kernel reads every dY tile anyway: the bias gradient (sum over views and pixels) rides along
-                db = torch.empty(Cout, device=x.device, dtype=torch.float32)
-                db_here = db
-            else:
-                db_here = None
-            _launch("conv_wgrad", ctx.flops, "vf_wino_wgrad", _ptr(x), _ptr(dy), _ptr(dw), _ptr(db_here), _ptr(ws),
-                    ws.numel(), S, Cin, Cout, H, W, m, st, tag=ctx.tag)
+                # the wgrad kernel reads every dY tile anyway: the bias gradient (sum over views and pixels) rides
+                # along; with a residual branch its 1x1 conv has the same bias gradient and gets its own row
+                db_here = torch.empty(2 if hr else 1, Cout, device=x.device, dtype=torch.float32)
+                db, db_twin = db_here[0], (db_here[1] if hr else None)
+            _launch("conv_wgrad", ctx.flops, "vf_wino_wgrad", _ptr(x), _ptr(dy), _ptr(dw), _ptr(db_here),
+                    2 if db_twin is not None else 1, _ptr(ws), ws.numel(), S, Cin, Cout, H, W, m, st, tag=ctx.tag)
         elif ctx.needs_input_grad[1]:
             need = _lib.load().vf_conv_wgrad_ws_floats(S, Cin, Cout, H, W, KS)
             ws = _workspace(x.device, need)
@@ -488,7 +488,7 @@ class _Conv2dFn(torch.autograd.Function):
                 db = torch.empty(Cout, device=x.device, dtype=torch.float32)
                 _lib.call("vf_colsum", _ptr(dvb), _ptr(db), 1, S, Cout, st)
             if hr and want_b:                    # the residual branch (1x1 conv) receives this very dY
-                _rowsum_put(dy, dvb, db)
+                _rowsum_put(dy, dvb, db_twin if db_twin is not None else db)
             if not want_b:
                 db = None
             if not want_v:
