@@ -96,9 +96,9 @@ int vf_wino_conv_fwd(const float* x, const float* u_packed, const float* bias, c
  * slabs that are summed in a fixed order, then dW = G^T dU G */
 int vf_wino_wgrad_supported(int H, int W, int mode);
 long vf_wino_wgrad_ws_floats(int S, int Cin, int Cout, int H, int W);
-/* db (or NULL): also the bias gradient sum_{s,p} dY -- the kernel reads every dY tile anyway; db_copies (1|2) rows
- * of [Cout] are filled (a layer sharing this dY, the residual 1x1 conv, gets its own tensor) */
-int vf_wino_wgrad(const float* x, const float* dy, float* dw_oihw, float* db, int db_copies, float* ws, long ws_floats,
+/* db (or NULL): also the bias gradient sum_{s,p} dY -- the kernel reads every dY tile anyway; db2 (or NULL) is a
+ * second [Cout] destination for the same sums (a layer sharing this dY, the residual 1x1 conv, gets its own tensor) */
+int vf_wino_wgrad(const float* x, const float* dy, float* dw_oihw, float* db, float* db2, float* ws, long ws_floats,
                   int S, int Cin, int Cout, int H, int W, int mode, void* stream);
 
 /* ---- grouped time-embedding affine: all FeatureWiseAffine Linear(K->C_g) layers of the UNet on the same
@@ -107,9 +107,11 @@ int vf_wino_wgrad(const float* x, const float* dy, float* dw_oihw, float* db, in
 int vf_time_affine_fwd(const void* desc, int ngroups, const float* emb, float* out, int S, int K, int CT,
                        void* stream);
 long vf_time_affine_ws_floats(int S, int K);
+/* gdst (or NULL): device array of ngroups rows {float* dW_g, float* db_g}: one destination per layer (the slots of
+ * a data-parallel gradient buffer) instead of the flat dw / db */
 int vf_time_affine_bwd(const void* desc, int ngroups, const float* emb, const float* de, float* dw /*[CT][K]*/,
-                       float* db /*[CT]*/, float* demb /*[S][K] or NULL*/, float* ws, int S, int K, int CT,
-                       void* stream);
+                       float* db /*[CT]*/, const void* gdst, float* demb /*[S][K] or NULL*/, float* ws, int S, int K,
+                       int CT, void* stream);
 
 /* ---- batched GEMM + softmax : torch.einsum / torch.softmax / nn.Linear,
  *      unet.py:267-274 (attention), :29-31,165 (linears) ---- */

@@ -1,6 +1,7 @@
-"""World-size-2 CPU (gloo) test of the data-parallel harness: the Trainer's DDP wrapping,
-per-rank shards and the gradient all-reduce (mean) give the same update as one process on the
-concatenated batch.  The HIP model cannot run on CPU (no fallback by design), so a small
+"""World-size-2 CPU (gloo) test of the data-parallel harness: the Trainer's reducer (the gradient
+arena of reducer.py by default, torch DDP with VF_REDUCER=ddp), per-rank shards and the gradient
+all-reduce (mean) give the same updates as one process on the concatenated batch, over several
+iterations (the arena lays its slots out on the first one and overlaps segments from the second).  The HIP model cannot run on CPU (no fallback by design), so a small
 stand-in module with the ViewFusion.forward signature takes its place; what is under test is
 the harness (view_fusion_amd.train), which is device-agnostic.  RCCL itself only runs on the
 GPU box (bench.py --gpus N)."""
@@ -8,6 +9,7 @@ import os
 import socket
 import sys
 
+import pytest
 import torch
 import torch.multiprocessing as mp
 
@@ -36,29 +38,39 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out):
+STEPS = 3
+
+
+def _worker(rank, world, port, out, reducer_kind):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
-                      WORLD_SIZE=str(world))
+                      WORLD_SIZE=str(world), VF_REDUCER=reducer_kind)
     torch.set_num_threads(1)
     from view_fusion_amd import train
     r, lr, w = train.init_distributed()
     assert (r, w) == (rank, world)
     tr = train.Trainer(StandIn(), world=w, local_rank=lr, lr_warmup=1)
     tr.it = 0                                   # lr(1) = peak
-    batch = train.synthetic_batch(4, 3, 8, "cpu", seed=rank)
-    tr.step(batch)
+    assert (tr.arena is not None) == (reducer_kind == "arena")
+    for it in range(STEPS):
+        tr.step(train.synthetic_batch(4, 3, 8, "cpu", seed=10 * it + rank))
+    if tr.arena is not None:                    # every gradient lives in its arena slot, segments cover the arena
+        a = tr.arena
+        assert all(p.grad.data_ptr() == a.base + 4 * a.off[i] for i, p in enumerate(a.params))
+        assert a.seg_range[0][0] == 0 and a.seg_range[-1][1] == a.flat.numel()
+        assert all(x[1] == y[0] for x, y in zip(a.seg_range, a.seg_range[1:]))
     out[rank] = [p.detach().clone() for p in tr.module.parameters()]
     torch.distributed.destroy_process_group()
 
 
-def test_two_rank_gloo_matches_single_process_on_the_global_batch():
+@pytest.mark.parametrize("reducer_kind", ["arena", "ddp"])
+def test_two_rank_gloo_matches_single_process_on_the_global_batch(reducer_kind):
     sys.path.insert(0, ROOT)
     from view_fusion_amd import train
     world = 2
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), out, reducer_kind), nprocs=world, join=True)
     # replicas stay in lock-step
     for a, b in zip(out[0], out[1]):
         assert torch.equal(a, b)
@@ -67,8 +79,8 @@ def test_two_rank_gloo_matches_single_process_on_the_global_batch():
         os.environ.pop(k, None)
     tr = train.Trainer(StandIn(), world=1, lr_warmup=1)
     tr.it = 0
-    shards = [train.synthetic_batch(4, 3, 8, "cpu", seed=r) for r in range(world)]
-    batch = {k: torch.cat([s[k] for s in shards]) for k in shards[0]}
-    tr.step(batch)
+    for it in range(STEPS):
+        shards = [train.synthetic_batch(4, 3, 8, "cpu", seed=10 * it + r) for r in range(world)]
+        tr.step({k: torch.cat([s[k] for s in shards]) for k in shards[0]})
     for a, b in zip(out[0], tr.module.parameters()):
         assert torch.allclose(a, b.detach(), rtol=1e-5, atol=1e-7)

@@ -224,3 +224,58 @@ def test_psnr_and_sampler_drivers(dev):
     assert float((weight_arr.sum(dim=2) - 1).abs().max()) < 1e-5 and bool(torch.isfinite(ret).all())
     orbit = drivers.autoregressive_rollout(vf, cond[:, 0], steps=4)
     assert orbit.shape == (2, 4, 3, 16, 16) and bool(torch.isfinite(orbit).all())
+
+
+def test_gradient_arena_matches_plain_training(dev):
+    """§8(e): the data-parallel reducer on the GPU over RCCL (a world of one rank -- the box has one GPU): with
+    the gradient arena every dW/db/dgamma/dbeta is written into the communication buffer by the backward kernels
+    (no gradient is copied from the second iteration on), segments are all-reduced asynchronously, and the
+    parameters after three Adam steps are bit-identical to single-process training (same kernels, only the
+    destination of the gradients differs).  World-size-2 semantics are covered on CPU (tests/test_ddp_gloo.py)."""
+    import socket
+    import torch.distributed as dist
+    from view_fusion_amd import reducer, train
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    g = torch.Generator().manual_seed(9)
+    B, N = 4, 3
+    batches = []
+    for _ in range(3):
+        batches.append(dict(y_0=torch.rand(B, 3, 16, 16, generator=g).to(dev),
+                            y_cond=torch.rand(B, N, 3, 16, 16, generator=g).to(dev),
+                            angle=(2 * np.pi / 24 * torch.randint(0, 24, (B, 1), generator=g).float()).to(dev),
+                            view_count=torch.tensor([3, 1, 2, 3]),
+                            noise=torch.randn(B, 3, 16, 16, generator=g).to(dev),
+                            t=torch.randint(1, 2000, (B,), generator=g).to(dev), u=torch.rand(B, 1, generator=g).to(dev)))
+
+    def run(world):
+        vf = make_vf(TINY, SCHED_TRAIN, dev, True)
+        tr = train.Trainer(vf, world=world, lr_warmup=1)
+        tr.it = 0
+        copied = []
+        for b in batches:
+            b = dict(b)
+            extra = {k: b.pop(k) for k in ("noise", "t", "u")}
+            if tr.arena is not None:
+                tr.arena.copied = 0
+            tr.step(b, **extra)
+            copied.append(tr.arena.copied if tr.arena is not None else None)
+        return vf, tr, copied
+
+    plain, _, _ = run(1)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        vf, tr, copied = run(2)                          # world=2 only selects the reducer; the group has one rank
+        a = tr.arena
+        assert a is not None and reducer.ACTIVE is a
+        assert copied[1:] == [0, 0], copied              # zero-copy from the second iteration on
+        assert all(p.grad.data_ptr() == a.base + 4 * a.off[i] for i, p in enumerate(a.params))
+        assert len(a.seg_range) >= 2 and a.seg_range[-1][1] == a.flat.numel()
+        for (k, p), q in zip(vf.state_dict().items(), plain.state_dict().values()):
+            assert torch.equal(p, q), k
+    finally:
+        reducer.ACTIVE = None
+        dist.destroy_process_group()

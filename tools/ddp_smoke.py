@@ -1,28 +1,57 @@
 #!/usr/bin/env python3
-"""Single-GPU smoke test of the DDP/RCCL path (world_size 1): DDP wrapper + reducer hooks on top of
-the custom autograd Functions, gradient buckets as views, fused Adam.  Prints ms/step."""
+"""Single-GPU check of the data-parallel exchange step over RCCL (world_size 1): the gradient arena
+(reducer.py: gradients written into the communication buffer by the backward kernels, segment-wise
+async all-reduce) against torch DDP and against plain single-process training.  Prints ms/step, the
+number of gradients per step that still had to be copied into the arena, and a parameter checksum
+(identical for all three: the same kernels run, only the destination of the gradients differs).
+
+    python tools/ddp_smoke.py            # runs the three modes as child processes
+"""
 import os
+import subprocess
 import sys
 import time
 
-import torch
-import torch.distributed as dist
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from view_fusion_amd import train  # noqa: E402
 
-os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-os.environ.setdefault("MASTER_PORT", "29533")
-torch.cuda.set_device(0)
-dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-model = train.build_model(device="cuda:0")
-tr = train.Trainer(model, world=2, local_rank=0)        # world=2 only selects the DDP branch
-batch = train.synthetic_batch(16, 6, 64, torch.device("cuda:0"))
-for _ in range(2):
-    tr.step(batch)
-torch.cuda.synchronize(); t0 = time.perf_counter()
-for _ in range(5):
-    loss = tr.step(batch)
-torch.cuda.synchronize()
-print(f"DDP(world=1) {1e3 * (time.perf_counter() - t0) / 5:.2f} ms/step loss {loss.item():.5f}")
-dist.destroy_process_group()
+def child(kind):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    from view_fusion_amd import train
+    torch.cuda.set_device(0)
+    if kind != "none":
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ["VF_REDUCER"] = kind
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    model = train.build_model(device="cuda:0")
+    tr = train.Trainer(model, world=2 if kind != "none" else 1, local_rank=0)   # world=2 only selects the reducer
+    batch = train.synthetic_batch(16, 6, 64, torch.device("cuda:0"))
+    for _ in range(3):
+        tr.step(batch)
+    if tr.arena is not None:
+        tr.arena.copied = 0
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    n = 10
+    for _ in range(n):
+        loss = tr.step(batch)
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / n
+    chk = sum(float(p.double().abs().sum()) for p in model.parameters())
+    extra = ""
+    if tr.arena is not None:
+        a = tr.arena
+        extra = f" copied/step {a.copied / n:.0f} of {len(a.params)} segments {[(hi - lo) * 4 >> 20 for lo, hi in a.seg_range]} MiB"
+    print(f"reducer={kind:5s} {ms:.2f} ms/step loss {loss.item():.6f} param-checksum {chk:.9e}{extra}", flush=True)
+    if kind != "none":
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 1:
+        child(sys.argv[1])
+    else:
+        for kind in ("none", "ddp", "arena"):
+            subprocess.run([sys.executable, os.path.abspath(__file__), kind], check=False)

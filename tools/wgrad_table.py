@@ -20,7 +20,7 @@ for Cin, Cout, H in shapes:
         _lib.call("vf_conv_wgrad", x.data_ptr(), dy.data_ptr(), dw0.data_ptr(), ws.data_ptr(), ws.numel(), S, Cin, Cout,
                   H, H, 3, 0, st)
     def wino():
-        _lib.call("vf_wino_wgrad", x.data_ptr(), dy.data_ptr(), dw1.data_ptr(), None, 1, ws.data_ptr(), ws.numel(), S, Cin, Cout,
+        _lib.call("vf_wino_wgrad", x.data_ptr(), dy.data_ptr(), dw1.data_ptr(), None, None, ws.data_ptr(), ws.numel(), S, Cin, Cout,
                   H, H, 0, st)
     res = []
     for fn in (direct, wino):

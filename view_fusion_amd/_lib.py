@@ -44,11 +44,11 @@ SIGNATURES = {
     "vf_wino_conv_fwd": [_P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P],
     "vf_wino_wgrad_ws_floats": [_I, _I, _I, _I, _I],
     "vf_wino_wgrad_supported": [_I, _I, _I],
-    "vf_wino_wgrad": [_P, _P, _P, _P, _I, _P, _L, _I, _I, _I, _I, _I, _I, _P],
+    "vf_wino_wgrad": [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P],
     "vf_sumpool2": [_P, _P, _L, _I, _P],
     "vf_time_affine_fwd": [_P, _I, _P, _P, _I, _I, _I, _P],
     "vf_time_affine_ws_floats": [_I, _I],
-    "vf_time_affine_bwd": [_P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "vf_time_affine_bwd": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "vf_bgemm": [_P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _L, _L, _L, _L, _L, _F, _F, _P],
     "vf_attention_fwd": [_P, _P, _P, _I, _I, _I, _P],
     "vf_softmax_fwd": [_P, _P, _I, _I, _P],

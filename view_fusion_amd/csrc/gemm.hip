@@ -256,6 +256,11 @@ struct TADesc {
     long long C, out_off, c_off;
 };
 
+struct TAGrad {
+    float* dw;
+    float* db;
+};
+
 __device__ __forceinline__ int ta_group(const TADesc* __restrict__ d, int ng, int cg) {
     int lo = 0, hi = ng;
     while (hi - lo > 1) {
@@ -289,12 +294,18 @@ __global__ __launch_bounds__(256) void time_affine_fwd_kernel(const TADesc* __re
 __global__ __launch_bounds__(256) void time_affine_bwd_w_kernel(const TADesc* __restrict__ desc, int ng,
                                                                 const float* __restrict__ emb,
                                                                 const float* __restrict__ de, float* __restrict__ dw,
-                                                                float* __restrict__ db, int S, int K, int CT) {
+                                                                float* __restrict__ db,
+                                                                const TAGrad* __restrict__ gdst, int S, int K, int CT) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= CT * K) return;
     const int k = idx % K, cg = idx / K;
-    const TADesc d = desc[ta_group(desc, ng, cg)];
+    const int gi = ta_group(desc, ng, cg);
+    const TADesc d = desc[gi];
     const int c = cg - (int)d.c_off;
+    if (gdst) {                                  // per-layer destinations instead of the flat [CT][K] / [CT] buffers
+        dw = gdst[gi].dw - (size_t)d.c_off * K;
+        db = gdst[gi].db - d.c_off;
+    }
     const float* g = de + d.out_off + c;
     float a[4] = {0.f, 0.f, 0.f, 0.f}, bsum[4] = {0.f, 0.f, 0.f, 0.f};
     int s = 0;
@@ -427,15 +438,16 @@ int vf_time_affine_fwd(const void* desc, int ngroups, const float* emb, float* o
 
 long vf_time_affine_ws_floats(int S, int K) { return (long)TA_NSPLIT * S * K; }
 
-// dw: [CT][K] (group g's weight gradient = rows c_off_g ..), db: [CT], demb: [S][K] (or NULL; needs ws of
-// vf_time_affine_ws_floats(S, K) floats)
+// dw: [CT][K] (group g's weight gradient = rows c_off_g ..), db: [CT]; or, with gdst != NULL (ngroups rows of
+// {float* dW_g [C_g][K], float* db_g [C_g]}), one destination per layer and dw/db unused; demb: [S][K] (or NULL;
+// needs ws of vf_time_affine_ws_floats(S, K) floats)
 int vf_time_affine_bwd(const void* desc, int ngroups, const float* emb, const float* de, float* dw, float* db,
-                       float* demb, float* ws, int S, int K, int CT, void* stream) {
+                       const void* gdst, float* demb, float* ws, int S, int K, int CT, void* stream) {
     if (ngroups <= 0 || S <= 0) return 0;
     if (K % 8 != 0 || K > 256 || 256 % K != 0) return (int)hipErrorInvalidValue;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(time_affine_bwd_w_kernel, dim3((CT * K + 255) / 256), dim3(256), 0, st, (const TADesc*)desc,
-                       ngroups, emb, de, dw, db, S, K, CT);
+                       ngroups, emb, de, dw, db, (const TAGrad*)gdst, S, K, CT);
     if (demb) {
         if (!ws) return (int)hipErrorInvalidValue;
         hipLaunchKernelGGL(time_affine_bwd_x_kernel, dim3(S, TA_NSPLIT), dim3(256), 0, st, (const TADesc*)desc,

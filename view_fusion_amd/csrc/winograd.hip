@@ -884,7 +884,7 @@ __global__ __launch_bounds__(256) void wino_wgrad_slabsum_kernel(const float* __
 __global__ __launch_bounds__(256) void wino_wgrad_finish_kernel(const float* __restrict__ du, float* __restrict__ dw,
                                                                 int Cout, int Cin, int CoutP, int CinQ,
                                                                 const float* __restrict__ bsum, float* __restrict__ db,
-                                                                int nslab, int nmain, int db_copies) {
+                                                                int nslab, int nmain, float* db2) {
     if ((int)blockIdx.x >= nmain) {      // trailing blocks: db[co] = sum over the slices' dY sums (64 channels x 4
         __shared__ float red[4][64];     // slice groups per block, 8 loads in flight, fixed order)
         const int cx = threadIdx.x & 63, g = threadIdx.x >> 6;
@@ -903,7 +903,8 @@ __global__ __launch_bounds__(256) void wino_wgrad_finish_kernel(const float* __r
         __syncthreads();
         if (g == 0 && co < Cout) {
             const float v = (red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]);
-            for (int c = 0; c < db_copies; ++c) db[(size_t)c * Cout + co] = v;   // a second owner gets its own copy
+            db[co] = v;
+            if (db2) db2[co] = v;                 // a second owner (the residual 1x1 conv) gets its own copy
         }
         return;
     }
@@ -935,7 +936,7 @@ __global__ __launch_bounds__(256) void wino_wgrad_finish_kernel(const float* __r
 }
 
 template <int LOGW, int MODE>
-int launch_wino_wgrad(WinoWgradArgs a, float* dw, float* db, int db_copies, size_t ws_floats, hipStream_t st) {
+int launch_wino_wgrad(WinoWgradArgs a, float* dw, float* db, float* db2, size_t ws_floats, hipStream_t st) {
     constexpr int W = 1 << LOGW;
     a.nchunks = a.S * ((W / 2) * (W / 2) / GT);
     const int nco = a.CoutP / 64, nci = (a.CinQ + 63) / 64;
@@ -959,7 +960,7 @@ int launch_wino_wgrad(WinoWgradArgs a, float* dw, float* db, int db_copies, size
     const int total = a.Cout * a.Cin;
     const int nmain = (total + 255) / 256, nbias = db ? (a.Cout + 63) / 64 : 0;
     hipLaunchKernelGGL(wino_wgrad_finish_kernel, dim3(nmain + nbias), dim3(256), 0, st, du, dw, a.Cout, a.Cin, a.CoutP,
-                       a.CinQ, a.bsum, db, z, nmain, db_copies);
+                       a.CinQ, a.bsum, db, z, nmain, db2);
     VF_RETURN_LAST_ERROR();
 }
 
@@ -985,8 +986,8 @@ int vf_wino_wgrad_supported(int H, int W, int mode) {
 // dw[Cout][Cin][3][3] of a stride-1 3x3 conv (H = W = output size in {8, 16, 32, 64}; mode 2: x is stored at half
 // size and nearest-upsampled on read) via Winograd F(2x2,3x3)
 // db (or NULL): also the bias gradient sum_{s,p} dY[s][co][p] -- the kernel reads every dY tile anyway;
-// db_copies (1 or 2): db holds that many [Cout] rows, all filled (a second consumer gets its own tensor)
-int vf_wino_wgrad(const float* x, const float* dy, float* dw, float* db, int db_copies, float* ws, long ws_floats, int S,
+// db2 (or NULL): a second [Cout] destination for the same sums (the residual 1x1 conv shares this dY)
+int vf_wino_wgrad(const float* x, const float* dy, float* dw, float* db, float* db2, float* ws, long ws_floats, int S,
                   int Cin, int Cout, int H, int W, int mode, void* stream) {
     if (S <= 0) return 0;
     if (!vf_wino_wgrad_supported(H, W, mode)) return (int)hipErrorInvalidValue;
@@ -995,8 +996,8 @@ int vf_wino_wgrad(const float* x, const float* dy, float* dw, float* db, int db_
     a.CoutP = rup(Cout, 64); a.CinQ = rup(Cin, 32);
     hipStream_t st = (hipStream_t)stream;
 #define VF_WG(LW) \
-    return mode == 2 ? launch_wino_wgrad<LW, 2>(a, dw, db, db_copies, (size_t)ws_floats, st) \
-                     : launch_wino_wgrad<LW, 0>(a, dw, db, db_copies, (size_t)ws_floats, st)
+    return mode == 2 ? launch_wino_wgrad<LW, 2>(a, dw, db, db2, (size_t)ws_floats, st) \
+                     : launch_wino_wgrad<LW, 0>(a, dw, db, db2, (size_t)ws_floats, st)
     if (W == 8) VF_WG(3);
     if (W == 16) VF_WG(4);
     if (W == 32) VF_WG(5);

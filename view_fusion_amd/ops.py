@@ -10,7 +10,7 @@ import math
 
 import torch
 
-from . import _lib
+from . import _lib, reducer
 
 _MODES = {"same": 0, "down2": 1, "up2": 2}
 
@@ -107,6 +107,18 @@ def _rowsum_get(t):
     return hit
 
 
+def _gslot(p):
+    """Parameter p's slot in the data-parallel gradient arena (reducer.py), or None: the backward kernels write a
+    gradient there directly so that neither autograd nor the reducer has to copy it."""
+    a = reducer.ACTIVE
+    return a.slot(p) if (a is not None and p is not None) else None
+
+
+def _gout(p, *shape, like):
+    t = _gslot(p)
+    return t if t is not None else torch.empty(*shape, device=like.device, dtype=torch.float32)
+
+
 def _gn_backward(ctx, dy, addend, addend2=None):
     x, gamma, beta, mean, rstd = ctx.saved_tensors
     dy = _c(dy)
@@ -123,7 +135,9 @@ def _gn_backward(ctx, dy, addend, addend2=None):
               ctx.silu, _stream())
     if rowsum is not None:
         _rowsum_put(dx, rowsum, None)
-    dgb = torch.empty(2, C, device=x.device, dtype=torch.float32)
+    dgb = reducer.ACTIVE.slot_pair(*ctx.gb) if reducer.ACTIVE is not None else None
+    if dgb is None:
+        dgb = torch.empty(2, C, device=x.device, dtype=torch.float32)
     _lib.call("vf_colsum", _ptr(parts), _ptr(dgb), 2, S, C, _stream())
     return dx, dgb[0], dgb[1]
 
@@ -133,7 +147,7 @@ class _GroupNormFn(torch.autograd.Function):
     def forward(ctx, x, gamma, beta, groups, silu):
         y, mean, rstd = _gn_forward(x, gamma, beta, groups, silu)
         ctx.save_for_backward(x, gamma, beta, mean, rstd)
-        ctx.groups, ctx.silu = groups, int(silu)
+        ctx.groups, ctx.silu, ctx.gb = groups, int(silu), (gamma, beta)
         return y
 
     @staticmethod
@@ -150,7 +164,7 @@ class _GroupNormSkipFn(torch.autograd.Function):
     def forward(ctx, x, gamma, beta, groups, silu):
         y, mean, rstd = _gn_forward(x, gamma, beta, groups, silu)
         ctx.save_for_backward(x, gamma, beta, mean, rstd)
-        ctx.groups, ctx.silu = groups, int(silu)
+        ctx.groups, ctx.silu, ctx.gb = groups, int(silu), (gamma, beta)
         ctx.set_materialize_grads(False)          # an unused handle must not cost a zero tensor + an add
         return y, x.view_as(x), x.view_as(x)
 
@@ -176,7 +190,7 @@ class _GroupNormCatSkipFn(torch.autograd.Function):
         _lib.call("vf_gn_cat_fwd", _ptr(x1), _ptr(x2), C1, _ptr(gamma), _ptr(beta), _ptr(y), _ptr(mean), _ptr(rstd), S,
                   C, H * W, groups, 1e-5, int(silu), _stream())
         ctx.save_for_backward(x1, x2, gamma, beta, mean, rstd)
-        ctx.groups, ctx.silu = groups, int(silu)
+        ctx.groups, ctx.silu, ctx.gb = groups, int(silu), (gamma, beta)
         return y, x1.view_as(x1), x2.view_as(x2)
 
     @staticmethod
@@ -195,7 +209,9 @@ class _GroupNormCatSkipFn(torch.autograd.Function):
         _lib.call("vf_gn_cat_bwd", _ptr(x1), _ptr(x2), C1, _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd), _ptr(dy),
                   _ptr(d1), _ptr(d2), _ptr(dx1), _ptr(dx2), _ptr(parts[0]), _ptr(parts[1]), None, S, C, H * W,
                   ctx.groups, ctx.silu, _stream())
-        dgb = torch.empty(2, C, device=x1.device, dtype=torch.float32)
+        dgb = reducer.ACTIVE.slot_pair(*ctx.gb) if reducer.ACTIVE is not None else None
+        if dgb is None:
+            dgb = torch.empty(2, C, device=x1.device, dtype=torch.float32)
         _lib.call("vf_colsum", _ptr(parts), _ptr(dgb), 2, S, C, _stream())
         return dx1, dx2, dgb[0], dgb[1], None, None
 
@@ -388,7 +404,7 @@ def pack_all(root, S=None):
 
 class _Conv2dFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, view_bias, residual, layer, mode, training):
+    def forward(ctx, x, weight, bias, view_bias, residual, layer, mode, training, twin):
         _check(x, bias, view_bias, residual)
         S, Cin, Hi, Wi = x.shape
         Cout, _, KS, _ = weight.shape
@@ -414,6 +430,7 @@ class _Conv2dFn(torch.autograd.Function):
         ctx.wino = wino
         ctx.wb, ctx.m, ctx.KS, ctx.Cout = wb, m, KS, Cout
         ctx.has = (bias is not None, view_bias is not None, residual is not None)
+        ctx.pw, ctx.pb, ctx.twin = weight, bias, (twin.bias if twin is not None else None)
         return y
 
     @staticmethod
@@ -453,31 +470,34 @@ class _Conv2dFn(torch.autograd.Function):
                 _lib.call("vf_sumpool2", _ptr(dup), _ptr(dx), dx.numel(), Wi, st)
         hb, hv, hr = ctx.has
         want_b, want_v = hb and ctx.needs_input_grad[2], hv and ctx.needs_input_grad[3]
+        arena = reducer.ACTIVE is not None
         hit = _rowsum_get(dy) if (want_b or want_v) else None
         if hit is not None:
             dvb, db = hit[1], hit[2]
-        db_here, db_twin = None, None
+        db2 = None            # this dY's channel sums for the residual 1x1 conv, in a tensor of its own
         if ctx.needs_input_grad[1] and use_winograd_wgrad(S, Cin, Cout, H, W, KS, m):
             need = _lib.load().vf_wino_wgrad_ws_floats(S, Cin, Cout, H, W)
             ws = _workspace(x.device, need)
-            dw = torch.empty(Cout, Cin, 3, 3, device=x.device, dtype=torch.float32)
+            dw = _gout(ctx.pw, Cout, Cin, 3, 3, like=x)
+            db_here = None
             if want_b and db is None:
                 # the wgrad kernel reads every dY tile anyway: the bias gradient (sum over views and pixels) rides
-                # along; with a residual branch its 1x1 conv has the same bias gradient and gets its own row
-                db_here = torch.empty(2 if hr else 1, Cout, device=x.device, dtype=torch.float32)
-                db, db_twin = db_here[0], (db_here[1] if hr else None)
-            _launch("conv_wgrad", ctx.flops, "vf_wino_wgrad", _ptr(x), _ptr(dy), _ptr(dw), _ptr(db_here),
-                    2 if db_twin is not None else 1, _ptr(ws), ws.numel(), S, Cin, Cout, H, W, m, st, tag=ctx.tag)
+                # along; with a residual branch its 1x1 conv has the same bias gradient and gets its own copy
+                db = db_here = _gout(ctx.pb, Cout, like=x)
+                if hr:
+                    db2 = _gout(ctx.twin, Cout, like=x)
+            _launch("conv_wgrad", ctx.flops, "vf_wino_wgrad", _ptr(x), _ptr(dy), _ptr(dw), _ptr(db_here), _ptr(db2),
+                    _ptr(ws), ws.numel(), S, Cin, Cout, H, W, m, st, tag=ctx.tag)
         elif ctx.needs_input_grad[1]:
             need = _lib.load().vf_conv_wgrad_ws_floats(S, Cin, Cout, H, W, KS)
             ws = _workspace(x.device, need)
-            dw = torch.empty(Cout, Cin, KS, KS, device=x.device, dtype=torch.float32)
+            dw = _gout(ctx.pw, Cout, Cin, KS, KS, like=x)
             _launch("conv_wgrad", ctx.flops, "vf_conv_wgrad", _ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), ws.numel(), S,
                     Cin, Cout, H, W, KS, m, st, tag=ctx.tag)
         if want_b or want_v:
             if (want_v and dvb is None) or (want_b and db is None and dvb is None):
                 if Cout >= 192:                  # one launch, one workgroup per channel (enough channels to fill the chip)
-                    db_new = torch.empty(Cout, device=x.device, dtype=torch.float32) if (want_b and db is None) else None
+                    db_new = _gout(ctx.pb, Cout, like=x) if (want_b and db is None) else None
                     dvb = torch.empty(S, Cout, device=x.device, dtype=torch.float32) if want_v else None
                     _lib.call("vf_bias_grad", _ptr(dy), _ptr(db_new), _ptr(dvb), S, Cout, H * W, st)
                     db = db_new if db_new is not None else db
@@ -485,17 +505,19 @@ class _Conv2dFn(torch.autograd.Function):
                     dvb = torch.empty(S, Cout, device=x.device, dtype=torch.float32)
                     _lib.call("vf_rowsum", _ptr(dy), _ptr(dvb), S * Cout, H * W, st)
             if want_b and db is None:
-                db = torch.empty(Cout, device=x.device, dtype=torch.float32)
+                db = _gout(ctx.pb, Cout, like=x)
                 _lib.call("vf_colsum", _ptr(dvb), _ptr(db), 1, S, Cout, st)
             if hr and want_b:                    # the residual branch (1x1 conv) receives this very dY
-                _rowsum_put(dy, dvb, db_twin if db_twin is not None else db)
+                # a tensor living in the gradient arena is all-reduced in place as soon as its segment is complete:
+                # it must never be handed to a second layer (which gets db2, or re-derives db from the row sums)
+                _rowsum_put(dy, dvb, db2 if (db2 is not None or arena) else db)
             if not want_b:
                 db = None
             if not want_v:
                 dvb = None
         if hr and ctx.needs_input_grad[4]:
             dres = dy
-        return dx, dw, db, dvb, dres, None, None, None
+        return dx, dw, db, dvb, dres, None, None, None, None
 
 
 class _Conv1x1CatFn(torch.autograd.Function):
@@ -514,6 +536,7 @@ class _Conv1x1CatFn(torch.autograd.Function):
                 _ptr(bias), _ptr(y), _ptr(ws), nws, S, Cin, Cout, H, W, _stream(), tag=(Cin, Cout, H, 1, 0))
         ctx.save_for_backward(x1, x2)
         ctx.wb, ctx.dims, ctx.has_bias = wb, (Cin, Cout), bias is not None
+        ctx.pw, ctx.pb = weight, bias
         return y
 
     @staticmethod
@@ -531,7 +554,7 @@ class _Conv1x1CatFn(torch.autograd.Function):
                     Cin, Cout, H, W, st, tag=tag)
         if ctx.needs_input_grad[2]:
             ws = _workspace(x1.device, _lib.load().vf_conv_wgrad_ws_floats(S, Cin, Cout, H, W, 1))
-            dw = torch.empty(Cout, Cin, 1, 1, device=x1.device, dtype=torch.float32)
+            dw = _gout(ctx.pw, Cout, Cin, 1, 1, like=x1)
             _launch("conv_wgrad", flops, "vf_conv1x1_cat_wgrad", _ptr(x1), _ptr(x2), C1, _ptr(dy), _ptr(dw), _ptr(ws),
                     ws.numel(), S, Cin, Cout, H, W, st, tag=tag)
         if ctx.has_bias and ctx.needs_input_grad[3]:
@@ -542,7 +565,7 @@ class _Conv1x1CatFn(torch.autograd.Function):
                 if dvb is None:
                     dvb = torch.empty(S, Cout, device=x1.device, dtype=torch.float32)
                     _lib.call("vf_rowsum", _ptr(dy), _ptr(dvb), S * Cout, H * W, st)
-                db = torch.empty(Cout, device=x1.device, dtype=torch.float32)
+                db = _gout(ctx.pb, Cout, like=x1)
                 _lib.call("vf_colsum", _ptr(dvb), _ptr(db), 1, S, Cout, st)
         return dx1, dx2, dw, db, None, None
 
@@ -553,14 +576,15 @@ def conv1x1_cat(x1, x2, layer):
     return _Conv1x1CatFn.apply(x1, x2, layer.weight, layer.bias, layer, training)
 
 
-def conv2d(x, layer, view_bias=None, residual=None, mode="same"):
+def conv2d(x, layer, view_bias=None, residual=None, mode="same", twin=None):
     """3x3 (pad 1) or 1x1 convolution with the parameters of `layer` (an nn.Conv2d holder).
 
     mode "same": stride 1; "down2": stride 2; "up2": nearest x2 upsample fused into the load.
-    Epilogue adds bias[c] + view_bias[s,c] + residual.
+    Epilogue adds bias[c] + view_bias[s,c] + residual.  twin: the 1x1 conv layer that produced `residual` (it has
+    the same bias gradient, which this layer's weight-gradient kernel then writes for both).
     """
     training = torch.is_grad_enabled() and layer.weight.requires_grad
-    return _Conv2dFn.apply(x, layer.weight, layer.bias, view_bias, residual, layer, mode, training)
+    return _Conv2dFn.apply(x, layer.weight, layer.bias, view_bias, residual, layer, mode, training, twin)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -578,6 +602,7 @@ class _LinearFn(torch.autograd.Function):
         y = torch.empty(S, O, device=x.device, dtype=torch.float32)
         _bgemm(x, w, y, b, 1, S, O, I, (0, I, 1), (0, 1, I), (0, O, 1))
         ctx.save_for_backward(x, w)
+        ctx.pw, ctx.pb = w, b
         return y
 
     @staticmethod
@@ -591,10 +616,10 @@ class _LinearFn(torch.autograd.Function):
             dx = torch.empty_like(x)
             _bgemm(dy, w, dx, None, 1, S, I, O, (0, O, 1), (0, I, 1), (0, I, 1))
         if ctx.needs_input_grad[1]:
-            dw = torch.empty_like(w)
+            dw = _gout(ctx.pw, O, I, like=x)
             _bgemm(dy, x, dw, None, 1, O, I, S, (0, 1, O), (0, I, 1), (0, I, 1))
         if ctx.needs_input_grad[2]:
-            db = torch.empty(O, device=x.device, dtype=torch.float32)
+            db = _gout(ctx.pb, O, like=x)
             _lib.call("vf_colsum", _ptr(dy), _ptr(db), 1, S, O, _stream())
         return dx, dw, db
 
@@ -607,6 +632,7 @@ def linear(x, weight, bias):
 # ---------------------------------------------------------------------------------------------
 # All FeatureWiseAffine linears of the UNet (30 x Linear(K -> C_g) on the SAME embedding) as one grouped launch.
 _TA_DESC = {}
+_TA_GDST = {}
 
 
 def _ta_desc(layers, S, device):
@@ -635,6 +661,7 @@ class _TimeAffineFn(torch.autograd.Function):
                   _stream())
         ctx.save_for_backward(emb)
         ctx.plan = (desc, Cs, coffs, CT)
+        ctx.params = params
         return tuple(out[S * o:S * (o + C)].view(S, C) for C, o in zip(Cs, coffs))
 
     @staticmethod
@@ -643,15 +670,33 @@ class _TimeAffineFn(torch.autograd.Function):
         desc, Cs, coffs, CT = ctx.plan
         S, K = emb.shape
         de = torch.cat([(g if g is not None else emb.new_zeros(S, C)).reshape(-1) for g, C in zip(grads, Cs)])
-        dw = torch.empty(CT, K, device=emb.device, dtype=torch.float32)
-        db = torch.empty(CT, device=emb.device, dtype=torch.float32)
+        slots = gdst = dw = db = None
+        arena = reducer.ACTIVE
+        if arena is not None:                       # every layer's dW / db straight into its arena slot
+            slots = [arena.slot(p) for p in ctx.params]
+            if any(t is None for t in slots):
+                slots = None
+            else:
+                key = (id(arena), arena.base)
+                hit = _TA_GDST.get(id(ctx.params[0]))
+                if hit is None or hit[0] != key:
+                    rows = [[slots[2 * g].data_ptr(), slots[2 * g + 1].data_ptr()] for g in range(len(Cs))]
+                    hit = (key, torch.tensor(rows, dtype=torch.int64).to(emb.device))
+                    _TA_GDST[id(ctx.params[0])] = hit
+                gdst = hit[1]
+        if slots is None:
+            dw = torch.empty(CT, K, device=emb.device, dtype=torch.float32)
+            db = torch.empty(CT, device=emb.device, dtype=torch.float32)
         demb = ws = None
         if ctx.needs_input_grad[0]:
             demb = torch.empty_like(emb)
             ws = torch.empty(_lib.load().vf_time_affine_ws_floats(S, K), device=emb.device, dtype=torch.float32)
         _lib.call("vf_time_affine_bwd", ctypes.c_void_p(desc.data_ptr()), len(Cs), _ptr(emb), _ptr(de), _ptr(dw),
-                  _ptr(db), _ptr(demb), _ptr(ws), S, K, CT, _stream())
+                  _ptr(db), ctypes.c_void_p(gdst.data_ptr()) if gdst is not None else None, _ptr(demb), _ptr(ws), S, K,
+                  CT, _stream())
         out = [demb, None]
+        if slots is not None:
+            return tuple(out + slots)
         for C, o in zip(Cs, coffs):
             out += [dw[o:o + C], db[o:o + C]]
         return tuple(out)

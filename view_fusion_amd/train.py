@@ -2,8 +2,10 @@
 
 Mirrors the reference's iteration semantics (experiment.py:90-120 model/optimizer/DDP setup,
 :265-293 the step: set LR -> zero_grad -> model(...) -> backward -> Adam.step) without its
-dataset, wandb and checkpoint plumbing.  One process per GPU; gradients are all-reduced by
-DistributedDataParallel over RCCL (backend "nccl" on ROCm).
+dataset, wandb and checkpoint plumbing.  One process per GPU; gradients are averaged over RCCL
+(backend "nccl" on ROCm) by the gradient arena of reducer.py -- the backward kernels write into the
+communication buffer, one all-reduce per segment overlaps the rest of the backward pass -- or, with
+VF_REDUCER=ddp, by torch's DistributedDataParallel as in the reference.
 """
 import math
 import os
@@ -12,6 +14,7 @@ import torch
 import torch.distributed as dist
 from torch.nn.parallel import DistributedDataParallel
 
+from . import reducer
 from .unet import UNet
 from .view_fusion import ViewFusion
 
@@ -71,7 +74,10 @@ class Trainer:
     def __init__(self, model, world=1, local_rank=0, lr_warmup=2500, decay_it=4000000, bucket_cap_mb=32):
         self.module = model
         self.model = model
-        if world > 1:
+        self.arena = None
+        if world > 1 and os.environ.get("VF_REDUCER", "arena") != "ddp":
+            self.arena = reducer.ACTIVE = reducer.GradArena(model, world)
+        elif world > 1:
             kw = dict(broadcast_buffers=False, gradient_as_bucket_view=True, bucket_cap_mb=bucket_cap_mb)
             if next(model.parameters()).is_cuda:
                 kw.update(device_ids=[local_rank], output_device=local_rank)
@@ -96,5 +102,7 @@ class Trainer:
         loss = self.model(y_0=batch["y_0"], y_cond=batch["y_cond"], view_count=batch["view_count"],
                           angle=batch["angle"], **extra)
         loss.backward()
+        if self.arena is not None:
+            self.arena.finish()
         self.opt.step()
         return loss

@@ -61,14 +61,15 @@ class _ResBlock(nn.Module):
             a, x1, x2 = ops.group_norm_cat_skip(x, skip, b1["0"].weight, b1["0"].bias, self.groups, silu=True)
             h = ops.conv2d(a, b1["3"], view_bias=e)
             a = ops.group_norm(h, b2["0"].weight, b2["0"].bias, self.groups, silu=True)
-            return ops.conv2d(a, b2["3"], residual=ops.conv1x1_cat(x1, x2, self.res_conv))
+            return ops.conv2d(a, b2["3"], residual=ops.conv1x1_cat(x1, x2, self.res_conv), twin=self.res_conv)
         # x feeds both the first GroupNorm and the residual branch: the GN op hands x back so that
         # the residual gradient is summed inside its backward kernel
         a, xs, xt = ops.group_norm_skip(x, b1["0"].weight, b1["0"].bias, self.groups, silu=True, tap=True)
         h = ops.conv2d(a, b1["3"], view_bias=e)
         a = ops.group_norm(h, b2["0"].weight, b2["0"].bias, self.groups, silu=True)
-        skip = xs if isinstance(self.res_conv, nn.Identity) else ops.conv2d(xs, self.res_conv)
-        y = ops.conv2d(a, b2["3"], residual=skip)
+        twin = None if isinstance(self.res_conv, nn.Identity) else self.res_conv
+        skip = xs if twin is None else ops.conv2d(xs, twin)
+        y = ops.conv2d(a, b2["3"], residual=skip, twin=twin)
         return (y, xt) if tap else y
 
 
