@@ -81,8 +81,7 @@ def pmc_traffic(kernel):
             d = tab[k]
             tot += (2 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0 * d["launches"]
             n += d["launches"]
-        return dict(bytes_per_launch=tot / n,
-                    source="profiles/r01_bench_pmc_traffic_kib_per_launch.json (rocprofv3 --pmc, separate passes)")
+        return tot / n
     except (OSError, KeyError, ZeroDivisionError):
         return None
 
@@ -114,6 +113,9 @@ def roofline(trainer, batch, steps=2):
                     "cores actually sustain is mfma_executed_frac",
                mfma_executed_tflops=x / s / 1e12, mfma_executed_frac=x / s / 1e12 / PEAK_FP32_MATRIX_TFLOPS,
                traffic=pmc_traffic(("wino_conv_kernel", "conv_mfma_kernel")),
+               traffic_unit="HBM bytes per launch (launch-weighted mean of the kernel family)",
+               traffic_source="profiles/r01_bench_pmc_traffic_kib_per_launch.json (rocprofv3 --pmc, FETCH_SIZE and "
+                              "WRITE_SIZE in separate passes, gfx950 corrections of MI355X_MICROARCH.md applied)",
                launches_per_step=n // steps,
                avg_launch_us=s / n * 1e6, algorithmic_gflop_per_launch=f / n / 1e9)
     out["other_kernels"] = {k: dict(achieved_tflops=v[0] / v[1] / 1e12, mfma_executed_tflops=v[3] / v[1] / 1e12,
