@@ -52,8 +52,10 @@ class GradArena:
         self.copied = 0                                       # gradients not born in their slot (stats, per step)
         for i, p in enumerate(self.params):
             p.register_post_accumulate_grad_hook(functools.partial(self._ready, i))
+        dev = self.params[0].device
         for t in list(module.parameters()) + list(module.buffers()):      # rank 0's state everywhere (as DDP does)
-            dist.broadcast(t.data, 0, group=self.group)
+            if t.device == dev:
+                dist.broadcast(t.data, 0, group=self.group)
 
     # -- layout -------------------------------------------------------------------------------------------------
     def _lay_out(self):
