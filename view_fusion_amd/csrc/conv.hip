@@ -845,11 +845,17 @@ __global__ void conv_splitk_reduce_kernel(const float4* __restrict__ ws, const f
     y[i] = make_float4(v.x + b, v.y + b, v.z + b, v.w + b);
 }
 
-// Split-K factor: only when the natural grid cannot fill the chip (small S: the sampler).
+// Split-K factor: only when the natural grid cannot fill the chip (small S: the sampler).  Measured over the
+// sampler's layer shapes at S = 1 / 6 / 12 (tools/small_conv.py): the fastest split is the largest one that still
+// gives every workgroup a CU of its own in a single round (nblk * k <= 256) -- a second round, or more partial
+// sums than that for the reduce kernel to add up (k > 16), costs more than the shorter K loop saves.
 inline int choose_ksplit(int nblk, int nchunks) {
-    if (nblk >= 384 || nchunks < 2) return 1;
-    int k = (768 + nblk - 1) / nblk;
-    return k < nchunks ? k : nchunks;
+    static const int budget = [] { const char* e = getenv("VF_CONV_KSPLIT_WGS"); return e ? atoi(e) : 256; }();
+    if (nblk >= budget || nchunks < 2) return 1;
+    int k = budget / nblk;
+    if (k > 16) k = 16;
+    if (k > nchunks) k = nchunks;
+    return k < 1 ? 1 : k;
 }
 
 template <int KS, int LOGW, int MODE, int NPT, int NCO = 1>
@@ -1053,7 +1059,6 @@ int vf_conv1x1_cat_dgrad(const float* dy, const float* w_packed_bwd, float* dx1,
 long vf_conv_fwd_ws_floats(int S, int Cin, int Cout, int H, int W, int KS) {
     const long tiles64 = ((long)S * H * W + 63) / 64;
     const long nblk_min = ((long)S * H * W + 127) / 128 * (round_up(Cout, TCO) / TCO);
-    if (nblk_min >= 384) return 0;
     (void)tiles64;
     const int nch = round_up(Cin, KS == 3 ? 8 : 32) / (KS == 3 ? 8 : 32);
     const int ks = choose_ksplit((int)nblk_min, nch);
