@@ -260,10 +260,12 @@ def test_linear_swish_embed(dev):
     assert float((got.cpu() - ref).abs().max()) < 2e-6
 
 
-@pytest.mark.parametrize("C,H", [(192, 16), (320, 8), (64, 8)])
-def test_attention_fwd_bwd(dev, C, H):
+@pytest.mark.parametrize("C,H,S", [(192, 16, 3), (320, 8, 3), (64, 8, 3), (192, 16, 34), (96, 16, 33)])
+def test_attention_fwd_bwd(dev, C, H, S):
+    """S <= 32 at L=256 and every L=64 call run the key-split kernel (32 queries per workgroup, one wave per 32
+    keys); more views at L=256 run the 128-query kernel (the training shape)."""
     from view_fusion_amd import ops
-    S, L = 3, H * H
+    L = H * H
     qkv, gy = rnd(S, 3 * C, H, H, seed=1) * 2, rnd(S, C, H, H, seed=2)
     qc = qkv.clone().requires_grad_(True)
     q, k, v = qc.reshape(S, 3, C, L).unbind(1)
@@ -276,11 +278,12 @@ def test_attention_fwd_bwd(dev, C, H):
     assert rel(qg.grad, qc.grad) < 5e-5
 
 
-@pytest.mark.parametrize("C,H", [(192, 16), (320, 8), (32, 32)])
-def test_attention_inference_path(dev, C, H):
-    """no-grad call: fused kernel without the probability write (L=64/256) / generic path (L=1024)."""
+@pytest.mark.parametrize("C,H,S", [(192, 16, 2), (320, 8, 2), (32, 32, 2), (192, 16, 12), (192, 16, 40), (320, 8, 40)])
+def test_attention_inference_path(dev, C, H, S):
+    """no-grad call: fused kernels without the probability write (L=64/256, both view-count regimes) / generic
+    path (L=1024)."""
     from view_fusion_amd import ops
-    S, L = 2, H * H
+    L = H * H
     qkv = rnd(S, 3 * C, H, H, seed=3) * 2
     q, k, v = qkv.reshape(S, 3, C, L).unbind(1)
     p = torch.softmax(torch.bmm(q.transpose(1, 2), k) / math.sqrt(C), -1)

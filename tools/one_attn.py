@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Time vf_attention_fwd for the UNet's two attention shapes at sampler and training batch sizes, and check it
-against a torch fp32 formula.   python tools/one_attn.py   (VF_ATTN_OLD=1 selects the one-wave-per-query-block kernel)"""
+against a torch fp32 formula.   python tools/one_attn.py"""
 import os
 import sys
 

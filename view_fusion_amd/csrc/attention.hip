@@ -13,7 +13,6 @@
 // K/Q are staged through LDS in 16-channel chunks, V in 32-channel tiles.
 // Optionally writes P (S,L,L) for the backward pass.  Bound: fp32 MFMA.
 #include "common.h"
-#include <cstdlib>
 
 namespace {
 
@@ -309,15 +308,12 @@ int vf_attention_fwd(const float* qkv, float* out, float* P, int S, int C, int L
     hipStream_t st = (hipStream_t)stream;
     // few views (sampler): the key-split kernel cuts the per-wave MFMA chain 8-fold; many views (training): it
     // would re-stream K and V once per 32 queries (L2-bound), the 128-query kernel wins from S ~ 50 on
-    static const bool old = getenv("VF_ATTN_OLD") != nullptr;
-    if (L == 256 && !old && S <= 32)
+    if (L == 256 && S <= 32)
         hipLaunchKernelGGL(attn_fwd_split_kernel<256>, dim3(8, S), dim3(512), 0, st, qkv, out, P, C, alpha);
-    else if (L == 64 && !old)
+    else if (L == 64)
         hipLaunchKernelGGL(attn_fwd_split_kernel<64>, dim3(2, S), dim3(128), 0, st, qkv, out, P, C, alpha);
     else if (L == 256)
         hipLaunchKernelGGL(attn_fwd_kernel<256>, dim3(2, S), dim3(256), 0, st, qkv, out, P, C, alpha);
-    else if (L == 64)
-        hipLaunchKernelGGL(attn_fwd_kernel<64>, dim3(1, S), dim3(128), 0, st, qkv, out, P, C, alpha);
     else
         return (int)hipErrorInvalidValue;
     VF_RETURN_LAST_ERROR();
