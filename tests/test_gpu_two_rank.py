@@ -1,0 +1,120 @@
+"""SURVEY 8(e) on real kernels: two ranks (two processes sharing the one GPU of the box, gloo as the transport --
+RCCL refuses two ranks on one device) train the HIP model through the gradient arena; the averaged gradients of
+every iteration must equal single-process gradients on the concatenated batch, on the copy path (first
+iteration) and on the zero-copy path (backward kernels writing into the all-reduce buffer while earlier
+segments are already being reduced), and the replicas must stay bit-identical under Adam.  RCCL itself is
+exercised with a world of one rank in test_gpu_model.py and by bench.py --gpus N on a multi-GPU node."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from conftest import TINY
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SCHED = dict(schedule="linear", num_timesteps=2000, linear_start=1e-6, linear_end=1e-2)
+B, N, HW, STEPS = 12, 6, 16, 3
+
+
+def _batch(step, rank):
+    g = torch.Generator().manual_seed(100 * step + rank)
+    return dict(y_0=torch.rand(B, 3, HW, HW, generator=g), y_cond=torch.rand(B, N, 3, HW, HW, generator=g),
+                angle=2 * np.pi / 24 * torch.randint(0, 24, (B, 1), generator=g).float(),
+                view_count=torch.randint(1, N + 1, (B,), generator=g),
+                noise=torch.randn(B, 3, HW, HW, generator=g), t=torch.randint(1, 2000, (B,), generator=g),
+                u=torch.rand(B, 1, generator=g))
+
+
+def _to(b, dev):
+    return {k: (v if k == "view_count" else v.to(dev)) for k, v in b.items()}
+
+
+def _model(dev):
+    from view_fusion_amd import UNet, ViewFusion
+    from view_fusion_amd.utils import deterministic_fill_
+    net = UNet(**TINY)
+    deterministic_fill_(net.state_dict())
+    vf = ViewFusion(net.to(dev), {"train": SCHED}, True, True)
+    vf.set_new_noise_schedule(device=dev, phase="train")
+    return vf
+
+
+def _run(tr, vf, batches, dev):
+    grads = []
+    for b in batches:
+        b = _to(b, dev)
+        extra = {k: b.pop(k) for k in ("noise", "t", "u")}
+        if tr.arena is not None:
+            tr.arena.copied = 0
+        tr.step(b, **extra)
+        grads.append([p.grad.detach().cpu().clone() for p in vf.parameters()])
+    return grads
+
+
+def _worker(rank, world, port, out, lr):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from view_fusion_amd import train
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    vf = _model(dev)
+    tr = train.Trainer(vf, world=world, lr_warmup=1)
+    tr.it, tr.sched.peak_lr = 0, lr
+    copied = []
+    grads = []
+    for s in range(STEPS):
+        grads += _run(tr, vf, [_batch(s, rank)], dev)
+        copied.append(tr.arena.copied)
+    out[rank] = dict(grads=grads, copied=copied, params=[p.detach().cpu().clone() for p in vf.parameters()])
+    dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _spawn(lr):
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(2, _free_port(), out, lr), nprocs=2, join=True)
+    return out[0], out[1]
+
+
+def test_two_rank_arena_gradients_match_the_global_batch():
+    from view_fusion_amd import train
+    r0, r1 = _spawn(lr=0.0)                       # lr 0: every iteration starts from the same parameters
+    assert r0["copied"][1:] == [0] * (STEPS - 1) and r1["copied"][1:] == [0] * (STEPS - 1), (r0["copied"], r1["copied"])
+    dev = torch.device("cuda:0")
+    vf = _model(dev)
+    tr = train.Trainer(vf, world=1, lr_warmup=1)
+    tr.it, tr.sched.peak_lr = 0, 0.0
+    glob = []
+    for s in range(STEPS):
+        a, b = _batch(s, 0), _batch(s, 1)
+        glob.append({k: torch.cat([a[k], b[k]]) for k in a})
+    ref = _run(tr, vf, glob, dev)
+    names = [k for k, _ in vf.named_parameters()]
+    for s in range(STEPS):
+        for k, g0, g1, gr in zip(names, r0["grads"][s], r1["grads"][s], ref[s]):
+            assert torch.equal(g0, g1), (s, k)                       # both ranks hold the same average
+            err = float((g0.double() - gr.double()).norm())
+            assert err <= 2e-5 * float(gr.double().norm()) + 1e-7 * gr.numel() ** 0.5, (s, k, err)
+
+
+def test_two_rank_arena_replicas_stay_in_lock_step():
+    r0, r1 = _spawn(lr=1e-4)
+    for a, b in zip(r0["params"], r1["params"]):
+        assert torch.equal(a, b)
+    moved = max(float((a - b).abs().max()) for a, b in zip(r0["params"], [p.detach().cpu() for p in _model(torch.device("cuda:0")).parameters()]))
+    assert moved > 1e-5                           # and the parameters really were updated
