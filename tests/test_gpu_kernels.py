@@ -260,9 +260,9 @@ def test_linear_swish_embed(dev):
     assert float((got.cpu() - ref).abs().max()) < 2e-6
 
 
-@pytest.mark.parametrize("C,H,S", [(192, 16, 3), (320, 8, 3), (64, 8, 3), (192, 16, 34), (96, 16, 33)])
+@pytest.mark.parametrize("C,H,S", [(192, 16, 3), (320, 8, 3), (64, 8, 3), (192, 16, 56), (96, 16, 53)])
 def test_attention_fwd_bwd(dev, C, H, S):
-    """S <= 32 at L=256 and every L=64 call run the key-split kernel (32 queries per workgroup, one wave per 32
+    """S <= 52 at L=256 and every L=64 call run the key-split kernel (32 queries per workgroup, one wave per 32
     keys); more views at L=256 run the 128-query kernel (the training shape)."""
     from view_fusion_amd import ops
     L = H * H
@@ -278,7 +278,7 @@ def test_attention_fwd_bwd(dev, C, H, S):
     assert rel(qg.grad, qc.grad) < 5e-5
 
 
-@pytest.mark.parametrize("C,H,S", [(192, 16, 2), (320, 8, 2), (32, 32, 2), (192, 16, 12), (192, 16, 40), (320, 8, 40)])
+@pytest.mark.parametrize("C,H,S", [(192, 16, 2), (320, 8, 2), (32, 32, 2), (192, 16, 12), (192, 16, 40), (192, 16, 60), (320, 8, 40)])
 def test_attention_inference_path(dev, C, H, S):
     """no-grad call: fused kernels without the probability write (L=64/256, both view-count regimes) / generic
     path (L=1024)."""

@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Diagnostic: per-workgroup phase clocks of attn_fwd_kh_kernel (S views, L=256, C=192).  usage: attn_stamps.py [S]"""
+import ctypes, os, subprocess, sys
+import numpy as np
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+so = os.path.join(ROOT, "build", "libvf_attn_stamps.so")
+if not os.path.exists(so):
+    os.makedirs(os.path.dirname(so), exist_ok=True)
+    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-DVF_ATTN_STAMPS", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "view_fusion_amd/csrc/attention.hip"), "-o", so], check=True)
+if len(sys.argv) > 1 and sys.argv[1] == "build":
+    sys.exit(0)
+S = int(sys.argv[1]) if len(sys.argv) > 1 else 96
+L, C = 256, 192
+lib = ctypes.CDLL(so)
+P, I = ctypes.c_void_p, ctypes.c_int
+lib.vf_attention_fwd.argtypes = [P, P, P, I, I, I, P]
+dev = torch.device("cuda:0")
+qkv = torch.randn(S, 3 * C, L, device=dev)
+out = torch.empty(S, C, L, device=dev)
+stamps = torch.zeros(S * L * L // 2, dtype=torch.int64, device=dev)
+st = torch.cuda.current_stream().cuda_stream
+for _ in range(5):
+    assert lib.vf_attention_fwd(qkv.data_ptr(), out.data_ptr(), stamps.data_ptr(), S, C, L, st) == 0
+torch.cuda.synchronize()
+a = stamps.cpu().numpy()[: 2 * S * 8].reshape(-1, 8)
+life = (a[:, 7] - a[:, 6]) / 100e6
+tot = (a[:, 4] - a[:, 0]).astype(float)
+wall = (a[:, 7].max() - a[:, 6].min()) / 100e6
+print(f"S={S}: {len(a)} WGs, wall {wall * 1e6:.1f} us, WG life {life.mean() * 1e6:.1f} us (min {life.min() * 1e6:.1f} max {life.max() * 1e6:.1f}), "
+      f"shader clock {np.median(tot / life) / 1e9:.2f} GHz")
+ph = [(a[:, i + 1] - a[:, i]).mean() for i in range(4)]
+print(f"  cycles/WG: total {tot.mean():.0f} = QK {ph[0]:.0f} + softmax {ph[1]:.0f} + (P write skipped) {ph[2]:.0f} + PV {ph[3]:.0f};  "
+      f"MFMA issue floor per SIMD: QK {2 * 12 * 8 * 4 * 64} + PV {2 * 6 * 16 * 4 * 64}")

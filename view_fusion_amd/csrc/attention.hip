@@ -1,125 +1,154 @@
 // Fused single-head spatial self-attention forward (reference model/unet.py:258-277, the core
 // between the qkv and out 1x1 convs):   O[c][i] = sum_j V[c][j] * softmax_j(Q[:,i].K[:,j] / sqrt(C))
 //
-// One workgroup = one view x 128 queries (4 waves x 32 queries; 64 queries / 2 waves at L=64).
-// Orientation: S^T = K^T Q on v_mfma_f32_32x32x2_f32 with A = K^T (row = key), B = Q (col = query):
+// Orientation (both kernels): S^T = K^T Q on v_mfma_f32_32x32x2_f32 with A = K^T (row = key), B = Q (col = query):
 // every lane owns ONE query column, its keys sit in the accumulator registers.  So
-//   * the row softmax is in-register (max / sum over the lane's registers + one cross-half
-//     shuffle), scores never leave the register file (L <= 256 -> <= 128 accumulators / lane);
-//   * the probabilities are directly the B operand of the second product O = V P^T (their
-//     accumulator row order is taken as the k order, V is fetched in that order with one
-//     ds_read_b128 per four MFMAs);
+//   * the row softmax is in-register (max / sum over the lane's registers + one cross-half shuffle, then the
+//     statistics of the waves sharing the query block through LDS); scores never leave the register file;
+//   * the probabilities are the B operand of the second product O = V P^T: the accumulator row order is taken as
+//     the k order, V is fetched in that order with one 16-byte read per four MFMAs;
 //   * O comes out with the query on the lane -> coalesced NCHW stores.
-// K/Q are staged through LDS in 16-channel chunks, V in 32-channel tiles.
 // Optionally writes P (S,L,L) for the backward pass.  Bound: fp32 MFMA.
+//   attn_fwd_kh_kernel        L = 256, many views (training): 128 queries per workgroup, 8 waves = 4 query blocks x
+//                             2 key halves; K/Q chunks and V tiles double-buffered in LDS
+//   attn_fwd_split_kernel<L>  few views (sampler) and L = 64: 32 queries per workgroup, one wave per 32 keys
 #include "common.h"
 
 namespace {
 
-template <int L>
-__global__ __launch_bounds__(L >= 128 ? 256 : 128) void attn_fwd_kernel(const float* __restrict__ qkv,
-                                                                        float* __restrict__ out,
-                                                                        float* __restrict__ P, int C, float alpha) {
-    constexpr int NW = L >= 128 ? 4 : 2;
-    constexpr int NTH = NW * 64;
-    constexpr int QW = NW * 32;
-    constexpr int NKT = L / 32;
-    constexpr int CKA = 16;
-    constexpr int RSV = L + 4;
-    constexpr int LDS1 = CKA * L + CKA * QW, LDS3 = 32 * RSV;
-    __shared__ __attribute__((aligned(16))) float lds[LDS1 > LDS3 ? LDS1 : LDS3];
-    float* const Kl = lds;
-    float* const Ql = lds + CKA * L;
-    float* const Vl = lds;
+// Many views (training), L = 256: one workgroup = one view x 128 queries = 4 query blocks of 32, each shared by
+// TWO waves that own half of the keys -- 8 waves, two per SIMD, so a SIMD interleaves two 23 us MFMA chains (one
+// wave per query block with all 256 keys, 4 waves per workgroup, measured 73 us per launch at S = 96; this
+// kernel 66 us).  K and V are streamed once per 128 queries (2 x S workgroups).  K/Q chunks and V tiles are double-buffered in LDS (ONE barrier per chunk / tile: the next
+// one is written while this one feeds the MFMAs).  Softmax statistics of the two key halves are combined through
+// LDS; the partial O tiles of the upper half are handed to the lower-half wave through a double-buffered LDS
+// slot, one channel tile behind the MFMAs.
+__global__ __launch_bounds__(512) void attn_fwd_kh_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                          float* __restrict__ P, int C, float alpha) {
+    constexpr int L = 256, NTH = 512, QW = 128, NKT = 4, CKA = 16, RSV = L + 4;
+    constexpr int KS = L + 32;                       // K row stride: the two lane halves hit different banks
+    constexpr int KQ = CKA * KS + CKA * QW, VT = 32 * RSV;
+    __shared__ __attribute__((aligned(16))) float lds[2 * (KQ > VT ? KQ : VT)];
+    __shared__ float oex[2][4][16][64];
+    __shared__ float red[2][2][QW];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
+    const int qb = wid & 3, kh = wid >> 2;           // waves w and w+4 (same SIMD) share a query block
     const int b = blockIdx.y, q0 = blockIdx.x * QW;
-    const float* qb = qkv + (size_t)b * 3 * C * L;
-    const float* kb = qb + (size_t)C * L;
-    const float* vb = qb + (size_t)2 * C * L;
+    const float* qp = qkv + (size_t)b * 3 * C * L;
+    const float* kp = qp + (size_t)C * L;
+    const float* vp = qp + (size_t)2 * C * L;
 
+#ifdef VF_ATTN_STAMPS   // diagnostic build only (tools/attn_stamps.py): phase clocks of wave 0, in the P slot
+    long long st_[6] = {clock64(), 0, 0, 0, 0, 0}, rt0_ = wall_clock64();
+#endif
     f32x16 acc[NKT];
 #pragma unroll
     for (int t = 0; t < NKT; ++t) acc[t] = (f32x16){0};
 
-    // K / Q chunk staging: all loads of a chunk are issued together into registers, one chunk ahead of their use
-    // (a `*lds = *global` loop compiles to load -> wait -> store per element: six serial round trips per chunk)
-    constexpr int NK4 = CKA * L / 4 / NTH, NQ4 = CKA * QW / 4 / NTH;
-    static_assert(NK4 * NTH * 4 == CKA * L && NQ4 * NTH * 4 == CKA * QW, "whole passes");
-    // (named registers: the array form of these staging sets is not promoted out of scratch memory)
-    float4 kr0, kr1, kr2, kr3, qr0, qr1;
-    kr0 = kr1 = kr2 = kr3 = qr0 = qr1 = make_float4(0.f, 0.f, 0.f, 0.f);
-    static_assert(NK4 <= 4 && NQ4 <= 2, "staging register sets");
-#define VF_AT_LK(I, C0) if constexpr ((I) < NK4) { const int e = tid + (I) * NTH;                          \
-        kr##I = *reinterpret_cast<const float4*>(kb + (size_t)((C0) + e / (L / 4)) * L + 4 * (e % (L / 4))); }
-#define VF_AT_LQ(I, C0) if constexpr ((I) < NQ4) { const int e = tid + (I) * NTH;                          \
-        qr##I = *reinterpret_cast<const float4*>(qb + (size_t)((C0) + e / (QW / 4)) * L + q0 + 4 * (e % (QW / 4))); }
-#define VF_AT_SK(I) if constexpr ((I) < NK4) { const int e = tid + (I) * NTH;                               \
-        *reinterpret_cast<float4*>(Kl + (e / (L / 4)) * L + 4 * (e % (L / 4))) = kr##I; }
-#define VF_AT_SQ(I) if constexpr ((I) < NQ4) { const int e = tid + (I) * NTH;                               \
-        *reinterpret_cast<float4*>(Ql + (e / (QW / 4)) * QW + 4 * (e % (QW / 4))) = qr##I; }
-#define VF_AT_LOAD(C0) { VF_AT_LK(0, C0) VF_AT_LK(1, C0) VF_AT_LK(2, C0) VF_AT_LK(3, C0) VF_AT_LQ(0, C0) VF_AT_LQ(1, C0) }
-    VF_AT_LOAD(0);
-    for (int c0 = 0; c0 < C; c0 += CKA) {
-        __syncthreads();
-        VF_AT_SK(0) VF_AT_SK(1) VF_AT_SK(2) VF_AT_SK(3) VF_AT_SQ(0) VF_AT_SQ(1)
-        __syncthreads();
-        VF_AT_LOAD(min(c0 + CKA, C - CKA));              // next chunk (clamped: the last one is re-read, unused)
+    // K chunk = 16 x 256 floats = 1024 float4 (2 per thread), Q chunk = 16 x 128 = 512 float4 (1 per thread);
+    // (32-channel chunks, i.e. half the barriers, measured 2 % slower)
+    float4 kr0, kr1, qr;
+#define VF_AK_LOAD(C0) {                                                                                    \
+        kr0 = *reinterpret_cast<const float4*>(kp + (size_t)((C0) + tid / 64) * L + 4 * (tid % 64));          \
+        kr1 = *reinterpret_cast<const float4*>(kp + (size_t)((C0) + 8 + tid / 64) * L + 4 * (tid % 64));      \
+        qr = *reinterpret_cast<const float4*>(qp + (size_t)((C0) + tid / 32) * L + q0 + 4 * (tid % 32)); }
+#define VF_AK_STORE(BUF) { float* kl_ = lds + (BUF) * KQ;                                                    \
+        *reinterpret_cast<float4*>(kl_ + (tid / 64) * KS + 4 * (tid % 64)) = kr0;                             \
+        *reinterpret_cast<float4*>(kl_ + (8 + tid / 64) * KS + 4 * (tid % 64)) = kr1;                         \
+        *reinterpret_cast<float4*>(kl_ + CKA * KS + (tid / 32) * QW + 4 * (tid % 32)) = qr; }
+    VF_AK_LOAD(0);
+    VF_AK_STORE(0);
+    VF_AK_LOAD(min(CKA, C - CKA));
+    __syncthreads();
+    for (int c0 = 0, cur = 0; c0 < C; c0 += CKA, cur ^= 1) {
+        VF_AK_STORE(cur ^ 1);                            // next chunk (its buffer was last read before the barrier)
+        VF_AK_LOAD(min(c0 + 2 * CKA, C - CKA));          // the one after (clamped: re-reads the last one, unused)
+        const float* Kl = lds + cur * KQ;
+        const float* Ql = Kl + CKA * KS;
+        // operand fragments of step s + 1 are read from LDS before the MFMAs of step s are issued
+        const float* kq = Kl + lh * KS + kh * NKT * 32 + li;
+        const float* qq = Ql + lh * QW + qb * 32 + li;
+        float bq = qq[0], ak0 = kq[0], ak1 = kq[32], ak2 = kq[64], ak3 = kq[96];
 #pragma unroll
         for (int s = 0; s < CKA / 2; ++s) {
-            const float bq = Ql[(2 * s + lh) * QW + wid * 32 + li];
-#pragma unroll
-            for (int t = 0; t < NKT; ++t) {
-                const float ak = Kl[(2 * s + lh) * L + t * 32 + li];
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ak, bq, acc[t], 0, 0, 0);
+            float bqn = bq, an0 = ak0, an1 = ak1, an2 = ak2, an3 = ak3;
+            if (s + 1 < CKA / 2) {
+                bqn = qq[(2 * s + 2) * QW];
+                an0 = kq[(2 * s + 2) * KS];
+                an1 = kq[(2 * s + 2) * KS + 32];
+                an2 = kq[(2 * s + 2) * KS + 64];
+                an3 = kq[(2 * s + 2) * KS + 96];
             }
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ak0, bq, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ak1, bq, acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(ak2, bq, acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(ak3, bq, acc[3], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            bq = bqn; ak0 = an0; ak1 = an1; ak2 = an2; ak3 = an3;
         }
+        __syncthreads();
     }
-#undef VF_AT_LOAD
-#undef VF_AT_LK
-#undef VF_AT_LQ
-#undef VF_AT_SK
-#undef VF_AT_SQ
-    // first V chunk: requested now, lands while the softmax is computed
-    constexpr int NV4 = 32 * L / 4 / NTH;
-    static_assert(NV4 * NTH * 4 == 32 * L, "whole passes");
-    static_assert(NV4 <= 8, "staging register set");
-    float4 vr0, vr1, vr2, vr3, vr4, vr5, vr6, vr7;
-    vr0 = vr1 = vr2 = vr3 = vr4 = vr5 = vr6 = vr7 = make_float4(0.f, 0.f, 0.f, 0.f);
-#define VF_AT_LV(I, C0) if constexpr ((I) < NV4) { const int e = tid + (I) * NTH;                          \
-        vr##I = *reinterpret_cast<const float4*>(vb + (size_t)((C0) + e / (L / 4)) * L + 4 * (e % (L / 4))); }
-#define VF_AT_SV(I) if constexpr ((I) < NV4) { const int e = tid + (I) * NTH;                               \
-        *reinterpret_cast<float4*>(Vl + (e / (L / 4)) * RSV + 4 * (e % (L / 4))) = vr##I; }
-#define VF_AT_LOADV(C0) { VF_AT_LV(0, C0) VF_AT_LV(1, C0) VF_AT_LV(2, C0) VF_AT_LV(3, C0) VF_AT_LV(4, C0) VF_AT_LV(5, C0) VF_AT_LV(6, C0) VF_AT_LV(7, C0) }
-    VF_AT_LOADV(0);
+#undef VF_AK_LOAD
+#undef VF_AK_STORE
+#ifdef VF_ATTN_STAMPS
+    st_[1] = clock64();
+#endif
+    // V tiles (32 channels x 256 keys = 2048 float4, 4 per thread): tile 0 is requested now and lands during the
+    // softmax
+    float4 vr0, vr1, vr2, vr3;
+#define VF_AK_LV(I, C0) { const int e = tid + (I) * NTH;                                                   \
+        vr##I = *reinterpret_cast<const float4*>(vp + (size_t)((C0) + e / 64) * L + 4 * (e % 64)); }
+#define VF_AK_SV(I, BUF) { const int e = tid + (I) * NTH;                                                   \
+        *reinterpret_cast<float4*>(lds + (BUF) * VT + (e / 64) * RSV + 4 * (e % 64)) = vr##I; }
+#define VF_AK_LOADV(C0) { VF_AK_LV(0, C0) VF_AK_LV(1, C0) VF_AK_LV(2, C0) VF_AK_LV(3, C0) }
+#define VF_AK_STOREV(BUF) { VF_AK_SV(0, BUF) VF_AK_SV(1, BUF) VF_AK_SV(2, BUF) VF_AK_SV(3, BUF) }
+    VF_AK_LOADV(0);
 
-    // softmax over keys: this lane's query, keys in registers (+ the other lane half)
+    // softmax over all keys of the lane's query: this wave's 128 keys, then the partner wave's statistics
+    const int ql = qb * 32 + li;
     float mx = -INFINITY;
 #pragma unroll
     for (int t = 0; t < NKT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) mx = fmaxf(mx, acc[t][r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    if (lh == 0) red[0][kh][ql] = mx;
+    __syncthreads();
+    mx = fmaxf(red[0][0][ql], red[0][1][ql]);
+    // exp(alpha (s - max)) as ONE v_exp_f32 per score: 2^(c s - c max), c = alpha log2(e); the argument is <= 0, so
+    // the range handling of expf() has nothing to do
+    const float c2 = alpha * 1.44269504088896341f, mc = mx * c2;
     float sum = 0.f;
 #pragma unroll
     for (int t = 0; t < NKT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float p = expf(alpha * (acc[t][r] - mx));
+            const float p = __builtin_amdgcn_exp2f(fmaf(acc[t][r], c2, -mc));
             acc[t][r] = p;
             sum += p;
         }
     sum += __shfl_xor(sum, 32, 64);
-    const float inv = 1.0f / sum;
+    if (lh == 0) red[1][kh][ql] = sum;
+    VF_AK_STOREV(0);                                     // (the K/Q buffers are dead since the loop's last barrier)
+    VF_AK_LOADV(min(32, C - 32));
+    __syncthreads();
+    const float inv = 1.0f / (red[1][0][ql] + red[1][1][ql]);
 #pragma unroll
     for (int t = 0; t < NKT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] *= inv;
 
-    const int qi = q0 + wid * 32 + li;
+    const int qi = q0 + ql;
+#ifdef VF_ATTN_STAMPS
+    st_[2] = clock64();
+    if (false) {
+#else
     if (P) {
-        float* pr = P + ((size_t)b * L + qi) * L;
+#endif
+        float* pr = P + ((size_t)b * L + qi) * L + kh * NKT * 32;
 #pragma unroll
         for (int t = 0; t < NKT; ++t)
 #pragma unroll
@@ -127,39 +156,75 @@ __global__ __launch_bounds__(L >= 128 ? 256 : 128) void attn_fwd_kernel(const fl
                 *reinterpret_cast<float4*>(pr + t * 32 + 8 * g + 4 * lh) =
                     make_float4(acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]);
     }
+#ifdef VF_ATTN_STAMPS
+    st_[3] = clock64();
+#endif
 
-    for (int c0 = 0; c0 < C; c0 += 32) {
-        __syncthreads();
-        VF_AT_SV(0) VF_AT_SV(1) VF_AT_SV(2) VF_AT_SV(3) VF_AT_SV(4) VF_AT_SV(5) VF_AT_SV(6) VF_AT_SV(7)
-        __syncthreads();
-        VF_AT_LOADV(min(c0 + 32, C - 32));               // next chunk, issued before this chunk's output stores
+    // O = V P^T, one 32-channel tile per iteration: tile c0 feeds the MFMAs from V buffer `cur` while tile c0 + 32
+    // is written to the other buffer; the upper-half wave's partial tile goes to oex[cur] and is added and stored
+    // by its partner at the top of the next iteration
+    f32x16 oprev = {0};
+    for (int c0 = 0, cur = 0; c0 < C; c0 += 32, cur ^= 1) {
+        if (kh == 0 && c0 > 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int c = c0 - 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                out[((size_t)b * C + c) * L + qi] = oprev[r] + oex[cur ^ 1][qb][r][lane];
+            }
+        }
+        VF_AK_STOREV(cur ^ 1);                           // tile c0 + 32
+        VF_AK_LOADV(min(c0 + 64, C - 32));               // tile c0 + 64 (clamped)
+        const float* Vl = lds + cur * VT;
         f32x16 o = {0};
+        const float* vq = Vl + li * RSV + kh * NKT * 32 + 4 * lh;
+        float4 av = *reinterpret_cast<const float4*>(vq);
 #pragma unroll
         for (int t = 0; t < NKT; ++t)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const float4 av = *reinterpret_cast<const float4*>(Vl + li * RSV + t * 32 + 8 * g + 4 * lh);
+                float4 avn = av;
+                if (t * 4 + g + 1 < NKT * 4) avn = *reinterpret_cast<const float4*>(vq + (t * 4 + g + 1) * 8);
+                __builtin_amdgcn_sched_barrier(0);
                 o = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, acc[t][4 * g + 0], o, 0, 0, 0);
                 o = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, acc[t][4 * g + 1], o, 0, 0, 0);
                 o = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, acc[t][4 * g + 2], o, 0, 0, 0);
                 o = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, acc[t][4 * g + 3], o, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                av = avn;
             }
+        if (kh == 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oex[cur][qb][r][lane] = o[r];
+        } else {
+            oprev = o;
+        }
+        __syncthreads();
+    }
+    if (kh == 0) {                                       // last tile (its oex slot is (C / 32 - 1) & 1)
+        const int last = (C / 32 - 1) & 1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int c = c0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            out[((size_t)b * C + c) * L + qi] = o[r];
+            const int c = C - 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            out[((size_t)b * C + c) * L + qi] = oprev[r] + oex[last][qb][r][lane];
         }
     }
-#undef VF_AT_LOADV
-#undef VF_AT_LV
-#undef VF_AT_SV
+#undef VF_AK_LOADV
+#undef VF_AK_STOREV
+#undef VF_AK_LV
+#undef VF_AK_SV
+#ifdef VF_ATTN_STAMPS
+    if (tid == 0 && P) {
+        long long* o = reinterpret_cast<long long*>(P) + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8;
+        o[0] = st_[0]; o[1] = st_[1]; o[2] = st_[2]; o[3] = st_[3]; o[4] = clock64(); o[5] = 0;
+        o[6] = rt0_; o[7] = wall_clock64();
+    }
+#endif
 }
 
-
-// Key-split variant: one workgroup = one view x 32 queries, wave w owns keys [32w, 32w+32) -- L/32 waves.
-// The 47 us dependent MFMA chain of one wave in the kernel above (all L keys x C channels for its 32 queries) is cut
-// L/32-fold, and the grid grows 4x (S x L/32 workgroups): the sampler (S = 1..12 views) no longer runs its seven
-// attention layers on a dozen waves, and at S = 96 every CU holds several workgroups whose phases overlap.
+// Few views: one workgroup = one view x 32 queries, wave w owns keys [32w, 32w+32) -- L/32 waves.  The dependent
+// MFMA chain per wave is L/32 times shorter than with one wave per query block and the grid is S x L/32 workgroups:
+// the sampler (S = 1..12 views) no longer runs its seven attention layers on a dozen waves (57 -> 21 us per layer).
+// With many views this kernel would re-stream K and V once per 32 queries (L2-bound: 113 us at S = 96).
 //   1. S^T tile (32 keys x 32 queries) per wave, K/Q staged through LDS in 32-channel chunks;
 //   2. softmax across waves: per-wave max / sum of the lane's query through LDS (two barriers), fixed order;
 //   3. P (normalised) -> LDS [key][query] (aliases the K/Q staging area) and, optionally, global (S,L,L);
@@ -242,10 +307,11 @@ __global__ __launch_bounds__(L / 32 * 64) void attn_fwd_split_kernel(const float
     mx = red[0][0][li];
 #pragma unroll
     for (int w = 1; w < NW; ++w) mx = fmaxf(mx, red[0][w][li]);
+    const float c2 = alpha * 1.44269504088896341f, mc = mx * c2;     // exp(alpha (s - max)) = 2^(c s - c max), one v_exp_f32
     float sum = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        acc[r] = expf(alpha * (acc[r] - mx));
+        acc[r] = __builtin_amdgcn_exp2f(fmaf(acc[r], c2, -mc));
         sum += acc[r];
     }
     sum += __shfl_xor(sum, 32, 64);
@@ -307,13 +373,14 @@ int vf_attention_fwd(const float* qkv, float* out, float* P, int S, int C, int L
     const float alpha = 1.0f / sqrtf((float)C);
     hipStream_t st = (hipStream_t)stream;
     // few views (sampler): the key-split kernel cuts the per-wave MFMA chain 8-fold; many views (training): it
-    // would re-stream K and V once per 32 queries (L2-bound), the 128-query kernel wins from S ~ 50 on
-    if (L == 256 && S <= 32)
+    // would re-stream K and V once per 32 queries (L2-bound), the 128-query kernel wins from S ~ 55 on (key-split
+    // 44.1 us at S = 44, 128-query 58.9 us at S = 48)
+    if (L == 256 && S <= 52)
         hipLaunchKernelGGL(attn_fwd_split_kernel<256>, dim3(8, S), dim3(512), 0, st, qkv, out, P, C, alpha);
+    else if (L == 256)
+        hipLaunchKernelGGL(attn_fwd_kh_kernel, dim3(2, S), dim3(512), 0, st, qkv, out, P, C, alpha);
     else if (L == 64)
         hipLaunchKernelGGL(attn_fwd_split_kernel<64>, dim3(2, S), dim3(128), 0, st, qkv, out, P, C, alpha);
-    else if (L == 256)
-        hipLaunchKernelGGL(attn_fwd_kernel<256>, dim3(2, S), dim3(256), 0, st, qkv, out, P, C, alpha);
     else
         return (int)hipErrorInvalidValue;
     VF_RETURN_LAST_ERROR();
