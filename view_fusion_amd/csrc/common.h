@@ -47,7 +47,17 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
     return t;
 }
 
-__device__ __forceinline__ float silu_f(float z) { return z / (1.0f + expf(-z)); }
+// sigmoid(z) = 1 / (1 + 2^(-z log2 e)) as v_exp_f32 + v_rcp_f32 (1 ulp each): expf() + an IEEE division cost ~25 VALU
+// instructions per element, which made the "HBM-bound" GroupNorm+Swish kernels VALU-bound.  Saturates correctly:
+// z -> -inf gives 2^(+inf) = inf, rcp(inf) = 0; z -> +inf gives rcp(1) = 1.
+__device__ __forceinline__ float sigmoid_f(float z) {
+#ifdef VF_EXACT_SILU
+    return 1.0f / (1.0f + expf(-z));
+#else
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z * -1.44269504088896341f));
+#endif
+}
+__device__ __forceinline__ float silu_f(float z) { return z * sigmoid_f(z); }
 
 // XCD-aware remap of a 1-D grid: consecutive *logical* ids run on the same XCD (blocks are
 // dealt round-robin over the 8 XCDs), so neighbouring tiles share one L2.  Bijective for any

@@ -31,7 +31,7 @@ __global__ void swish_bwd_kernel(const float* __restrict__ x, const float* __res
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
         const float z = x[i];
-        const float sg = 1.0f / (1.0f + expf(-z));
+        const float sg = sigmoid_f(z);
         dx[i] = dy[i] * (sg * (1.0f + z * (1.0f - sg)));
     }
 }

@@ -100,7 +100,7 @@ __global__ __launch_bounds__(NT) void gn_fwd_kernel(const float* __restrict__ x,
 }
 
 __device__ __forceinline__ float dsilu_mul(float z, float dy) {
-    const float sg = 1.0f / (1.0f + expf(-z));
+    const float sg = sigmoid_f(z);
     return dy * (sg * (1.0f + z * (1.0f - sg)));
 }
 
