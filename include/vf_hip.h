@@ -16,7 +16,8 @@
 extern "C" {
 #endif
 
-/* ---- GroupNorm (+Swish) : nn.GroupNorm(32,C,eps) -> Swish, unet.py:211-212,254,180-182 ---- */
+/* ---- GroupNorm (+Swish) : nn.GroupNorm(32,C,eps) -> Swish, unet.py:211-212,254,180-182 ----
+ * HW = H*W must be a power of two >= 4 (square power-of-two maps), else hipErrorInvalidValue. */
 int vf_gn_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean /*[S*G]*/,
               float* rstd /*[S*G]*/, int S, int C, int HW, int groups, float eps, int silu, void* stream);
 /* dgamma_part/dbeta_part: [S][C] per-view partials; reduce over S with vf_colsum.

@@ -33,6 +33,9 @@ __global__ __launch_bounds__(NT) void gn_fwd_kernel(const float* __restrict__ x,
     const int s = sg / G, g = sg - s * G;
     const size_t base = ((size_t)s * C + (size_t)g * cpg) * HW;
     const int n = cpg * HW, n4 = n >> 2;
+    // HW is a power of two (checked by the launcher): channel-of-element is a shift, not an integer division
+    // (a runtime division is ~30 VALU instructions, and there is one per float4 of payload)
+    const int hwsh = 31 - __clz(HW >> 2), hwmask = (HW >> 2) - 1;
     const float4* x4 = reinterpret_cast<const float4*>(x + base);
     float4* y4 = reinterpret_cast<float4*>(y + base);
 
@@ -44,8 +47,8 @@ __global__ __launch_bounds__(NT) void gn_fwd_kernel(const float* __restrict__ x,
     if (x2) {              // concatenated input: per-access source tensor
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const int idc = min((int)threadIdx.x + i * NT, n4 - 1), hw4 = HW >> 2;
-            v[i] = cat_ptr(x, x2, C1, C, s, g * cpg + idc / hw4, HW)[idc % hw4];
+            const int idc = min((int)threadIdx.x + i * NT, n4 - 1);
+            v[i] = cat_ptr(x, x2, C1, C, s, g * cpg + (idc >> hwsh), HW)[idc & hwmask];
         }
     } else {
 #pragma unroll
@@ -53,7 +56,7 @@ __global__ __launch_bounds__(NT) void gn_fwd_kernel(const float* __restrict__ x,
     }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        const int c = g * cpg + (min((int)threadIdx.x + i * NT, n4 - 1) * 4) / HW;
+        const int c = g * cpg + (min((int)threadIdx.x + i * NT, n4 - 1) >> hwsh);
         gam[i] = gamma[c];
         bet[i] = beta[c];
     }
@@ -165,6 +168,7 @@ __global__ __launch_bounds__(256) void gn_bwd_dx_kernel(const float* __restrict_
         s2 += ga * dgamma_part[s * C + c];
     }
     const int n = cpg * HW, n4 = n >> 2;
+    const int hwsh = 31 - __clz(HW >> 2);
     const float inv_n = 1.0f / (float)n;
     s1 *= inv_n;
     s2 *= inv_n;
@@ -174,7 +178,7 @@ __global__ __launch_bounds__(256) void gn_bwd_dx_kernel(const float* __restrict_
     const float4* d4 = reinterpret_cast<const float4*>(dy + base);
     float4* o4 = reinterpret_cast<float4*>(dx + base);
     for (int i = blockIdx.y * 256 + threadIdx.x; i < n4; i += gridDim.y * 256) {
-        const int c = g * cpg + (i * 4) / HW;
+        const int c = g * cpg + (i >> hwsh);
         const float ga = gamma[c], be = beta[c];
         const float4 xv = x4[i], dv = d4[i];
         const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
@@ -219,7 +223,8 @@ __global__ __launch_bounds__(NT) void gn_bwd_fused_kernel(const float* __restric
     const int sg = blockIdx.x;
     const int s = sg / G, g = sg - s * G;
     const size_t base = ((size_t)s * C + (size_t)g * cpg) * HW;
-    const int n = cpg * HW, n4 = n >> 2, hw4 = HW >> 2;
+    const int n = cpg * HW, n4 = n >> 2;
+    const int hwsh = 31 - __clz(HW >> 2), hwmask = (HW >> 2) - 1;      // HW is a power of two: shifts, not divisions
     const float4* x4 = reinterpret_cast<const float4*>(x + base);
     const float4* d4 = reinterpret_cast<const float4*>(dy + base);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -235,7 +240,7 @@ __global__ __launch_bounds__(NT) void gn_bwd_fused_kernel(const float* __restric
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int idc = min((int)threadIdx.x + i * NT, n4 - 1);
-            xv[i] = cat_ptr(x, x2, C1, C, s, g * cpg + idc / hw4, HW)[idc % hw4];
+            xv[i] = cat_ptr(x, x2, C1, C, s, g * cpg + (idc >> hwsh), HW)[idc & hwmask];
             dv[i] = d4[idc];
         }
     } else {
@@ -249,11 +254,11 @@ __global__ __launch_bounds__(NT) void gn_bwd_fused_kernel(const float* __restric
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         if (SEG == 64) {   // wave-uniform channel of this access: scalar loads, no vector registers
-            const int c = __builtin_amdgcn_readfirstlane(g * cpg + min(wid * 64 + i * NT, n4 - 1) / hw4);
+            const int c = __builtin_amdgcn_readfirstlane(g * cpg + (min(wid * 64 + i * NT, n4 - 1) >> hwsh));
             gam[i] = gamma[c];
             bet[i] = beta[c];
         } else {
-            const int c = g * cpg + min((int)threadIdx.x + i * NT, n4 - 1) / hw4;
+            const int c = g * cpg + (min((int)threadIdx.x + i * NT, n4 - 1) >> hwsh);
             gam[i] = gamma[c];
             bet[i] = beta[c];
         }
@@ -264,7 +269,7 @@ __global__ __launch_bounds__(NT) void gn_bwd_fused_kernel(const float* __restric
         float a = 0.f, b = 0.f, xsum = 0.f;
         int cl = 0;
         if (idx0 < n4) {
-            cl = idx0 / hw4;                         // channel within the group (uniform over the segment)
+            cl = idx0 >> hwsh;                        // channel within the group (uniform over the segment)
             const float ga = gam[i], be = bet[i];
             float xs[4] = {xv[i].x, xv[i].y, xv[i].z, xv[i].w};
             float ds[4] = {dv[i].x, dv[i].y, dv[i].z, dv[i].w};
@@ -328,7 +333,7 @@ __global__ __launch_bounds__(NT) void gn_bwd_fused_kernel(const float* __restric
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
                 const int idc = min((int)threadIdx.x + i * NT, n4 - 1);
-                xv[i] = cat_ptr(addend, addend2, C1, C, s, g * cpg + idc / hw4, HW)[idc % hw4];
+                xv[i] = cat_ptr(addend, addend2, C1, C, s, g * cpg + (idc >> hwsh), HW)[idc & hwmask];
             }
 #pragma unroll
             for (int i = 0; i < NV; ++i) { dv[i].x += xv[i].x; dv[i].y += xv[i].y; dv[i].z += xv[i].z; dv[i].w += xv[i].w; }
@@ -337,7 +342,7 @@ __global__ __launch_bounds__(NT) void gn_bwd_fused_kernel(const float* __restric
         for (int i = 0; i < NV; ++i) {
             const int idx = threadIdx.x + i * NT;
             if (idx < n4)
-                const_cast<float4*>(cat_ptr(dx, dx2, C1, C, s, g * cpg + idx / hw4, HW))[idx % hw4] = dv[i];
+                const_cast<float4*>(cat_ptr(dx, dx2, C1, C, s, g * cpg + (idx >> hwsh), HW))[idx & hwmask] = dv[i];
         }
         return;
     }
@@ -479,7 +484,8 @@ int vf_gn_cat_fwd(const float* x, const float* x2, int C1, const float* gamma, c
                   float* rstd, int S, int C, int HW, int groups, float eps, int silu, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (S <= 0) return 0;
-    if (C % groups != 0 || (HW & 3) || (x2 && (C1 <= 0 || C1 >= C))) return (int)hipErrorInvalidValue;
+    // HW: a power of two >= 4 (square power-of-two maps; the kernels index channels by shifts)
+    if (C % groups != 0 || HW < 4 || (HW & (HW - 1)) || (x2 && (C1 <= 0 || C1 >= C))) return (int)hipErrorInvalidValue;
     const int cpg = C / groups;
     const long n4 = (long)cpg * HW / 4;
 #define VF_GN(NV, NT) return launch_gn_fwd<NV, NT>(x, x2, C1, gamma, beta, y, mean, rstd, S, C, HW, cpg, eps, silu, st)
@@ -516,7 +522,7 @@ int vf_gn_cat_bwd(const float* x, const float* x2, int C1, const float* gamma, c
                   void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (S <= 0) return 0;
-    if (C % groups != 0 || (HW & 3)) return (int)hipErrorInvalidValue;
+    if (C % groups != 0 || HW < 4 || (HW & (HW - 1))) return (int)hipErrorInvalidValue;
     if (x2 && (C1 <= 0 || C1 >= C || !dx2 || (addend && !addend2) || !vf_gn_bwd_emits_rowsum(C, HW, groups)))
         return (int)hipErrorInvalidValue;                // cat inputs: single-pass kernels only
     const int cpg = C / groups;
