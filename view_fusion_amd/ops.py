@@ -293,6 +293,7 @@ WINOGRAD = True           # fused Winograd F(2x2,3x3) for stride-1 3x3 convs on 
 FORCE_WINOGRAD = False    # tests: take the Winograd path even when the grid would not fill the chip
 WINO_MIN_TILES = int(os.environ.get("VF_WINO_MIN_TILES", 30))   # policy thresholds (tuning aid)
 WINO_MIN_FILL = int(os.environ.get("VF_WINO_MIN_FILL", 65))
+WINO_WGRAD_MIN_TILES = int(os.environ.get("VF_WINO_WGRAD_MIN_TILES", 256))   # measured at B = 4 / 8 (S = 24 / 48)
 WINOGRAD_WGRAD = True     # weight gradients of those layers (plain stride-1 ones) through the same transform
 
 
@@ -313,7 +314,7 @@ def use_winograd_wgrad(S, Cin, Cout, H, W, KS, m):
     """Weight gradients split over (co, ci, tile range), so the grid fills the chip at any map size."""
     if not (WINOGRAD and WINOGRAD_WGRAD) or KS != 3 or not _lib.load().vf_wino_wgrad_supported(H, W, m):
         return False
-    return FORCE_WINOGRAD or S * (H // 2) * (W // 2) >= 8 * 128
+    return FORCE_WINOGRAD or S * (H // 2) * (W // 2) >= WINO_WGRAD_MIN_TILES
 
 
 def _packed_wino(layer, force):
