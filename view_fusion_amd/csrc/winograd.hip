@@ -812,25 +812,41 @@ __global__ __launch_bounds__(512, 2) void wino_wgrad_kernel(WinoWgradArgs a) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             float4 a_nxt = a_cur, b_nxt = b_cur;
+            // ---- side work (raw strip of chunk c+1 -> LDS in slice 0, barrier, transforms in slices 4-7; spreading
+            // them over slices 2-6 measured the same),
+            // interleaved with the slice's own MFMAs: the two waves of a SIMD run in phase, side work in front of
+            // the MFMAs would idle the matrix pipe in both at once
+            __builtin_amdgcn_sched_barrier(0);
+            acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.x, b_cur.x, acc[k], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
             if (k + 1 < 8) {
                 a_nxt = *reinterpret_cast<const float4*>(ab + (k + 1) * 64 * GT);
                 b_nxt = *reinterpret_cast<const float4*>(bb + (k + 1) * 64 * GT);
             }
-            // ---- side work: raw strip of chunk c+1 -> LDS (slice 0), barrier, transforms (slices 4-7)
             if (k == 0 && has1) store_x();
             if (k == 1 && has2) load_x(c_begin + c + 2);
             if (k == 4) __syncthreads();               // raw strip of chunk c+1 visible to every thread
             if (has1) {
-                if (k == 4) { xform_x_read(0); xform_x_read(1); }
-                if (k == 5) { xform_x_read(2); xform_x_read(3); xform_dy(nxt); }
-                if (k == 6) { xform_x_write(0, nxt); xform_x_write(1, nxt); }
-                if (k == 7) { xform_x_write(2, nxt); xform_x_write(3, nxt); }
+                if (k == 4) xform_x_read(0);
+                if (k == 5) xform_x_read(2);
+                if (k == 6) xform_x_write(0, nxt);
+                if (k == 7) xform_x_write(2, nxt);
             }
+            __builtin_amdgcn_sched_barrier(0);
+            acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.y, b_cur.y, acc[k], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (has1) {
+                if (k == 4) xform_x_read(1);
+                if (k == 5) xform_x_read(3);
+                if (k == 6) xform_x_write(1, nxt);
+                if (k == 7) xform_x_write(3, nxt);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.z, b_cur.z, acc[k], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (k == 5 && has1) xform_dy(nxt);
             if (k == 6 && has2) load_dy(c_begin + c + 2);
             __builtin_amdgcn_sched_barrier(0);
-            acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.x, b_cur.x, acc[k], 0, 0, 0);
-            acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.y, b_cur.y, acc[k], 0, 0, 0);
-            acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.z, b_cur.z, acc[k], 0, 0, 0);
             acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.w, b_cur.w, acc[k], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             a_cur = a_nxt; b_cur = b_nxt;
