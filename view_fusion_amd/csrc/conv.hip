@@ -259,14 +259,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
             float b_nxt[NPT][4];
 #pragma unroll
             for (int j = 0; j < NCO; ++j) a_nxt[j] = a_cur[j];
-            if (g + 1 < NG) {
-#pragma unroll
-                for (int j = 0; j < NCO; ++j) a_nxt[j] = frag_a(g + 1, j);
-#pragma unroll
-                for (int nt = 0; nt < NPT; ++nt)
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) b_nxt[nt][s] = frag_b(g + 1, nt, s);
-            }
+            // the LDS reads of group g+1 go BEHIND the first MFMA of group g: all waves of a SIMD run this loop in
+            // phase, reads in front of the MFMAs would leave the matrix pipe idle in all of them at once
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < NCO; ++j) {
@@ -277,8 +271,21 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
 #pragma unroll
-                    for (int nt = 0; nt < NPT; ++nt)
+                    for (int nt = 0; nt < NPT; ++nt) {
                         acc[ja][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], b_cur[nt][s], acc[ja][nt], 0, 0, 0);
+                        if (j == 0 && s == 0 && nt == 0) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (g + 1 < NG) {
+#pragma unroll
+                                for (int jj = 0; jj < NCO; ++jj) a_nxt[jj] = frag_a(g + 1, jj);
+#pragma unroll
+                                for (int n2 = 0; n2 < NPT; ++n2)
+#pragma unroll
+                                    for (int s2 = 0; s2 < 4; ++s2) b_nxt[n2][s2] = frag_b(g + 1, n2, s2);
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
             }
             __builtin_amdgcn_sched_barrier(0);
             if (g + 1 < NG) {
