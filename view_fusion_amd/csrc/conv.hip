@@ -434,8 +434,12 @@ __global__ __launch_bounds__(256, BIG ? 1 : 2) void conv_wgrad_kernel(WgradArgs 
     const int kq = BIG ? 0 : (wid >> 1);          // pixel half of this wave (small tile only)
     const int ciw = BIG ? (wid >> 1) : 0;         // ci half of this wave (big tile only)
     const int li = lane & 31, lh = lane >> 5;
-    const int co0 = blockIdx.x * TCO, ci0 = blockIdx.y * TCI;
-    const int t_begin = blockIdx.z * a.tiles_per_slice;
+    // XCD-aware decode (see wino_wgrad_kernel)
+    const unsigned lgc = xcd_remap(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z),
+                                   gridDim.x * gridDim.y * gridDim.z);
+    const int bx = lgc % gridDim.x, by = (lgc / gridDim.x) % gridDim.y, bz = lgc / (gridDim.x * gridDim.y);
+    const int co0 = bx * TCO, ci0 = by * TCI;
+    const int t_begin = bz * a.tiles_per_slice;
     const int t_end = min(a.ntiles, t_begin + a.tiles_per_slice);
 
     for (int i = tid; i < TCI * PSO; i += 256) xl[i] = 0.f;
@@ -581,7 +585,7 @@ __global__ __launch_bounds__(256, BIG ? 1 : 2) void conv_wgrad_kernel(WgradArgs 
         }
     }
     if (kq != 0) return;
-    const int slab = blockIdx.z;
+    const int slab = bz;
 #pragma unroll
     for (int tap = 0; tap < NT; ++tap) {
 #pragma unroll
@@ -655,8 +659,13 @@ __global__ __launch_bounds__(256, 2) void conv1x1_wgrad_kernel(Wgrad1Args a) {
     __shared__ __attribute__((aligned(16))) float Xl[TN * RS];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int cw = wid & 1, ciw = wid >> 1, li = lane & 31, lh = lane >> 5;
-    const int co0 = blockIdx.x * TM, ci0 = blockIdx.y * TN;
-    const int t_begin = blockIdx.z * a.steps_per_slice;
+    // XCD-aware decode (see wino_wgrad_kernel): the (co, ci) tile pairs of one K slice read the same x / dY pixels;
+    // consecutive logical ids share an XCD, so those pixels come from HBM once per slice
+    const unsigned lgc = xcd_remap(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z),
+                                   gridDim.x * gridDim.y * gridDim.z);
+    const int bx = lgc % gridDim.x, by = (lgc / gridDim.x) % gridDim.y, bz = lgc / (gridDim.x * gridDim.y);
+    const int co0 = bx * TM, ci0 = by * TN;
+    const int t_begin = bz * a.steps_per_slice;
     const int t_end = min(a.nsteps, t_begin + a.steps_per_slice);
     const int spv = a.HW / KP;                            // steps per view
 
@@ -749,7 +758,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_wgrad_kernel(Wgrad1Args a) {
 #undef VF_W1_ST
 #undef VF_W1_LOAD
 #undef VF_W1_STORE
-    float* sb = a.ws + (size_t)blockIdx.z * a.CoutP * a.CinQ;
+    float* sb = a.ws + (size_t)bz * a.CoutP * a.CinQ;
 #pragma unroll
     for (int i = 0; i < NI; ++i)
 #pragma unroll

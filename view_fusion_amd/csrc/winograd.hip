@@ -675,8 +675,15 @@ __global__ __launch_bounds__(512, 2) void wino_wgrad_kernel(WinoWgradArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int cw = wid & 1, ciw = (wid >> 1) & 1, kh = wid >> 2;
     const int li = lane & 31, lh = lane >> 5;
-    const int co0 = blockIdx.x * 64, ci0 = blockIdx.y * 64;
-    const int c_begin = blockIdx.z * a.chunks_per_slice;
+    // XCD-aware decode of (co tile, ci tile, K slice): the workgroups of ONE slice stream the same x and dY chunks
+    // (x is shared by the co tiles, dY by the ci tiles).  Hardware deals linear block ids round-robin over the 8 XCDs,
+    // each with its own L2; xcd_remap makes consecutive LOGICAL ids -- the pairs of one slice -- run on the same XCD
+    // at the same time, so a chunk is fetched from HBM once per slice instead of once per XCD that touches it.
+    const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const unsigned lgc = xcd_remap(lin, gridDim.x * gridDim.y * gridDim.z);
+    const int bx = lgc % gridDim.x, by = (lgc / gridDim.x) % gridDim.y, bz = lgc / (gridDim.x * gridDim.y);
+    const int co0 = bx * 64, ci0 = by * 64;
+    const int c_begin = bz * a.chunks_per_slice;
     const int c_end = min(a.nchunks, c_begin + a.chunks_per_slice);
     const int n = c_end - c_begin;
 
@@ -855,8 +862,8 @@ __global__ __launch_bounds__(512, 2) void wino_wgrad_kernel(WinoWgradArgs a) {
     }
 
     // partial dU of this slice: rows k = 8kh .. 8kh+7
-    const int slab = blockIdx.z;
-    if (a.bsum && blockIdx.y == 0) {                   // bias gradient partial: the 8 tile lanes of a channel, fixed order
+    const int slab = bz;
+    if (a.bsum && by == 0) {                   // bias gradient partial: the 8 tile lanes of a channel, fixed order
         float b = bias_acc;
         b += __shfl_xor(b, 1, 64);
         b += __shfl_xor(b, 2, 64);
