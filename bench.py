@@ -12,12 +12,13 @@ NMR-shaped tensors resident in HBM.  `value` = view denoise-steps/s over all ran
 (= S_per_rank * world * iterations/s); weak scaling (per-GPU work fixed).
 
 Rank 0 prints ONE JSON line.  At --gpus 1 it also carries
-  roofline     : the dominant kernel (conv_mfma_kernel, fwd + dgrad launches) timed with HIP events
-                 on its launch stream over extra instrumented steps; algorithmic FLOPs / time
-                 against the 157.3 TF fp32 matrix peak
+  roofline     : the dominant kernel (wino_conv_kernel, forward + dgrad launches) timed with HIP events
+                 on its launch stream over extra instrumented steps; `frac` = the multiplies the matrix
+                 cores EXECUTE / time / the 157.3 TF fp32 matrix peak (<= 1); plus a per-kernel-family
+                 table (both roofs) and the step's distance from its Winograd-adjusted compute floor
   sampler      : sampled views/s of the T=1000 reverse loop (HIP-graph replay at small S)
   cpu_baseline : the CPU oracle (fresh PyTorch-CPU restatement of the reference, kind "port")
-                 timed on a bounded sample (B=1, N=6 -> 6 views/iteration) on the host cores.
+                 timed on bounded samples (all cores and one thread; training and sampler).
 """
 import argparse
 import json
@@ -37,90 +38,182 @@ PEAK_FP32_MATRIX_TFLOPS = 157.3      # MI355X_MICROARCH.md chip table
 PEAK_HBM_GBS = 8000.0
 
 
-def cpu_baseline(hw, n_views, iters=2):
-    """Oracle (oracle/, CPU fp32) training iteration incl. Adam on B=1 x N views."""
+# Algorithmic constants of one stacked view through the small UNet (measured on the reference):
+GFLOP_PER_VIEW_TRAIN = 62.98           # 3 x 20.994 forward (conv3x3 19.19, conv1x1 1.45, attention 0.36)
+GFLOP_3X3_S1_PER_VIEW_FWD = 19.1905 - 0.19     # stride-1 3x3 layers: what the Winograd kernels run (2.25x fewer multiplies)
+HBM_MB_PER_VIEW_TRAIN = 3 * 141.7      # ideal-fusion traffic
+
+
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(hw, n_views, threads_all=None):
+    """The CPU oracle (oracle/: PyTorch-CPU fp32 restatement of the reference, pinned to it by tests/golden; kind
+    "port") on the host cores, on BOUNDED samples of the bench workload (same network, image size and N; fewer
+    samples per iteration so that the leg takes ~1 minute):
+      train, all cores : B=2 x N views, 1 warm-up + 2 timed iterations (fwd + bwd + Adam)
+      train, 1 thread  : B=1 x N views, 1 warm-up + 1 timed iteration
+      sampler, all cores: B=1 x N views, 10 reverse steps of the T=1000 schedule (extrapolated linearly to T=1000)
+    """
     from oracle import unet_ref, view_fusion_ref as vfr
     from view_fusion_amd import UNet
     hp = train.SMALL_UNET
-    torch.manual_seed(0)
-    sd = {k: v.clone().requires_grad_(True) for k, v in UNet(**hp).state_dict().items()}
-    opt = torch.optim.Adam(list(sd.values()), lr=1e-4)
-    sched = vfr.schedule_buffers(vfr.beta_schedule(**train.BETA_SCHEDULE["train"]))
-    b = train.synthetic_batch(1, n_views, hw, "cpu", seed=0)
-    fn = lambda x, a, l: unet_ref.unet_forward(sd, hp, x, a, l)
-    g = torch.Generator().manual_seed(1)
+    threads_all = threads_all or torch.get_num_threads()
 
-    def one():
-        t = torch.randint(1, 2000, (1,), generator=g)
-        u, noise = torch.rand(1, 1, generator=g), torch.randn(1, 3, hw, hw, generator=g)
-        opt.zero_grad()
-        loss = vfr.train_loss(fn, sched, b["y_cond"], b["view_count"], b["angle"], b["y_0"], t, u, noise, True)
-        loss.backward()
-        opt.step()
+    def train_leg(B, iters, threads):
+        torch.set_num_threads(threads)
+        torch.manual_seed(0)
+        sd = {k: v.clone().requires_grad_(True) for k, v in UNet(**hp).state_dict().items()}
+        opt = torch.optim.Adam(list(sd.values()), lr=1e-4)
+        sched = vfr.schedule_buffers(vfr.beta_schedule(**train.BETA_SCHEDULE["train"]))
+        b = train.synthetic_batch(B, n_views, hw, "cpu", seed=0)
+        fn = lambda x, a, l: unet_ref.unet_forward(sd, hp, x, a, l)
+        g = torch.Generator().manual_seed(1)
 
-    one()                                     # warm-up (oneDNN primitive creation)
-    t0 = time.perf_counter()
-    for _ in range(iters):
-        one()
-    dt = (time.perf_counter() - t0) / iters
-    return dict(value=n_views / dt, unit="view denoise-steps/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"oracle train iteration (fwd+bwd+Adam), B=1 N={n_views} 64x64, {iters} timed iterations "
-                       f"after 1 warm-up, {dt:.2f} s/iteration")
+        def one():
+            t = torch.randint(1, 2000, (B,), generator=g)
+            u, noise = torch.rand(B, 1, generator=g), torch.randn(B, 3, hw, hw, generator=g)
+            opt.zero_grad()
+            loss = vfr.train_loss(fn, sched, b["y_cond"], b["view_count"], b["angle"], b["y_0"], t, u, noise, True)
+            loss.backward()
+            opt.step()
+
+        one()                                     # warm-up (oneDNN primitive creation)
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            one()
+        dt = (time.perf_counter() - t0) / iters
+        return B * n_views / dt, dt
+
+    def sampler_leg_cpu(steps, threads):
+        torch.set_num_threads(threads)
+        torch.manual_seed(0)
+        sd = {k: v.clone() for k, v in UNet(**hp).state_dict().items()}
+        sched = vfr.schedule_buffers(vfr.beta_schedule(**train.BETA_SCHEDULE["test"]))
+        b = train.synthetic_batch(1, n_views, hw, "cpu", seed=0)
+        fn = lambda x, a, l: unet_ref.unet_forward(sd, hp, x, a, l)
+        g = torch.Generator().manual_seed(2)
+        y = torch.randn(1, 3, hw, hw, generator=g)
+        with torch.no_grad():
+            for i in range(steps + 1):
+                if i == 1:
+                    t0 = time.perf_counter()      # step 0 is the warm-up
+                t = torch.full((1,), 999 - i, dtype=torch.long)
+                y, _, _ = vfr.p_sample(fn, sched, y, b["y_cond"], b["view_count"], b["angle"], t,
+                                       torch.randn(1, 3, hw, hw, generator=g))
+        return (time.perf_counter() - t0) / steps
+
+    v_all, dt_all = train_leg(2, 2, threads_all)
+    v_one, dt_one = train_leg(1, 1, 1)
+    s_step = sampler_leg_cpu(10, threads_all)
+    torch.set_num_threads(threads_all)
+    return dict(value=v_all, unit="view denoise-steps/s", cores=threads_all, kind="port",
+                cpu_model=_cpu_model(), logical_cpus=os.cpu_count(), torch=torch.__version__,
+                sample=f"oracle training iteration (fwd+bwd+Adam) on the bench network / image size / N={n_views}, "
+                       f"B=2 ({2 * n_views} views), 2 timed iterations after 1 warm-up, {dt_all:.2f} s/iteration, "
+                       f"{threads_all} threads",
+                one_thread=dict(value=v_one, cores=1, sample=f"B=1 ({n_views} views), 1 timed iteration after 1 warm-up, "
+                                                             f"{dt_one:.2f} s/iteration"),
+                sampler=dict(value=1.0 / (s_step * 1000), unit="sampled views/s at T=1000", cores=threads_all,
+                             ms_per_step=s_step * 1e3,
+                             sample=f"oracle p_sample, B=1 N={n_views}, 10 timed reverse steps after 1 warm-up, "
+                                    "extrapolated linearly to T=1000"))
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same bench
-    command (profiles/r01_bench_pmc_traffic_kib_per_launch.json: FETCH_SIZE and WRITE_SIZE collected
-    in separate --pmc runs; FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 correction).  PMC
-    counters cannot be read from inside the process, so this is the recorded, not a live, figure."""
-    path = os.path.join(ROOT, "profiles", "r01_bench_pmc_traffic_kib_per_launch.json")
-    try:
-        tab = json.load(open(path))
-        tot = n = 0.0
-        for k in kernel:                      # launch-weighted mean over the kernels of the family
-            d = tab[k]
-            tot += (2 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0 * d["launches"]
-            n += d["launches"]
-        return tot / n
-    except (OSError, KeyError, ZeroDivisionError):
-        return None
+def pmc_traffic():
+    """HBM bytes per launch per kernel from the committed rocprofv3 PMC passes of this same bench command
+    (profiles/r02_bench_pmc_traffic_kib_per_launch.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs;
+    FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 correction).  PMC counters cannot be read from inside the
+    process, so this is the recorded, not a live, figure; None when no table is committed."""
+    for name in ("r02_bench_pmc_traffic_kib_per_launch.json", "r01_bench_pmc_traffic_kib_per_launch.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        try:
+            tab = json.load(open(path))
+            return {k: (2 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0 for k, d in tab.items()}, "profiles/" + name
+        except (OSError, KeyError, ValueError):
+            continue
+    return {}, None
 
 
-def roofline(trainer, batch, steps=2):
-    """Per-launch HIP-event timing of the conv contraction kernels over `steps` extra iterations."""
+# kind (ops._launch) -> (label, binding roof).  Events bracket the C-ABI launcher, i.e. the kernel family it enqueues.
+FAMILIES = {
+    "wino_conv": ("wino_conv_kernel<LOGW,MODE> (+ tail fixup): forward + dgrad of every stride-1 3x3 layer", "mfma"),
+    "direct_conv": ("conv_mfma_kernel<KS,LOGW,MODE,NPT>: forward + dgrad of the 1x1 / stride-2 layers", "mfma"),
+    "wino_wgrad": ("wino_wgrad_kernel (+ slab sum, finish): weight gradient of the stride-1 3x3 layers", "mfma"),
+    "direct_wgrad": ("conv1x1_wgrad_kernel / conv_wgrad_kernel (+ reduce): weight gradient of the 1x1 / stride-2 layers", "mfma"),
+    "attn_fwd": ("attn_fwd_kh_kernel / attn_fwd_split_kernel", "mfma"),
+    "attn_bwd": ("attention backward", "mfma"),
+    "gn_fwd": ("gn_fwd_kernel (GroupNorm + Swish)", "hbm"),
+    "gn_bwd": ("gn_bwd_fused_kernel (+ fused residual / skip gradient adds)", "hbm"),
+    "adam": ("adam_multi_kernel", "hbm"),
+}
+
+
+def _family(kind, name):
+    if kind in ("conv_fwd", "conv_dgrad"):
+        return "wino_conv" if name.startswith("vf_wino") else "direct_conv"
+    if kind == "conv_wgrad":
+        return "wino_wgrad" if name.startswith("vf_wino") else "direct_wgrad"
+    return kind
+
+
+def roofline(trainer, batch, S, ms_step, steps=2):
+    """Per-launch HIP-event timing (events recorded on the launch stream) of the kernel families over `steps` extra
+    iterations after the timed region.  The headline `frac` is the EXECUTED fp32-MFMA fraction of the dominant
+    kernel, wino_conv_kernel: its launches' algorithmic direct-convolution FLOPs / 2.25 (Winograd F(2x2,3x3)
+    multiplies 16 values per 2x2 outputs x 9 taps = 36 direct ones) / its own event time / 157.3 TF."""
     ops.KERNEL_LOG = []
     for _ in range(steps):
         trainer.step(batch)
     torch.cuda.synchronize()
     log, ops.KERNEL_LOG = ops.KERNEL_LOG, None
     agg = {}
-    for kind, flops, e0, e1, _tag, name in log:
-        a = agg.setdefault(kind, [0.0, 0.0, 0, 0.0])
+    for kind, flops, e0, e1, _tag, name, nbytes in log:
+        a = agg.setdefault(_family(kind, name), [0.0, 0.0, 0, 0.0])
         a[0] += flops
         a[1] += e0.elapsed_time(e1) * 1e-3
         a[2] += 1
-        a[3] += flops / 2.25 if name.startswith("vf_wino") else flops     # multiplies the matrix cores execute
-    f = agg["conv_fwd"][0] + agg["conv_dgrad"][0]
-    s = agg["conv_fwd"][1] + agg["conv_dgrad"][1]
-    n = agg["conv_fwd"][2] + agg["conv_dgrad"][2]
-    x = agg["conv_fwd"][3] + agg["conv_dgrad"][3]
-    out = dict(bound="mfma", kernel="conv forward + dgrad launches: wino_conv_kernel<LOGW,MODE> (fused Winograd F(2x2,3x3): "
-                                   "every stride-1 3x3 layer) + conv_mfma_kernel<KS,LOGW,MODE,NPT> (1x1, stride 2)",
-               achieved=f / s / 1e12, peak=PEAK_FP32_MATRIX_TFLOPS, unit="TFLOP/s",
-               frac=f / s / 1e12 / PEAK_FP32_MATRIX_TFLOPS,
-               note="achieved = ALGORITHMIC direct-convolution FLOPs (2*S*Cout*Cin*KS^2*H*W) / time; the Winograd "
-                    "launches execute 2.25x fewer multiplies, so the fraction of the fp32 MFMA peak the matrix "
-                    "cores actually sustain is mfma_executed_frac",
-               mfma_executed_tflops=x / s / 1e12, mfma_executed_frac=x / s / 1e12 / PEAK_FP32_MATRIX_TFLOPS,
-               traffic=pmc_traffic(("wino_conv_kernel", "conv_mfma_kernel")),
-               traffic_unit="HBM bytes per launch (launch-weighted mean of the kernel family)",
-               traffic_source="profiles/r01_bench_pmc_traffic_kib_per_launch.json (rocprofv3 --pmc, FETCH_SIZE and "
-                              "WRITE_SIZE in separate passes, gfx950 corrections of MI355X_MICROARCH.md applied)",
-               launches_per_step=n // steps,
-               avg_launch_us=s / n * 1e6, algorithmic_gflop_per_launch=f / n / 1e9)
-    out["other_kernels"] = {k: dict(achieved_tflops=v[0] / v[1] / 1e12, mfma_executed_tflops=v[3] / v[1] / 1e12,
-                                    launches_per_step=v[2] // steps, avg_launch_us=v[1] / v[2] * 1e6)
-                            for k, v in agg.items()}
+        a[3] += nbytes
+    traffic, source = pmc_traffic()
+    table = {}
+    for fam, (f, s, n, nb) in agg.items():
+        label, bound = FAMILIES.get(fam, (fam, "hbm"))
+        executed = f / 2.25 if fam.startswith("wino") else f
+        row = dict(kernel=label, bound=bound, launches_per_step=n // steps, ms_per_step=s / steps * 1e3,
+                   avg_launch_us=s / n * 1e6)
+        if f:
+            row.update(direct_equivalent_tflops=f / s / 1e12, mfma_executed_tflops=executed / s / 1e12,
+                       frac_of_fp32_mfma_peak=executed / s / 1e12 / PEAK_FP32_MATRIX_TFLOPS)
+        if nb:
+            row.update(algorithmic_gbs=nb / s / 1e9, frac_of_hbm_peak=nb / s / 1e9 / PEAK_HBM_GBS,
+                       algorithmic_mb_per_launch=nb / n / 1e6)
+        table[fam] = row
+    f, s, n, _ = agg["wino_conv"]
+    executed = f / 2.25
+    # floor of the whole step: every conv at the fp32 MFMA peak, the stride-1 3x3 layers at Winograd's multiply count
+    step_tflop_direct = GFLOP_PER_VIEW_TRAIN * S / 1e3
+    step_tflop_wino = step_tflop_direct - 3 * GFLOP_3X3_S1_PER_VIEW_FWD * S / 1e3 * (1 - 1 / 2.25)
+    floor_ms = step_tflop_wino / PEAK_FP32_MATRIX_TFLOPS * 1e3
+    out = dict(bound="mfma", kernel=FAMILIES["wino_conv"][0], achieved=executed / s / 1e12, peak=PEAK_FP32_MATRIX_TFLOPS,
+               unit="TFLOP/s", frac=executed / s / 1e12 / PEAK_FP32_MATRIX_TFLOPS,
+               note="achieved = multiplies the matrix cores EXECUTE: algorithmic direct-convolution FLOPs "
+                    "(2*S*Cout*Cin*9*H*W per launch) / 2.25 / HIP-event time of the vf_wino_conv_fwd launches "
+                    "(forward + dgrad); direct_equivalent_tflops prices the same launches at the direct count",
+               direct_equivalent_tflops=f / s / 1e12, launches_per_step=n // steps, avg_launch_us=s / n * 1e6,
+               algorithmic_gflop_per_launch=f / n / 1e9, executed_gflop_per_launch=executed / n / 1e9,
+               traffic=traffic.get("wino_conv_kernel"), traffic_unit="HBM bytes per launch", traffic_source=source,
+               step_floor_ms=dict(direct_fp32_mfma=step_tflop_direct / PEAK_FP32_MATRIX_TFLOPS * 1e3,
+                                  winograd_adjusted=floor_ms,
+                                  hbm=HBM_MB_PER_VIEW_TRAIN * S / 1e3 / PEAK_HBM_GBS * 1e3),
+               step_frac_of_floor=floor_ms / ms_step, kernels=table,
+               unattributed_ms_per_step=ms_step - sum(r["ms_per_step"] for r in table.values()))
     return out
 
 
@@ -196,7 +289,7 @@ def main():
             "achieved_tflops_total": 62.98e9 * S * world * args.steps / dt / 1e12,
         }
         if world == 1 and not args.no_roofline:
-            res["roofline"] = roofline(trainer, batch)
+            res["roofline"] = roofline(trainer, batch, S, ms)
         if world == 1 and not args.no_sampler:
             res["sampler"] = sampler_leg()
         if world == 1 and not args.no_cpu_baseline:

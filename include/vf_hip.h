@@ -131,14 +131,19 @@ int vf_sincos_embed(const float* level /*[S]*/, const float* angle /*[S]*/, floa
 int vf_swish_fwd(const float* x, float* y, long n, void* stream);
 int vf_swish_bwd(const float* x, const float* dy, float* dx, long n, void* stream);
 int vf_concat_channels(float* a, float* b, float* out, int S, long na, long nb, int split, void* stream);
+/* nn.Dropout(p) inside Block, unet.py:207-216 (training mode): y = x * (u >= p) / (1-p), u = caller's uniform draws;
+ * applied to dy it is the backward */
+int vf_dropout(const float* x, const float* u, float* y, long n, float p, void* stream);
 
 /* ---- ViewFusion : view_fusion.py:162-164 (q_sample), :244-263/:95-115 (stack), :265-298/:116-150
  *      (compose, mean ablation, MSE), :70-84,152-177 (posterior + p_sample), :314-317 (extract) ---- */
 int vf_gather_level(const float* gammas, const long long* t, const float* u /*[B]|NULL*/, float* level, int B,
                     void* stream);
-int vf_stack_views(const float* y_cond, const float* y_t, const float* noise /*|NULL*/, const float* level,
-                   const float* angle, const int* off /*[B+1]*/, float* x, float* level_s, float* angle_s, int B,
-                   int Nmax, int HW, int S, int copy_cond, void* stream);
+int vf_stack_views(const float* y_cond /*[B][Nmax][Cc][HW]*/, const float* y_t /*[B][3][HW]*/,
+                   const float* noise /*|NULL*/, const float* level, const float* angle, const int* off /*[B+1]*/,
+                   float* x /*[S][Cc+3][HW]*/, float* level_s, float* angle_s, int B, int Nmax,
+                   int Cc /* conditioning channels: 3, or 6 for the `relative` configs */, int HW, int S,
+                   int copy_cond, void* stream);
 int vf_compose_fwd(const float* unet_out, const int* off, const float* target /*|NULL*/, float* noise_hat,
                    float* weights /*[B][maxV][3][HW]|NULL*/, float* loss_part /*[B*64]*/, float* loss, int B,
                    int Cout, int HW, int maxV, int weighting, void* stream);

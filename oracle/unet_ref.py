@@ -83,19 +83,22 @@ def sincos_encoding(level, dim):
     return torch.cat([torch.sin(arg), torch.cos(arg)], dim=-1)
 
 
-def _gn_swish_conv(sd, key, x, groups):
+def _gn_swish_conv(sd, key, x, groups, drop=None):
     h = F.group_norm(x, groups, sd[f"{key}.block.0.weight"], sd[f"{key}.block.0.bias"], eps=1e-5)
     h = swish(h)
+    if drop is not None:                 # nn.Dropout(p), training mode, with explicit uniform draws u (unet.py:207-216)
+        p, u = drop
+        h = h * (u >= p).to(h.dtype) / (1.0 - p)
     return F.conv2d(h, sd[f"{key}.block.3.weight"], sd[f"{key}.block.3.bias"], padding=1)
 
 
-def _res_block(sd, key, x, emb, groups):
+def _res_block(sd, key, x, emb, groups, drop=None):
     rb = f"{key}.res_block"
     h = _gn_swish_conv(sd, f"{rb}.block1", x, groups)
     e = F.linear(emb, sd[f"{rb}.noise_func.noise_func.0.weight"],
                  sd[f"{rb}.noise_func.noise_func.0.bias"])          # (S,1,Cout)
     h = h + e.reshape(x.shape[0], -1, 1, 1)
-    h = _gn_swish_conv(sd, f"{rb}.block2", h, groups)
+    h = _gn_swish_conv(sd, f"{rb}.block2", h, groups, drop)          # the reference puts Dropout in block2 only
     if f"{rb}.res_conv.weight" in sd:
         x = F.conv2d(x, sd[f"{rb}.res_conv.weight"], sd[f"{rb}.res_conv.bias"])
     return h + x
@@ -114,10 +117,14 @@ def _self_attention(sd, key, x, groups):
     return o + x
 
 
-def unet_forward(sd, hp, x, angle, level):
+def unet_forward(sd, hp, x, angle, level, dropout_u=None):
     """sd: state_dict of the UNet (no prefix); hp: hyper-parameter dict;
-    x (S,Cin,H,W); angle (S,1); level (S,1)  ->  (S,Cout,H,W)."""
+    x (S,Cin,H,W); angle (S,1); level (S,1)  ->  (S,Cout,H,W).
+    dropout_u: None = eval mode (Dropout is the identity); else the uniform draws of the residual blocks'
+    Dropout(p = hp["dropout"]) layers in execution order (training mode with explicit randomness)."""
     topo = unet_topology(**hp)
+    p_drop = float(hp.get("dropout", 0) or 0)
+    draws = iter(dropout_u) if (dropout_u is not None and p_drop > 0) else None
     g = topo["groups"]
     half = topo["emb_dim"] // 2
     emb = torch.cat([sincos_encoding(level, half), sincos_encoding(angle, half)], dim=-1)
@@ -133,7 +140,7 @@ def unet_forward(sd, hp, x, angle, level):
         if kind == "up":
             x = F.interpolate(x, scale_factor=2, mode="nearest")
             return F.conv2d(x, sd[f"{key}.conv.weight"], sd[f"{key}.conv.bias"], padding=1)
-        x = _res_block(sd, key, x, emb, g)
+        x = _res_block(sd, key, x, emb, g, (p_drop, next(draws)) if draws is not None else None)
         if layer["attn"]:
             x = _self_attention(sd, key, x, g)
         return x

@@ -84,3 +84,45 @@ def test_two_rank_gloo_matches_single_process_on_the_global_batch(reducer_kind):
         tr.step({k: torch.cat([s[k] for s in shards]) for k in shards[0]})
     for a, b in zip(out[0], tr.module.parameters()):
         assert torch.allclose(a, b.detach(), rtol=1e-5, atol=1e-7)
+
+
+def _reduce_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
+                      WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from view_fusion_amd import drivers, train
+    r, _, w = train.init_distributed()
+    d = {"psnr": torch.tensor(20.0 + 4 * rank), "ssim": torch.tensor(0.5 + 0.25 * rank)}
+    avg = drivers.reduce_dict(d)
+    tot = drivers.reduce_dict(d, average=False)
+    # the eval flow of Experiment.eval with its three barriers (experiment.py:347-366), metrics precomputed
+    class Fixed(torch.nn.Module):
+        def forward(self, y_cond, view_count, angle, generate=False):
+            return (None, None, None, None, y_cond[:, 0] * (rank + 1))
+    tgt = torch.ones(2, 3, 4, 4)
+    ev = drivers.evaluate(Fixed(), [dict(target=tgt, cond=torch.full((2, 6, 3, 4, 4), 0.5), angle=torch.zeros(2, 1))],
+                          extra_metrics={"mse": lambda a, b: ((a - b) ** 2).mean(dim=(1, 2, 3))})
+    out[rank] = dict(avg={k: float(v) for k, v in avg.items()}, tot={k: float(v) for k, v in tot.items()},
+                     untouched=float(d["psnr"]), mse=float(ev["mse"]))
+    dist.destroy_process_group()
+
+
+def test_eval_reduction_world_two():
+    """reduce_dict (all_reduce AVG over the sorted keys, utils/dist.py:69-91) and the barrier-bracketed
+    eval reduction at world size 2.  The PSNR kernel needs a GPU, so the CPU run injects a host metric."""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_reduce_worker_patched, args=(2, _free_port(), out), nprocs=2, join=True)
+    for r in (0, 1):
+        assert out[r]["avg"] == {"psnr": 22.0, "ssim": 0.625} and out[r]["tot"] == {"psnr": 44.0, "ssim": 1.25}
+        assert out[r]["untouched"] == 20.0 + 4 * r              # the input dict is not modified
+        # rank 0 generates 0.5 (mse 0.25), rank 1 generates 1.0 (mse 0): mean over ranks
+        assert abs(out[r]["mse"] - 0.125) < 1e-7
+
+
+def _reduce_worker_patched(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    from view_fusion_amd import drivers
+    drivers.compute_psnr = lambda a, b: ((a - b) ** 2).mean(dim=(1, 2, 3))   # host stand-in for the HIP PSNR kernel
+    _reduce_worker(rank, world, port, out)

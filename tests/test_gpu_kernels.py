@@ -147,11 +147,11 @@ def test_group_norm_backward_rowsum(dev, C, H):
     x, gy = rnd(S, C, H, H, seed=1), rnd(S, C, H, H, seed=2)
     gamma, beta = (1 + 0.1 * rnd(C, seed=3)).to(dev), (0.1 * rnd(C, seed=4)).to(dev)
     xg = x.to(dev).requires_grad_(True)
-    ops.ROWSUM_CACHE.clear()
     y = ops.group_norm(xg, gamma, beta, 32, silu=True)
     y.backward(gy.to(dev))
-    assert len(ops.ROWSUM_CACHE) == 1
-    (t, rowsum, _), = ops.ROWSUM_CACHE.values()
+    t = xg.grad                                   # the dx tensor itself: the sums travel on it
+    ver, rowsum, _ = t._vf_sums
+    assert ver == t._version
     ref = t.double().sum((2, 3))
     scale = t.double().abs().sum((2, 3)).max().item()
     assert (rowsum.double() - ref).abs().max().item() < 2e-6 * scale
@@ -159,13 +159,22 @@ def test_group_norm_backward_rowsum(dev, C, H):
     layer = torch.nn.Conv2d(C, C, 3, padding=1).to(dev)
     vb = rnd(S, C, seed=5).to(dev).requires_grad_(True)
     grads = []
-    for cache in ({}, None):
-        ops.ROWSUM_CACHE = cache
-        layer.zero_grad(); vb.grad = None
-        h = ops.conv2d(x.to(dev), layer, view_bias=vb)
-        ops.group_norm(h, gamma, beta, 32, silu=True).backward(gy.to(dev))
-        grads.append((layer.bias.grad.clone(), vb.grad.clone()))
-    ops.ROWSUM_CACHE = {}
+    from view_fusion_amd import _lib
+    real_call, names = _lib.call, []
+    _lib.call = lambda name, *a: (names.append(name), real_call(name, *a))[1]
+    try:
+        for fusion in (True, False):
+            ops.ROWSUM_FUSION = fusion
+            layer.zero_grad(); vb.grad = None
+            del names[:]
+            h = ops.conv2d(x.to(dev), layer, view_bias=vb)
+            ops.group_norm(h, gamma, beta, 32, silu=True).backward(gy.to(dev))
+            grads.append((layer.bias.grad.clone(), vb.grad.clone()))
+            # with the sums riding on dY the conv backward re-reads nothing; without them it must
+            assert (("vf_rowsum" in names) or ("vf_bias_grad" in names)) == (not fusion), names
+    finally:
+        _lib.call = real_call
+        ops.ROWSUM_FUSION = True
     for a, b in zip(*grads):
         assert (a - b).abs().max().item() < 1e-5 * max(1.0, b.abs().max().item()) + 2e-6 * scale
 

@@ -279,3 +279,317 @@ def test_gradient_arena_matches_plain_training(dev):
     finally:
         reducer.ACTIVE = None
         dist.destroy_process_group()
+
+
+# ================================================================================================
+# Round 2: parity on the REAL workloads (BASELINE configs C1 / C2 / C4 / C5) and the remaining
+# boundary branches (relative conditioning, dropout, checkpoints, sampler drivers).
+# ================================================================================================
+from conftest import MICRO, SCHED_C1, c1_chain_inputs, check_digest   # noqa: E402
+
+
+def cpu_sd(module):
+    return {k: v.detach().cpu().clone().requires_grad_(True) for k, v in module.state_dict().items()}
+
+
+def oracle_train_chunked(sd, hp, sched, y_cond, vc, angle, y_0, t, u, noise, weighting=True, chunk=2):
+    """Oracle loss + gradients (accumulated into sd[k].grad) of a LARGE batch, evaluated a few samples at a time:
+    samples are independent through the UNet (GroupNorm / attention are per view) and the loss is the mean of the
+    per-sample MSEs, so loss = sum_chunks loss_chunk * B_chunk / B.  Keeps the CPU autograd tape small."""
+    from oracle import unet_ref, view_fusion_ref as vfr
+    B = y_0.shape[0]
+    fn = lambda x, a, l: unet_ref.unet_forward(sd, hp, x, a, l)
+    total = 0.0
+    for lo in range(0, B, chunk):
+        sl = slice(lo, min(B, lo + chunk))
+        part = vfr.train_loss(fn, sched, y_cond[sl], vc[sl], angle[sl], y_0[sl], t[sl], u[sl], noise[sl], weighting)
+        part = part * ((sl.stop - sl.start) / B)
+        part.backward()
+        total += float(part.item())
+    return total
+
+
+@pytest.mark.parametrize("B,N,ragged", [(16, 6, False), (8, 6, False), (16, 6, True)])
+def test_full_size_train_step_vs_oracle(dev, B, N, ragged):
+    """BASELINE C2 (B=16 N=6, S=96) and C4 (B=8 N=6, S=48) with the NATURAL kernel policy -- Winograd tail plans at
+    288/144 tiles, attn_fwd_kh vs attn_fwd_split, wgrad thresholds, concat-free decoder -- plus a ragged batch as the
+    reference's training loop draws it (experiment.py:277-279): loss rel 1e-5, every parameter gradient rel-L2 1e-4."""
+    from oracle import view_fusion_ref as vfr
+    vf = make_vf(SMALL, SCHED_TRAIN, dev, True)
+    g = torch.Generator().manual_seed(100 + B)
+    y_0, y_cond = torch.rand(B, 3, 64, 64, generator=g), torch.rand(B, N, 3, 64, 64, generator=g)
+    angle = 2 * np.pi / 24 * torch.randint(0, 24, (B, 1), generator=g).float()
+    noise, u = torch.randn(B, 3, 64, 64, generator=g), torch.rand(B, 1, generator=g)
+    t = torch.randint(1, 2000, (B,), generator=g)
+    vc = torch.randint(1, N + 1, (B,), generator=g) if ragged else torch.full((B,), N)
+    loss = vf(y_cond=y_cond.to(dev), view_count=vc, angle=angle.to(dev), y_0=y_0.to(dev), noise=noise.to(dev),
+              t=t.to(dev), u=u.to(dev))
+    loss.backward()
+    sd = cpu_sd(vf.denoise_fn)
+    sched = vfr.schedule_buffers(vfr.beta_schedule(**SCHED_TRAIN))
+    lref = oracle_train_chunked(sd, SMALL, sched, y_cond, vc, angle, y_0, t, u, noise)
+    assert abs(loss.item() - lref) <= 1e-5 * abs(lref), (loss.item(), lref)
+    worst, wk = 0.0, None
+    for k, p in vf.denoise_fn.named_parameters():
+        a, b = p.grad.detach().cpu().double(), sd[k].grad.double()
+        if float(b.norm()) > 1e-4:
+            err = float((a - b).norm() / b.norm())
+            if err > worst:
+                worst, wk = err, k
+    assert worst < 1e-4, (worst, wk)
+
+
+@pytest.mark.parametrize("use_graph", [True, False])
+def test_c1_small_unet_chain_vs_reference(dev, use_graph):
+    """BASELINE C1 as stated (small UNet, B=2 N=2 64x64, 10 DDPM steps) against the vectors of the real reference."""
+    g = load("c1_small_chain.npz")
+    _, y_cond, angle, _, vc, y_T, z_seq = c1_chain_inputs(g)
+    vf = make_vf(SMALL, SCHED_C1, dev, True)
+    y, ret, logit_arr, weight_arr, samples = vf.generate(y_cond.to(dev), vc, angle.to(dev), y_t=y_T.to(dev),
+                                                         z_seq=z_seq.to(dev), use_graph=use_graph)
+    np.testing.assert_allclose(y.cpu().numpy(), g["y"], rtol=1e-4, atol=5e-5)
+    np.testing.assert_allclose(samples.cpu().numpy(), g["samples"], rtol=1e-4, atol=5e-5)
+    check_digest(ret.cpu(), g, "ret")
+    check_digest(logit_arr.cpu(), g, "logit_arr")
+    check_digest(weight_arr.cpu(), g, "weight_arr", atol=1e-5)
+
+
+def test_c1_small_unet_train_step_vs_reference(dev):
+    g = load("c1_small_chain.npz")
+    y_0, y_cond, angle, noise, vc, _, _ = c1_chain_inputs(g)
+    vf = make_vf(SMALL, SCHED_TRAIN, dev, True)
+    loss = vf(y_cond=y_cond.to(dev), view_count=vc, angle=angle.to(dev), y_0=y_0.to(dev), noise=noise.to(dev),
+              t=T(g["t"], dev), u=T(g["u"], dev))
+    assert abs(loss.item() - float(g["loss"])) <= 1e-5 * abs(float(g["loss"]))
+    loss.backward()
+    check_grads(g, vf.denoise_fn.named_parameters())
+
+
+@pytest.mark.parametrize("use_graph", [True, False])
+@pytest.mark.parametrize("N", [1, 6, 12])
+def test_small_unet_sampler_vs_oracle(dev, N, use_graph):
+    """BASELINE C5 shapes: small UNet 64x64, B=1, N in {1,6,12} conditioning views, 12 reverse steps of the T=1000
+    schedule's kernels (graph capture with split-K workspaces + key-split attention, and eager), injected y_T / z."""
+    from oracle import unet_ref, view_fusion_ref as vfr
+    sched_kw = dict(schedule="linear", num_timesteps=12, linear_start=1e-4, linear_end=0.09)
+    vf = make_vf(SMALL, sched_kw, dev, True)
+    g = torch.Generator().manual_seed(200 + N)
+    y_cond = torch.rand(1, N, 3, 64, 64, generator=g)
+    angle = 2 * np.pi / 24 * torch.randint(0, 24, (1, 1), generator=g).float()
+    y_T = torch.randn(1, 3, 64, 64, generator=g)
+    z_seq = torch.randn(12, 1, 3, 64, 64, generator=g)
+    vc = torch.tensor([N])
+    y, ret, logit_arr, weight_arr, samples = vf.generate(y_cond.to(dev), vc, angle.to(dev), y_t=y_T.to(dev),
+                                                         z_seq=z_seq.to(dev), use_graph=use_graph)
+    sd = {k: v.detach().cpu() for k, v in vf.denoise_fn.state_dict().items()}
+    sched = vfr.schedule_buffers(vfr.beta_schedule(**sched_kw))
+    with torch.no_grad():
+        yr, retr, lr, wr, _ = vfr.generate(lambda x, a, l: unet_ref.unet_forward(sd, SMALL, x, a, l), sched, y_cond, vc,
+                                           angle, y_T, z_seq)
+    np.testing.assert_allclose(y.cpu().numpy(), yr.numpy(), rtol=1e-4, atol=5e-5)
+    np.testing.assert_allclose(ret.cpu().numpy(), retr.numpy(), rtol=1e-4, atol=5e-5)
+    np.testing.assert_allclose(logit_arr.cpu().numpy(), lr.numpy(), rtol=1e-4, atol=5e-5)
+    np.testing.assert_allclose(weight_arr.cpu().numpy(), wr.numpy(), rtol=1e-4, atol=1e-5)
+
+
+def test_long_chain_T1000_tolerance(dev):
+    """SURVEY 8c proposed max-abs 1e-3 for a T=1000 injected-noise chain; measured here on the tiny net with the real
+    sampler schedule (graph replay): the chain contracts errors (clamp + posterior mean), it does not amplify them."""
+    from oracle import unet_ref, view_fusion_ref as vfr
+    vf = make_vf(TINY, SCHED_TEST, dev, True)
+    g = torch.Generator().manual_seed(300)
+    B, N = 2, 3
+    y_cond = torch.rand(B, N, 3, 16, 16, generator=g)
+    angle = 2 * np.pi / 24 * torch.randint(0, 24, (B, 1), generator=g).float()
+    y_T = torch.randn(B, 3, 16, 16, generator=g)
+    z_seq = torch.randn(1000, B, 3, 16, 16, generator=g)
+    vc = torch.tensor([3, 2])
+    y, ret, *_ = vf.generate(y_cond.to(dev), vc, angle.to(dev), y_t=y_T.to(dev), z_seq=z_seq.to(dev), use_graph=True)
+    sd = {k: v.detach().cpu() for k, v in vf.denoise_fn.state_dict().items()}
+    sched = vfr.schedule_buffers(vfr.beta_schedule(**SCHED_TEST))
+    with torch.no_grad():
+        yr, retr, *_ = vfr.generate(lambda x, a, l: unet_ref.unet_forward(sd, TINY, x, a, l), sched, y_cond, vc, angle,
+                                    y_T, z_seq)
+    err = float((y.cpu() - yr).abs().max())
+    err_mid = float((ret.cpu() - retr).abs().max())
+    print(f"T=1000 chain: final max-abs {err:.3e}, over all stashed steps {err_mid:.3e}")
+    assert err < 1e-3 and err_mid < 1e-3          # the stated long-chain tolerance
+    assert err < 1e-4, err                          # what was actually measured leaves 10x margin
+
+
+def test_weights_are_fresh_after_training(dev):
+    """sample -> Trainer steps (FusedAdam writes through raw pointers) -> sample: the no-grad forwards must see the
+    UPDATED weights in every pack format (3x3 layers are Winograd at the training S, direct at the sampler's S).
+    Compared with a fresh model loaded from the trained state_dict."""
+    from view_fusion_amd import train
+    vf = make_vf(SMALL, SCHED_TRAIN, dev, True)
+    tr = train.Trainer(vf, lr_warmup=1)
+    tr.it = 0
+    tr.sched.peak_lr = 2e-3                           # large steps: stale weights would be far outside tolerance
+    b = train.synthetic_batch(4, 4, 64, dev, seed=3)
+    g = torch.Generator().manual_seed(7)
+    y_t, z = torch.randn(1, 3, 64, 64, generator=g).to(dev), torch.randn(1, 3, 64, 64, generator=g).to(dev)
+    cond, ang, t = b["y_cond"][:1, :2].contiguous(), b["angle"][:1], torch.tensor([500], device=dev)
+
+    def sample(model):
+        with torch.no_grad():
+            y, _, w = model.p_sample(y_t, cond, torch.tensor([2]), ang, t, z=z)
+        return y.clone(), w.clone()
+
+    before = sample(vf)
+    for _ in range(2):
+        tr.step(b)
+    mid = sample(vf)
+    tr.step(b)
+    after = sample(vf)
+    fresh = make_vf(SMALL, SCHED_TRAIN, dev, True)
+    fresh.load_state_dict(vf.state_dict())
+    want = sample(fresh)
+    assert float((after[0] - want[0]).abs().max()) < 1e-5 and float((after[1] - want[1]).abs().max()) < 1e-5
+    assert float((after[0] - mid[0]).abs().max()) > 1e-4 and float((mid[0] - before[0]).abs().max()) > 1e-4
+
+
+def test_relative_conditioning_vs_reference(dev):
+    """configs/relative-small-v100-4.yaml: in_channel 9, 6-channel conditioning views (experiment.py:274-283)."""
+    g = load("train_relative.npz")
+    vf = make_vf(dict(TINY, in_channel=9), SCHED_TRAIN, dev, True)
+    vc = torch.tensor(g["view_count"])
+    loss = vf(y_cond=T(g["y_cond"], dev), view_count=vc, angle=T(g["angle"], dev), y_0=T(g["y_0"], dev),
+              noise=T(g["noise"], dev), t=T(g["t"], dev), u=T(g["u"], dev))
+    assert abs(loss.item() - float(g["loss"])) <= 1e-5 * abs(float(g["loss"]))
+    loss.backward()
+    check_grads(g, vf.denoise_fn.named_parameters())
+    with torch.no_grad():
+        mean, logvar, logits, w = vf.p_mean_variance(T(g["y_t"], dev), T(g["y_cond"], dev), vc.to(dev),   # device tensor
+                                                     T(g["angle"], dev), T(g["pmv_t"], dev), clip_denoised=True)
+    np.testing.assert_allclose(mean.cpu().numpy(), g["mean"], rtol=1e-4, atol=5e-5)
+    np.testing.assert_array_equal(logvar.cpu().numpy(), g["logvar"])
+    np.testing.assert_allclose(logits.cpu().numpy(), g["logits"], rtol=1e-4, atol=5e-5)
+    np.testing.assert_allclose(w.cpu().numpy(), g["weights"], rtol=1e-4, atol=1e-5)
+
+
+def test_unet_dropout_vs_reference(dev):
+    """UNet(dropout=0.1): training mode replays the Dropout masks the reference drew; eval mode is the identity."""
+    from test_oracle_golden import dropout_draws
+    g = load("unet_tiny_dropout.npz")
+    hp = dict(TINY, dropout=float(g["p"]))
+    net = make_unet(hp, dev).train()
+    x = T(g["x"], dev).requires_grad_(True)
+    y = net(x, T(g["angle"], dev), T(g["level"], dev), dropout_u=[u.to(dev) for u in dropout_draws(g)])
+    np.testing.assert_allclose(y.detach().cpu().numpy(), g["y"], rtol=1e-4, atol=5e-5)
+    (y * T(g["gy"], dev)).sum().backward()
+    np.testing.assert_allclose(x.grad.cpu().numpy(), g["gx"], rtol=1e-3, atol=3e-5)
+    check_grads(g, net.named_parameters())
+    net.eval()
+    plain = make_unet(TINY, dev)
+    with torch.no_grad():
+        a = net(x.detach(), T(g["angle"], dev), T(g["level"], dev))
+        b = plain(x.detach(), T(g["angle"], dev), T(g["level"], dev))
+    assert torch.equal(a, b)
+    net.train()                                          # default draws: about p of block2's activations dropped
+    with torch.no_grad():
+        c = net(x.detach(), T(g["angle"], dev), T(g["level"], dev))
+    assert float((c - a).abs().max()) > 1e-3
+
+
+def test_checkpoint_from_the_reference_on_the_gpu(dev, tmp_path):
+    """the file written by the reference's Checkpoint.save (model + torch Adam state after one step) is
+    loaded into the HIP model + FusedAdam, two more steps land on the reference's continued parameters, and the file
+    saved afterwards has the reference's layout (torch.optim.Adam loads its optimizer state)."""
+    from view_fusion_amd import drivers
+    from view_fusion_amd.optim import FusedAdam
+    g = load("ckpt_continue.npz")
+    vf = make_vf(MICRO, SCHED_TRAIN, dev, True)
+    opt = FusedAdam(vf.parameters(), lr=1e-4)
+    rest = drivers.load_checkpoint(os.path.join(GOLDEN, "ckpt_ref_micro.pt"), vf, opt, device=dev)
+    assert rest["it"] == 0 and rest["run_id"] == "golden"
+    vc = torch.tensor(g["view_count"])
+    for step in (1, 2):
+        opt.zero_grad()
+        loss = vf(y_cond=T(g[f"s{step}.y_cond"], dev), view_count=vc, angle=T(g[f"s{step}.angle"], dev),
+                  y_0=T(g[f"s{step}.y_0"], dev), noise=T(g[f"s{step}.noise"], dev), t=T(g[f"s{step}.t"], dev),
+                  u=T(g[f"s{step}.u"], dev))
+        assert abs(loss.item() - float(g[f"s{step}.loss"])) <= 2e-5 * abs(float(g[f"s{step}.loss"]))
+        loss.backward()
+        opt.step()
+    d = np.concatenate([np.abs(v.cpu().numpy() - g[f"final.{k}"]).reshape(-1) for k, v in vf.state_dict().items()])
+    assert d.max() < 2.1e-4 and (d > 1e-5).mean() < 0.02, (d.max(), (d > 1e-5).mean())
+    path = str(tmp_path / "model.pt")
+    drivers.save_checkpoint(path, vf, opt, it=2, t=1.5, run_id="golden", ssim=-np.inf, psnr=-np.inf)
+    mine = torch.load(path, map_location="cpu", weights_only=False)
+    ref = torch.load(os.path.join(GOLDEN, "ckpt_ref_micro.pt"), map_location="cpu", weights_only=False)
+    assert list(mine.keys()) == list(ref.keys()) or set(mine) == set(ref)
+    assert list(mine["model"].keys()) == list(ref["model"].keys())
+    assert mine["optimizer"]["param_groups"][0]["params"] == ref["optimizer"]["param_groups"][0]["params"]
+    for i, st in ref["optimizer"]["state"].items():
+        ms = mine["optimizer"]["state"][i]
+        assert set(ms) == set(st) and ms["exp_avg"].shape == st["exp_avg"].shape and float(ms["step"]) == 3.0
+    cpu_params = [torch.nn.Parameter(v.clone()) for k, v in mine["model"].items() if k.startswith("denoise_fn.")]
+    torch.optim.Adam(cpu_params, lr=1e-4).load_state_dict(mine["optimizer"])      # the reference's optimizer class
+
+
+def test_sampler_drivers_vs_oracle(dev):
+    """the three sampler drivers with their real call shapes -- extrapolation (ragged 7..23 views), the
+    autoregressive rollout (view_count 1 -> 3) and the weight-animation call (B=24 targets x N=6 views) -- compared with
+    the oracle through the injected-randomness hooks of forward(generate=True)."""
+    from oracle import unet_ref, view_fusion_ref as vfr
+    from view_fusion_amd import drivers
+    vf = make_vf(TINY, SCHED_C1, dev, True)
+    sd = {k: v.detach().cpu() for k, v in vf.denoise_fn.state_dict().items()}
+    sched = vfr.schedule_buffers(vfr.beta_schedule(**SCHED_C1))
+    fn = lambda x, a, l: unet_ref.unet_forward(sd, TINY, x, a, l)
+    g = torch.Generator().manual_seed(400)
+    # extrapolate: B=3, view counts in 7..23
+    cond, angle = torch.rand(3, 23, 3, 16, 16, generator=g), torch.rand(3, 1, generator=g) * 6
+    vc = torch.tensor([23, 7, 15])
+    y_T, z_seq = torch.randn(3, 3, 16, 16, generator=g), torch.randn(10, 3, 3, 16, 16, generator=g)
+    ret, logit_arr, weight_arr, _ = drivers.extrapolate(vf, cond.to(dev), angle.to(dev), view_count=vc,
+                                                        y_t=y_T.to(dev), z_seq=z_seq.to(dev))
+    with torch.no_grad():
+        _, retr, lr, wr, _ = vfr.generate(fn, sched, cond, vc, angle, y_T, z_seq)
+    np.testing.assert_allclose(ret.cpu().numpy(), retr.clamp(0, 1).numpy(), rtol=1e-4, atol=5e-5)
+    np.testing.assert_allclose(logit_arr.cpu().numpy(), lr.numpy(), rtol=1e-4, atol=5e-5)
+    np.testing.assert_allclose(weight_arr.cpu().numpy(), wr.numpy(), rtol=1e-4, atol=1e-5)
+    # autoregressive rollout, 3 counts
+    first = torch.rand(2, 3, 16, 16, generator=g)
+    yts = [torch.randn(2, 3, 16, 16, generator=g) for _ in range(3)]
+    zs = [torch.randn(10, 2, 3, 16, 16, generator=g) for _ in range(3)]
+    orbit = drivers.autoregressive_rollout(vf, first.to(dev), steps=3, y_t=[t.to(dev) for t in yts],
+                                           z_seq=[z.to(dev) for z in zs])
+    c, want = first[:, None], []
+    with torch.no_grad():
+        for count in range(1, 4):
+            ang = torch.full((2, 1), 2 * np.pi / 24 * count)
+            *_, smp = vfr.generate(fn, sched, c, torch.full((2,), count), ang, yts[count - 1], zs[count - 1])
+            c = torch.cat((c, smp[:, None]), dim=1)
+            want.append(smp)
+    np.testing.assert_allclose(orbit.cpu().numpy(), torch.stack(want, 1).numpy(), rtol=1e-4, atol=1e-4)
+    # weight animation: one object, 24 target angles, 6 conditioning views each
+    views = torch.rand(24, 3, 16, 16, generator=g)
+    y_T, z_seq = torch.randn(24, 3, 16, 16, generator=g), torch.randn(10, 24, 3, 16, 16, generator=g)
+    ret, logit_arr, weight_arr, cond_views, angles = drivers.orbit_frames(vf, views.to(dev), y_t=y_T.to(dev),
+                                                                          z_seq=z_seq.to(dev))
+    assert cond_views.shape == (24, 6, 3, 16, 16) and weight_arr.shape == (24, 10, 6, 3, 16, 16)
+    want_cond = torch.stack([views[::4]] * 24)
+    want_ang = torch.tensor([2 * np.pi / 24 * i for i in range(24)], dtype=torch.float32).unsqueeze(1)
+    assert torch.equal(cond_views.cpu(), want_cond) and torch.equal(angles.cpu(), want_ang)
+    with torch.no_grad():
+        _, retr, lr, wr, _ = vfr.generate(fn, sched, want_cond, torch.full((24,), 6), want_ang, y_T, z_seq)
+    np.testing.assert_allclose(ret.cpu().numpy(), retr.clamp(0, 1).numpy(), rtol=1e-4, atol=5e-5)
+    np.testing.assert_allclose(weight_arr.cpu().numpy(), wr.numpy(), rtol=1e-4, atol=1e-5)
+
+
+def test_device_view_count_is_resolved_once(dev):
+    """A device-tensor view_count (what the reference's loops hand over) costs one read-back per tensor, not one per
+    p_sample call."""
+    from view_fusion_amd import ops
+    vc = torch.tensor([2, 1, 3], device=dev)
+    a = ops.view_offsets(vc, dev)
+    b = ops.view_offsets(vc, dev)
+    assert a is b and a[1:] == (6, 3) and a[0].cpu().tolist() == [0, 2, 3, 6]
+    vc += 1                                               # in-place change bumps the version: re-read
+    c = ops.view_offsets(vc, dev)
+    assert c[1:] == (9, 4)
+    assert ops.view_offsets(torch.tensor([2, 1, 3]), dev)[1:] == (6, 3)
+    with pytest.raises(ValueError):
+        ops.view_offsets([2, 0], dev)

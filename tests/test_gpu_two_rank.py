@@ -118,3 +118,56 @@ def test_two_rank_arena_replicas_stay_in_lock_step():
         assert torch.equal(a, b)
     moved = max(float((a - b).abs().max()) for a, b in zip(r0["params"], [p.detach().cpu() for p in _model(torch.device("cuda:0")).parameters()]))
     assert moved > 1e-5                           # and the parameters really were updated
+
+
+def _eval_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from view_fusion_amd import drivers
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    vf = _eval_model(dev)
+    res = drivers.evaluate(vf, [_eval_batch(rank, dev)], y_t=_eval_noise(rank)[0].to(dev), z_seq=_eval_noise(rank)[1].to(dev))
+    out[rank] = float(res["psnr"])
+    dist.destroy_process_group()
+
+
+def _eval_model(dev):
+    from view_fusion_amd import UNet, ViewFusion
+    from view_fusion_amd.utils import deterministic_fill_
+    net = UNet(**TINY)
+    deterministic_fill_(net.state_dict())
+    vf = ViewFusion(net.to(dev), {"train": dict(schedule="linear", num_timesteps=10, linear_start=1e-4, linear_end=0.09)})
+    vf.set_new_noise_schedule(device=dev, phase="train")
+    return vf
+
+
+def _eval_batch(rank, dev):
+    g = torch.Generator().manual_seed(500 + rank)
+    return dict(target=torch.rand(3, 3, HW, HW, generator=g).to(dev), cond=torch.rand(3, 6, 3, HW, HW, generator=g).to(dev),
+                angle=torch.rand(3, 1, generator=g).to(dev), view_count=torch.tensor([1 + rank, 6, 3]))
+
+
+def _eval_noise(rank):
+    g = torch.Generator().manual_seed(600 + rank)
+    return torch.randn(3, 3, HW, HW, generator=g), torch.randn(10, 3, 3, HW, HW, generator=g)
+
+
+def test_two_rank_eval_reduction():
+    """SURVEY 8(f4) on the GPU: each rank generates its validation shard, PSNR per image with the HIP kernel, barriers
+    and all_reduce(AVG) as Experiment.eval does (experiment.py:314-370) -> the mean over both shards on every rank."""
+    from view_fusion_amd import drivers
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_eval_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    dev = torch.device("cuda:0")
+    vf = _eval_model(dev)
+    per_rank = []
+    for r in (0, 1):
+        res = drivers.evaluate(vf, [_eval_batch(r, dev)], y_t=_eval_noise(r)[0].to(dev), z_seq=_eval_noise(r)[1].to(dev))
+        per_rank.append(float(res["psnr"]))
+    want = 0.5 * (per_rank[0] + per_rank[1])
+    assert abs(per_rank[0] - per_rank[1]) > 1e-3          # the shards really differ
+    assert abs(out[0] - want) < 1e-4 and out[0] == out[1]

@@ -31,3 +31,19 @@ def test_same_seed_same_default_init_as_torch_layers():
     torch.manual_seed(0)
     b = UNet(**TINY).state_dict()
     assert all(torch.equal(a[k], b[k]) for k in a)
+
+
+def test_constructor_branches_follow_the_reference():
+    """dropout: the reference adds a parameter-free nn.Dropout to block2 (unet.py:207-216), so the state_dict is
+    unchanged; with_noise_level_emb=False: the reference's own constructor raises TypeError (nn.Linear(None, C) in
+    FeatureWiseAffine, unet.py:165) -- same error type here."""
+    plain = [(k, tuple(v.shape)) for k, v in UNet(**TINY).state_dict().items()]
+    drop = UNet(**dict(TINY, dropout=0.1))
+    assert [(k, tuple(v.shape)) for k, v in drop.state_dict().items()] == plain
+    assert drop.downs[1].res_block.dropout == 0.1
+    with pytest.raises(TypeError):
+        UNet(**dict(TINY, with_noise_level_emb=False))
+    with pytest.raises(ValueError):
+        UNet(**dict(TINY, dropout=1.5))
+    rel = UNet(**dict(TINY, in_channel=9))                      # configs/relative-small-v100-4.yaml:22
+    assert rel.downs[0].weight.shape == (32, 9, 3, 3)

@@ -57,10 +57,11 @@ SIGNATURES = {
     "vf_swish_fwd": [_P, _P, _L, _P],
     "vf_swish_bwd": [_P, _P, _P, _L, _P],
     "vf_concat_channels": [_P, _P, _P, _I, _L, _L, _I, _P],
+    "vf_dropout": [_P, _P, _P, _L, _F, _P],
     "vf_adam_multi": [_P, _I, _L, _F, _F, _F, _F, _F, _F, _P],
     "vf_psnr": [_P, _P, _P, _I, _I, _P],
     "vf_gather_level": [_P, _P, _P, _P, _I, _P],
-    "vf_stack_views": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "vf_stack_views": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "vf_compose_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "vf_compose_mse_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "vf_p_sample_tail": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],

@@ -20,12 +20,14 @@ __device__ __forceinline__ int sample_of_view(const int* __restrict__ off, int B
 
 // x[v] = [ y_cond[b][v-off[b]] | y_t[b] ]  with optional q_sample on the fly:
 //   y_t' = sqrt(level_b) * y_t + sqrt(1-level_b) * noise.
-// grid (chunks, S); n4 = 3*HW/4 float4 per image.
+// The conditioning part has Cc channels (3 = an RGB view; 6 = the `relative` configs' view pair,
+// experiment.py:274-283 / configs/relative-small-v100-4.yaml:22), the noisy target always 3.
+// grid (chunks, S); nc4 = Cc*HW/4 and n4 = 3*HW/4 float4 per image.
 __global__ void stack_views_kernel(const float4* __restrict__ y_cond, const float4* __restrict__ y_t,
                                    const float4* __restrict__ noise, const float* __restrict__ level,
                                    const float* __restrict__ angle, const int* __restrict__ off,
                                    float4* __restrict__ x, float* __restrict__ level_s, float* __restrict__ angle_s,
-                                   int B, int Nmax, int n4, int copy_cond) {
+                                   int B, int Nmax, int nc4, int n4, int copy_cond) {
     const int v = blockIdx.y;
     const int b = sample_of_view(off, B, v);
     const int j = v - off[b];
@@ -35,12 +37,13 @@ __global__ void stack_views_kernel(const float4* __restrict__ y_cond, const floa
         angle_s[v] = angle[b];
     }
     const float sa = sqrtf(lv), sb = sqrtf(1.0f - lv);
-    const float4* c = y_cond + ((size_t)b * Nmax + j) * n4;
+    const float4* c = y_cond + ((size_t)b * Nmax + j) * nc4;
     const float4* t = y_t + (size_t)b * n4;
     const float4* z = noise ? noise + (size_t)b * n4 : nullptr;
-    float4* o = x + (size_t)v * 2 * n4;
+    float4* o = x + (size_t)v * (nc4 + n4);
+    if (copy_cond)
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nc4; i += gridDim.x * blockDim.x) o[i] = c[i];
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) {
-        if (copy_cond) o[i] = c[i];
         float4 y = t[i];
         if (z) {
             const float4 e = z[i];
@@ -49,7 +52,7 @@ __global__ void stack_views_kernel(const float4* __restrict__ y_cond, const floa
             y.z = sa * y.z + sb * e.z;
             y.w = sa * y.w + sb * e.w;
         }
-        o[n4 + i] = y;
+        o[nc4 + i] = y;
     }
 }
 
@@ -297,13 +300,13 @@ int vf_gather_level(const float* gammas, const long long* t, const float* u, flo
 // off [B+1] -> x [S][6][HW], level_s/angle_s [S].
 int vf_stack_views(const float* y_cond, const float* y_t, const float* noise, const float* level,
                    const float* angle, const int* off, float* x, float* level_s, float* angle_s, int B, int Nmax,
-                   int HW, int S, int copy_cond, void* stream) {
+                   int Cc, int HW, int S, int copy_cond, void* stream) {
     if (S <= 0) return 0;
-    if (HW & 3) return (int)hipErrorInvalidValue;
-    const int n4 = 3 * HW / 4;
-    hipLaunchKernelGGL(stack_views_kernel, dim3(chunks_for(n4), S), dim3(256), 0, (hipStream_t)stream,
+    if ((HW & 3) || Cc < 1) return (int)hipErrorInvalidValue;
+    const int n4 = 3 * HW / 4, nc4 = Cc * HW / 4;
+    hipLaunchKernelGGL(stack_views_kernel, dim3(chunks_for(nc4 > n4 ? nc4 : n4), S), dim3(256), 0, (hipStream_t)stream,
                        (const float4*)y_cond, (const float4*)y_t, (const float4*)noise, level, angle, off,
-                       (float4*)x, level_s, angle_s, B, Nmax, n4, copy_cond);
+                       (float4*)x, level_s, angle_s, B, Nmax, nc4, n4, copy_cond);
     VF_RETURN_LAST_ERROR();
 }
 

@@ -36,6 +36,17 @@ __global__ void swish_bwd_kernel(const float* __restrict__ x, const float* __res
     }
 }
 
+// nn.Dropout(p) of Block (unet.py:207-216, training mode only): y = x * (u >= p) / (1 - p) with the uniform
+// draws u in [0,1) supplied by the caller (the host's RNG; the same kernel applied to dy is the backward).
+__global__ void dropout_kernel(const float4* __restrict__ x, const float4* __restrict__ u, float4* __restrict__ y,
+                               size_t n4, float p, float scale) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const float4 a = x[i], r = u[i];
+    y[i] = make_float4(r.x >= p ? a.x * scale : 0.f, r.y >= p ? a.y * scale : 0.f, r.z >= p ? a.z * scale : 0.f,
+                       r.w >= p ? a.w * scale : 0.f);
+}
+
 // out[s] = [a[s] | b[s]] along channels; na4 / nb4 = float4 per sample of a / b.
 // split != 0 runs the copy the other way (out -> a, b).
 __global__ void concat_kernel(float4* __restrict__ a, float4* __restrict__ b, float4* __restrict__ out, int na4,
@@ -73,6 +84,16 @@ int vf_swish_bwd(const float* x, const float* dy, float* dx, long n, void* strea
     if (n <= 0) return 0;
     hipLaunchKernelGGL(swish_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, dy,
                        dx, (size_t)n);
+    VF_RETURN_LAST_ERROR();
+}
+
+// n a multiple of 4; 0 <= p < 1.
+int vf_dropout(const float* x, const float* u, float* y, long n, float p, void* stream) {
+    if (n <= 0) return 0;
+    if ((n & 3) || !(p >= 0.f && p < 1.f)) return (int)hipErrorInvalidValue;
+    const size_t n4 = (size_t)n >> 2;
+    hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float4*)x, (const float4*)u, (float4*)y, n4, p, 1.0f / (1.0f - p));
     VF_RETURN_LAST_ERROR();
 }
 

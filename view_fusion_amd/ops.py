@@ -39,13 +39,13 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
-# Optional per-launch timing of the contraction kernels (bench.py roofline leg).  When
-# KERNEL_LOG is a list, every conv launch is bracketed by HIP events recorded on the stream the
-# kernel is launched on, and (kind, algorithmic flops, start, end) is appended.
+# Optional per-launch timing (bench.py roofline leg).  When KERNEL_LOG is a list, every launch that goes through
+# _launch is bracketed by HIP events recorded on the stream the kernel is launched on, and
+# (kind, algorithmic flops, start, end, tag, C-ABI entry point, algorithmic HBM bytes) is appended.
 KERNEL_LOG = None
 
 
-def _launch(kind, flops, name, *args, tag=None):
+def _launch(kind, flops, name, *args, tag=None, nbytes=0.0):
     if KERNEL_LOG is None:
         _lib.call(name, *args)
         return
@@ -53,19 +53,21 @@ def _launch(kind, flops, name, *args, tag=None):
     e0.record()
     _lib.call(name, *args)
     e1.record()
-    KERNEL_LOG.append((kind, flops, e0, e1, tag, name))
+    KERNEL_LOG.append((kind, flops, e0, e1, tag, name, nbytes))
 
 
 # ---------------------------------------------------------------------------------------------
-# workspace shared by all wgrad launches on a device (stream ordered, grown on demand)
+# split-K / slab workspace: one buffer per (device, stream) -- launches on one stream are ordered, so consecutive
+# kernels may reuse it; two streams (two models driven concurrently) get separate buffers.  Grown on demand.
 _ws = {}
 
 
 def _workspace(device, nfloats):
-    buf = _ws.get(device)
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    buf = _ws.get(key)
     if buf is None or buf.numel() < nfloats:
         buf = torch.empty(int(nfloats), device=device, dtype=torch.float32)
-        _ws[device] = buf
+        _ws[key] = buf
     return buf
 
 
@@ -76,35 +78,30 @@ def _gn_forward(x, gamma, beta, groups, silu):
     y = torch.empty_like(x)
     mean = torch.empty(S * groups, device=x.device, dtype=torch.float32)
     rstd = torch.empty_like(mean)
-    _lib.call("vf_gn_fwd", _ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(mean), _ptr(rstd), S, C, H * W,
-              groups, 1e-5, int(silu), _stream())
+    _launch("gn_fwd", 0.0, "vf_gn_fwd", _ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(mean), _ptr(rstd), S, C, H * W,
+            groups, 1e-5, int(silu), _stream(), nbytes=8.0 * x.numel())        # read x once, write y once
     return y, mean, rstd
 
 
-# Per-(view, channel) map sums of gradient tensors that a kernel already had in registers, keyed by the
-# tensor's address: the GroupNorm backward knows sum_hw(dx) in closed form, and dx is exactly the dY of the
-# conv in front of it, whose bias / embedding-bias gradients are those sums; a residual 1x1 conv sees the
-# same dY tensor as the 3x3 conv it is added to.  Entries keep the tensor alive (so the address cannot be
-# recycled), are popped on use, bounded, and dropped at the next training forward.  None disables.
-ROWSUM_CACHE = {}
-_ROWSUM_MAX = 8
+# Per-(view, channel) map sums of a gradient tensor that a kernel already had in registers: the GroupNorm backward
+# knows sum_hw(dx) in closed form, and dx is exactly the dY of the conv in front of it, whose bias / embedding-bias
+# gradients are those sums; a residual 1x1 conv sees the same dY tensor as the 3x3 conv it is added to.  The sums
+# travel ON the gradient tensor itself (a Python attribute; autograd hands the same tensor object from one backward
+# node to the next), stamped with the tensor's version: no global table, nothing keyed on addresses, and a gradient
+# that autograd had to re-materialise (an accumulation) simply does not carry them.  ROWSUM_FUSION = False disables.
+ROWSUM_FUSION = True
 
 
 def _rowsum_put(t, rowsum, colsum):
-    if ROWSUM_CACHE is None:
-        return
-    while len(ROWSUM_CACHE) >= _ROWSUM_MAX:
-        ROWSUM_CACHE.pop(next(iter(ROWSUM_CACHE)))
-    ROWSUM_CACHE[t.data_ptr()] = (t, rowsum, colsum)
+    if ROWSUM_FUSION:
+        t._vf_sums = (t._version, rowsum, colsum)
 
 
 def _rowsum_get(t):
-    if ROWSUM_CACHE is None:
+    h = getattr(t, "_vf_sums", None) if ROWSUM_FUSION else None
+    if h is None or h[0] != t._version:
         return None
-    hit = ROWSUM_CACHE.pop(t.data_ptr(), None)
-    if hit is None or hit[0].shape != t.shape or hit[0]._version != t._version:
-        return None
-    return hit
+    return h
 
 
 def _gslot(p):
@@ -126,13 +123,14 @@ def _gn_backward(ctx, dy, addend, addend2=None):
     dx = torch.empty_like(x)
     parts = torch.empty(2, S, C, device=x.device, dtype=torch.float32)
     rowsum = None
-    if addend is None and ROWSUM_CACHE is not None and _lib.load().vf_gn_bwd_emits_rowsum(C, H * W, ctx.groups):
+    if addend is None and ROWSUM_FUSION and _lib.load().vf_gn_bwd_emits_rowsum(C, H * W, ctx.groups):
         rowsum = torch.empty(S, C, device=x.device, dtype=torch.float32)
     if addend is None and addend2 is not None:
         addend, addend2 = addend2, None
-    _lib.call("vf_gn_cat_bwd", _ptr(x), None, C, _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd), _ptr(dy), _ptr(addend),
-              _ptr(addend2), _ptr(dx), None, _ptr(parts[0]), _ptr(parts[1]), _ptr(rowsum), S, C, H * W, ctx.groups,
-              ctx.silu, _stream())
+    _launch("gn_bwd", 0.0, "vf_gn_cat_bwd", _ptr(x), None, C, _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd), _ptr(dy),
+            _ptr(addend), _ptr(addend2), _ptr(dx), None, _ptr(parts[0]), _ptr(parts[1]), _ptr(rowsum), S, C, H * W,
+            ctx.groups, ctx.silu, _stream(),              # read x, dy (+ the fused residual / skip gradients), write dx
+            nbytes=4.0 * x.numel() * (3 + (addend is not None) + (addend2 is not None)))
     if rowsum is not None:
         _rowsum_put(dx, rowsum, None)
     dgb = reducer.ACTIVE.slot_pair(*ctx.gb) if reducer.ACTIVE is not None else None
@@ -187,8 +185,8 @@ class _GroupNormCatSkipFn(torch.autograd.Function):
         y = torch.empty(S, C, H, W, device=x1.device, dtype=torch.float32)
         mean = torch.empty(S * groups, device=x1.device, dtype=torch.float32)
         rstd = torch.empty_like(mean)
-        _lib.call("vf_gn_cat_fwd", _ptr(x1), _ptr(x2), C1, _ptr(gamma), _ptr(beta), _ptr(y), _ptr(mean), _ptr(rstd), S,
-                  C, H * W, groups, 1e-5, int(silu), _stream())
+        _launch("gn_fwd", 0.0, "vf_gn_cat_fwd", _ptr(x1), _ptr(x2), C1, _ptr(gamma), _ptr(beta), _ptr(y), _ptr(mean),
+                _ptr(rstd), S, C, H * W, groups, 1e-5, int(silu), _stream(), nbytes=8.0 * y.numel())
         ctx.save_for_backward(x1, x2, gamma, beta, mean, rstd)
         ctx.groups, ctx.silu, ctx.gb = groups, int(silu), (gamma, beta)
         return y, x1.view_as(x1), x2.view_as(x2)
@@ -206,9 +204,9 @@ class _GroupNormCatSkipFn(torch.autograd.Function):
         d2 = None if d2 is None else _c(d2)
         dx1, dx2 = torch.empty_like(x1), torch.empty_like(x2)
         parts = torch.empty(2, S, C, device=x1.device, dtype=torch.float32)
-        _lib.call("vf_gn_cat_bwd", _ptr(x1), _ptr(x2), C1, _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd), _ptr(dy),
-                  _ptr(d1), _ptr(d2), _ptr(dx1), _ptr(dx2), _ptr(parts[0]), _ptr(parts[1]), None, S, C, H * W,
-                  ctx.groups, ctx.silu, _stream())
+        _launch("gn_bwd", 0.0, "vf_gn_cat_bwd", _ptr(x1), _ptr(x2), C1, _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd),
+                _ptr(dy), _ptr(d1), _ptr(d2), _ptr(dx1), _ptr(dx2), _ptr(parts[0]), _ptr(parts[1]), None, S, C, H * W,
+                ctx.groups, ctx.silu, _stream(), nbytes=4.0 * dy.numel() * (3 + (d1 is not None)))
         dgb = reducer.ACTIVE.slot_pair(*ctx.gb) if reducer.ACTIVE is not None else None
         if dgb is None:
             dgb = torch.empty(2, C, device=x1.device, dtype=torch.float32)
@@ -262,9 +260,10 @@ def _wino_ws(device, S, Cin, Cout, H, W):
 def _packed(layer, force):
     """Packed forward / dgrad weights of a conv layer.
 
-    Inference: cached, keyed on the parameter's version counter (load_state_dict / copy_ bump it).
+    Inference: cached, keyed on the parameter's version counter (load_state_dict / copy_ / FusedAdam.step bump it).
     Training (`force`): re-packed on every forward -- fused optimizers (torch._fused_adam_) update
-    parameters WITHOUT bumping `_version`, so the counter cannot be trusted across steps.
+    parameters WITHOUT bumping `_version`, so the counter cannot be trusted across steps; for the same reason a
+    training pack never becomes a cache hit for a later no-grad forward (its key stays None, see pack_all).
     """
     w = layer.weight
     cache = getattr(layer, "_vf_pack", None)
@@ -285,7 +284,7 @@ def _packed(layer, force):
     wd = w.detach()
     _check(wd)
     _lib.call("vf_conv_pack_weights", _ptr(wd), _ptr(wf), _ptr(wb), Cout, Cin, KS, _stream())
-    object.__setattr__(layer, "_vf_pack", (key, wf, wb))
+    object.__setattr__(layer, "_vf_pack", (None if force else key, wf, wb))   # training packs are never cache hits
     return wf, wb
 
 
@@ -338,7 +337,7 @@ def _packed_wino(layer, force):
     wd = w.detach()
     _check(wd)
     _lib.call("vf_wino_pack_weights", _ptr(wd), _ptr(uf), _ptr(ub), Cout, Cin, _stream())
-    object.__setattr__(layer, "_vf_wpack", (key, uf, ub))
+    object.__setattr__(layer, "_vf_wpack", (None if force else key, uf, ub))
     return uf, ub
 
 
@@ -353,8 +352,6 @@ def pack_all(root, S=None):
     if not layers:
         return
     _check(layers[0].weight.detach())
-    if ROWSUM_CACHE:
-        ROWSUM_CACHE.clear()
 
     def wants_wino(l):
         geom = getattr(l, "_vf_geom", None)
@@ -395,11 +392,18 @@ def pack_all(root, S=None):
         _lib.call("vf_conv_pack_weights_multi", ctypes.c_void_p(desc_d.data_ptr()), nd, blk_d, _stream())
     if nw:
         _lib.call("vf_wino_pack_weights_multi", ctypes.c_void_p(desc_w.data_ptr()), nw, blk_w, _stream())
+    # A training pack is consumed once, through its `_fresh` flag, by this forward's conv2d call.  Its cache key stays
+    # None (and the key of the layer's OTHER format is dropped too): an optimizer may update the weights without
+    # touching `_version` (torch._fused_adam_), so after a training forward no cached pack of either format may be
+    # trusted by a later no-grad forward (generate / p_sample after Trainer.step()).
     for l, (_, wino) in zip(layers, plan[1]):
-        w = l.weight
-        attr = "_vf_wpack" if wino else "_vf_pack"
+        attr, other = ("_vf_wpack", "_vf_pack") if wino else ("_vf_pack", "_vf_wpack")
         c = getattr(l, attr)
-        object.__setattr__(l, attr, ((w._version, w.data_ptr(), w.device), c[1], c[2]))
+        if c[0] is not None:
+            object.__setattr__(l, attr, (None, c[1], c[2]))
+        o = getattr(l, other, None)
+        if o is not None and o[0] is not None:
+            object.__setattr__(l, other, (None, o[1], o[2]))
         object.__setattr__(l, attr + "_fresh", True)
 
 
@@ -733,6 +737,33 @@ def swish(x):
     return _SwishFn.apply(x)
 
 
+class _DropoutFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, u, p):
+        _check(x, u)
+        y = torch.empty_like(x)
+        _lib.call("vf_dropout", _ptr(x), _ptr(u), _ptr(y), x.numel(), float(p), _stream())
+        ctx.save_for_backward(u)
+        ctx.p = float(p)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (u,) = ctx.saved_tensors
+        dy = _c(dy)
+        dx = torch.empty_like(dy)
+        _lib.call("vf_dropout", _ptr(dy), _ptr(u), _ptr(dx), dy.numel(), ctx.p, _stream())
+        return dx, None, None
+
+
+def dropout(x, p, u=None):
+    """nn.Dropout(p) in training mode (reference Block, unet.py:207-216): x * (u >= p) / (1 - p).  u = uniform draws
+    in [0,1) shaped like x (default: torch's device RNG; tests inject them)."""
+    if u is None:
+        u = torch.rand_like(x)
+    return _DropoutFn.apply(x, _c(u), p)
+
+
 def sincos_embedding(level, angle, dim):
     """(S,1),(S,1) -> (S,dim): [sin|cos](level*f) ++ [sin|cos](angle*f), dim/4 frequencies."""
     level = _c(level.detach().reshape(-1).float())
@@ -757,7 +788,8 @@ class _AttentionFn(torch.autograd.Function):
         out = torch.empty(S, C, H, W, device=qkv.device, dtype=torch.float32)
         if L in (64, 256) and C % 32 == 0:        # fused flash-style kernel, scores stay in registers
             P = torch.empty(S, L, L, device=qkv.device, dtype=torch.float32) if need_p else None
-            _lib.call("vf_attention_fwd", _ptr(qkv), _ptr(out), _ptr(P), S, C, L, _stream())
+            _launch("attn_fwd", 4.0 * S * L * L * C, "vf_attention_fwd", _ptr(qkv), _ptr(out), _ptr(P), S, C, L, _stream(),
+                    nbytes=4.0 * (qkv.numel() + out.numel() + (S * L * L if need_p else 0)))
         else:                                     # generic sizes: materialised scores
             P = torch.empty(S, L, L, device=qkv.device, dtype=torch.float32)
             _bgemm(qkv, qkv, P, None, S, L, L, C, (C3 * L, 1, L), (C3 * L, L, 1), (L * L, L, 1), alpha,
@@ -822,14 +854,26 @@ def concat_channels(a, b):
 
 # ---------------------------------------------------------------------------------------------
 # ViewFusion glue
+_VC_CACHE = []            # [(device view_count tensor, version, (off, S, maxV))], most recent first, bounded
+
+
 def view_offsets(view_count, device):
     """view_count (list / CPU tensor / device tensor) -> (off int32 [B+1] on device, S, maxV).
 
-    A CPU-side view_count (what the reference's training loop produces, experiment.py:277-279)
-    needs no device sync; a device tensor costs one D2H copy, like the reference's .tolist().
+    A CPU-side view_count (what the harness and INTEGRATION.md hand over) needs no device sync.  A DEVICE tensor
+    (what the reference's loops produce with `.to(device)`, experiment.py:277-279, 476-478) must be read back once,
+    because S sizes every allocation -- the same one D2H the reference pays in `cumsum(view_count).tolist()`
+    (view_fusion.py:95, 244); the result is remembered per tensor object and version, so a caller that drives
+    `p_sample` / `p_mean_variance` step by step with the same device tensor syncs once, not once per step
+    (`generate` resolves it once per call anyway).
     """
-    if torch.is_tensor(view_count):
+    if torch.is_tensor(view_count) and view_count.is_cuda:
+        for ent in _VC_CACHE:
+            if ent[0] is view_count and ent[1] == view_count._version:
+                return ent[2]
         vc = view_count.detach().cpu().tolist()
+    elif torch.is_tensor(view_count):
+        vc = view_count.detach().tolist()
     else:
         vc = [int(v) for v in view_count]
     off = [0]
@@ -840,7 +884,11 @@ def view_offsets(view_count, device):
     t = torch.tensor(off, dtype=torch.int32)
     if device.type == "cuda":
         t = t.pin_memory().to(device, non_blocking=True)
-    return t, off[-1], max(vc)
+    out = (t, off[-1], max(vc))
+    if torch.is_tensor(view_count) and view_count.is_cuda:
+        _VC_CACHE.insert(0, (view_count, view_count._version, out))
+        del _VC_CACHE[4:]
+    return out
 
 
 def gather_level(gammas, t, u=None):
@@ -854,17 +902,20 @@ def gather_level(gammas, t, u=None):
 
 
 def stack_views(y_cond, y_t, noise, level, angle, off, S, x=None, copy_cond=True):
-    """Ragged stacking (+ optional q_sample): -> x (S,6,H,W), level_s (S,1), angle_s (S,1)."""
+    """Ragged stacking (+ optional q_sample): -> x (S,Cc+3,H,W), level_s (S,1), angle_s (S,1); Cc = y_cond's
+    channel count (3, or 6 for the `relative` configs)."""
     y_cond, y_t = _c(y_cond), _c(y_t)
     angle = _c(angle.reshape(-1).float())
     _check(y_cond, y_t, noise, level, angle)
-    B, Nmax, _, H, W = y_cond.shape
+    B, Nmax, Cc, H, W = y_cond.shape
+    if y_t.shape[1] != 3:
+        raise ValueError(f"the noisy target must have 3 channels, got {tuple(y_t.shape)}")
     if x is None:
-        x = torch.empty(S, 6, H, W, device=y_cond.device, dtype=torch.float32)
+        x = torch.empty(S, Cc + 3, H, W, device=y_cond.device, dtype=torch.float32)
     ls = torch.empty(S, 1, device=y_cond.device, dtype=torch.float32)
     as_ = torch.empty(S, 1, device=y_cond.device, dtype=torch.float32)
     _lib.call("vf_stack_views", _ptr(y_cond), _ptr(y_t), _ptr(noise), _ptr(level), _ptr(angle),
-              ctypes.c_void_p(off.data_ptr()), _ptr(x), _ptr(ls), _ptr(as_), B, Nmax, H * W, S, int(copy_cond),
+              ctypes.c_void_p(off.data_ptr()), _ptr(x), _ptr(ls), _ptr(as_), B, Nmax, Cc, H * W, S, int(copy_cond),
               _stream())
     return x, ls, as_
 

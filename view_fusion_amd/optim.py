@@ -4,28 +4,41 @@ Drop-in for `torch.optim.Adam(params, lr)` as the reference uses it (experiment.
 betas/eps, no weight decay, no amsgrad); `state_dict()` uses torch's keys (`step`, `exp_avg`,
 `exp_avg_sq`) so optimizer checkpoints interchange.  The learning rate is read from
 `param_group["lr"]` every step (the reference sets it from its LrScheduler before each step).
+
+Step counts are per parameter, as in torch: the parameters of a group that share a step count form one
+"bucket" = one launch (in the ViewFusion UNet every parameter receives a gradient every iteration, so
+there is exactly one bucket); a parameter that joins later (first gradient at iteration k) gets a bucket
+of its own with its own bias corrections.
 """
 import ctypes
 
 import torch
 
-from . import _lib
+from . import _lib, ops
 
 
 class FusedAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
-        self._plans = {}          # per param group: cached descriptor rows + pinned staging buffers
+        self._plans = {}          # per param group: buckets of {descriptor rows, staging buffers, step count}
+
+    # -- descriptor tables ---------------------------------------------------------------------------------------
+    def _flush_steps(self, gi):
+        """Write the buckets' step counters back into the per-parameter state (torch's `step` entries)."""
+        for b in self._plans.get(gi, {}).get("buckets", ()):
+            for p in b["params"]:
+                self.state[p]["step"] = torch.tensor(float(b["t"]))
 
     def _plan(self, gi, group):
-        """Static part of the descriptor table {param, grad, exp_avg, exp_avg_sq, numel, first_block}: built once
-        (state tensors never move); only the gradient pointers change from step to step."""
+        """Static part of the descriptor tables {param, grad, exp_avg, exp_avg_sq, numel, first_block}: built once
+        (state tensors never move); only the gradient pointers can change from step to step."""
         params = [p for p in group["params"] if p.grad is not None]
         key = tuple(id(p) for p in params)
         plan = self._plans.get(gi)
         if plan is not None and plan["key"] == key:
             return plan
-        rows, first = [], 0
+        self._flush_steps(gi)                          # a changed parameter set must not restart the bias correction
+        by_step = {}
         for p in params:
             if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
                 raise _lib.VFHipError("FusedAdam needs contiguous float32 GPU parameters")
@@ -34,44 +47,67 @@ class FusedAdam(torch.optim.Optimizer):
                 st["step"] = torch.tensor(0.0)
                 st["exp_avg"] = torch.zeros_like(p)
                 st["exp_avg_sq"] = torch.zeros_like(p)
-            rows.append([p.data_ptr(), 0, st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel(), first])
-            first += (p.numel() + 1023) // 1024
-        dev = params[0].device
-        plan = dict(key=key, params=params, blocks=first, t=int(float(self.state[params[0]]["step"])),
-                    host=[torch.tensor(rows, dtype=torch.int64).pin_memory() for _ in range(2)],
-                    dev=[torch.empty(len(rows), 6, dtype=torch.int64, device=dev) for _ in range(2)], flip=0)
+            by_step.setdefault(int(float(st["step"])), []).append(p)
+        buckets = []
+        for t, ps in sorted(by_step.items()):
+            rows, first = [], 0
+            for p in ps:
+                st = self.state[p]
+                rows.append([p.data_ptr(), 0, st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel(), first])
+                first += (p.numel() + 1023) // 1024
+            dev = ps[0].device
+            buckets.append(dict(params=ps, blocks=first, t=t, numel=sum(p.numel() for p in ps),
+                                host=[torch.tensor(rows, dtype=torch.int64).pin_memory() for _ in range(2)],
+                                dev=[torch.empty(len(rows), 6, dtype=torch.int64, device=dev) for _ in range(2)],
+                                ptrs=[None, None], done=[None, None], flip=0))
+        plan = dict(key=key, buckets=buckets)
         self._plans[gi] = plan
         return plan
 
     def state_dict(self):
-        for plan in self._plans.values():        # the per-parameter step counters are kept lazily
-            for p in plan["params"]:
-                self.state[p]["step"] = torch.tensor(float(plan["t"]))
+        for gi in self._plans:                         # the per-parameter step counters are kept lazily
+            self._flush_steps(gi)
         return super().state_dict()
 
     def load_state_dict(self, sd):
         super().load_state_dict(sd)
         self._plans = {}
 
+    # -- the step ------------------------------------------------------------------------------------------------
     @torch.no_grad()
     def step(self, closure=None):
         loss = None
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        stream = torch.cuda.current_stream()
         for gi, group in enumerate(self.param_groups):
             if not any(p.grad is not None for p in group["params"]):
                 continue
-            plan = self._plan(gi, group)
-            plan["t"] += 1
-            t = plan["t"]
-            plan["flip"] ^= 1                     # two staging buffers: the previous step's copy may still be queued
-            host, desc = plan["host"][plan["flip"]], plan["dev"][plan["flip"]]
-            grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in plan["params"]]
-            host[:, 1] = torch.tensor([g.data_ptr() for g in grads], dtype=torch.int64)
-            desc.copy_(host, non_blocking=True)
             b1, b2 = group["betas"]
-            _lib.call("vf_adam_multi", ctypes.c_void_p(desc.data_ptr()), len(grads), plan["blocks"],
-                      float(group["lr"]), float(b1), float(b2), float(group["eps"]), 1.0 - b1 ** t, 1.0 - b2 ** t,
-                      ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+            for b in self._plan(gi, group)["buckets"]:
+                b["t"] += 1
+                t = b["t"]
+                grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in b["params"]]
+                ptrs = [g.data_ptr() for g in grads]
+                f = b["flip"]
+                if b["ptrs"][f] != ptrs:               # gradient arena / stable allocations: the table is reused as is
+                    f = b["flip"] = f ^ 1
+                    if b["ptrs"][f] != ptrs:
+                        # two staging buffers, each guarded by an event: the H2D copy that last read this pinned
+                        # buffer (two steps ago) must have executed before the host overwrites it -- the host may
+                        # run several iterations ahead of the GPU
+                        if b["done"][f] is not None:
+                            b["done"][f].synchronize()
+                        b["host"][f][:, 1] = torch.tensor(ptrs, dtype=torch.int64)
+                        b["dev"][f].copy_(b["host"][f], non_blocking=True)
+                        ev = torch.cuda.Event()
+                        ev.record(stream)
+                        b["done"][f], b["ptrs"][f] = ev, ptrs
+                ops._launch("adam", 0.0, "vf_adam_multi", ctypes.c_void_p(b["dev"][f].data_ptr()), len(grads), b["blocks"],
+                            float(group["lr"]), float(b1), float(b2), float(group["eps"]), 1.0 - b1 ** t, 1.0 - b2 ** t,
+                            ctypes.c_void_p(stream.cuda_stream), nbytes=28.0 * b["numel"])   # 4 reads + 3 writes
+                # the kernel writes through raw pointers: tell autograd (and the packed-weight caches of ops.py,
+                # which are keyed on the version counter) that the parameters changed
+                torch.autograd.graph.increment_version(b["params"])
         return loss

@@ -16,7 +16,10 @@ The slot order is the order in which gradients become ready, observed on the fir
 that the parameters of one layer stay adjacent; the first iteration itself reduces from a copy.
 A gradient produced outside our kernels (or by a stand-in torch module in the CPU tests) is
 moved into its slot by the hook -- the arena is a correct reducer for any module, the zero-copy
-path is an optimisation on top.
+path is an optimisation on top.  A parameter used by several layers of one graph gets its slot
+handed out once per iteration; the other uses return ordinary tensors that autograd adds.
+Gradient accumulation over several backward passes per optimizer step is NOT supported (the
+reference never does it, experiment.py:286-293) and raises.
 
 Single-process training (world 1) never constructs an arena.
 """
@@ -48,6 +51,7 @@ class GradArena:
         self.flat = None                                      # laid out at the end of the first iteration
         self.fired = []                                       # first iteration: parameter indices in ready order
         self.got = [False] * len(self.params)
+        self.handed = set()
         self.works = []
         self.copied = 0                                       # gradients not born in their slot (stats, per step)
         for i, p in enumerate(self.params):
@@ -93,6 +97,7 @@ class GradArena:
         self.pending = list(self.seg_count)
         self.launched = [False] * len(self.seg_range)
         self.got = [False] * len(self.params)
+        self.handed = set()                                   # slots given to a backward kernel this iteration
 
     def _view(self, i):
         p, o = self.params[i], self.off[i]
@@ -103,8 +108,9 @@ class GradArena:
         """Fresh alias of p's gradient slot, or None when there is no layout yet, p is unknown, or p already holds
         a gradient (accumulation over several backward passes must add, not overwrite)."""
         i = self.index.get(id(p))
-        if i is None or self.flat is None or p.grad is not None:
-            return None
+        if i is None or self.flat is None or p.grad is not None or i in self.handed:
+            return None                                       # second use of a shared layer: autograd must ADD
+        self.handed.add(i)
         return self._view(i)
 
     def slot_pair(self, p, q):
@@ -113,16 +119,22 @@ class GradArena:
         if i is None or j is None or self.flat is None or p.grad is not None or q.grad is not None:
             return None
         n = p.numel()
-        if q.numel() != n or self.off[j] != self.off[i] + n:
+        if q.numel() != n or self.off[j] != self.off[i] + n or i in self.handed or j in self.handed:
             return None
+        self.handed.update((i, j))
         return self.flat[self.off[i]:self.off[i] + 2 * n].view(2, n)
 
     # -- autograd thread ----------------------------------------------------------------------------------------
     def _ready(self, i, p):
-        self.got[i] = True
         if self.flat is None:
+            self.got[i] = True
             self.fired.append(i)
             return
+        if self.got[i]:
+            # a second backward pass before finish(): the slot's segment may already have been averaged in place
+            raise RuntimeError("GradArena does not support gradient accumulation over several backward passes per "
+                               "optimizer step (use VF_REDUCER=ddp with no_sync() for that)")
+        self.got[i] = True
         g = p.grad
         if g.data_ptr() != self.base + 4 * self.off[i] or not g.is_contiguous():
             s = self._view(i)

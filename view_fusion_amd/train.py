@@ -40,15 +40,25 @@ class LrScheduler:
 
 
 def init_distributed():
-    """(rank, local_rank, world).  torchrun env -> RCCL process group; else single process."""
+    """(rank, local_rank, world).  torchrun env -> process group; else single process.
+
+    Backend: RCCL ("nccl" on ROCm) over xGMI, one rank per GPU, as the reference (utils/dist.py:21).  Two knobs exist
+    for exercising the multi-rank code path on a box with fewer GPUs than ranks (tests/test_gpu_bench_two_rank.py):
+    VF_DIST_BACKEND=gloo selects the gloo transport (RCCL refuses two ranks on one device) and VF_SHARE_GPU=1 maps
+    rank r to device r % device_count.  The process group is created BEFORE the first HIP call of the process."""
     if "WORLD_SIZE" not in os.environ or int(os.environ["WORLD_SIZE"]) <= 1:
         return 0, 0, 1
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
-    if torch.cuda.is_available():
+    backend = os.environ.get("VF_DIST_BACKEND", "nccl" if torch.cuda.device_count() > 0 else "gloo")
+    if os.environ.get("VF_SHARE_GPU") == "1" and torch.cuda.device_count() > 0:
+        local_rank %= torch.cuda.device_count()
+    if backend == "nccl":
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     else:
-        dist.init_process_group(backend="gloo")
+        dist.init_process_group(backend=backend)
+        if torch.cuda.device_count() > 0:
+            torch.cuda.set_device(local_rank)
     return dist.get_rank(), local_rank, dist.get_world_size()
 
 

@@ -36,15 +36,23 @@ def _norm_act_conv(cin, cout, groups):
 
 
 class _ResBlock(nn.Module):
-    def __init__(self, cin, cout, emb_dim, groups):
+    def __init__(self, cin, cout, emb_dim, groups, dropout=0):
         super().__init__()
         self.noise_func = _Named(noise_func=_Named(**{"0": nn.Linear(emb_dim, cout)}))
         self.block1 = _norm_act_conv(cin, cout, groups)
         self.block2 = _norm_act_conv(cout, cout, groups)
         self.res_conv = nn.Conv2d(cin, cout, 1) if cin != cout else nn.Identity()
         self.groups = groups
+        self.dropout = float(dropout)      # reference: nn.Dropout in block2 only (slot "2", no parameters), unet.py:236
 
-    def forward(self, x, e, skip=None, tap=False):
+    def _drop(self, a, draws):
+        """block2's nn.Dropout between Swish and the conv: identity in eval mode, as in torch."""
+        if self.dropout == 0 or not self.training:
+            return a
+        from . import ops
+        return ops.dropout(a, self.dropout, next(draws) if draws is not None else None)
+
+    def forward(self, x, e, skip=None, tap=False, draws=None):
         """tap=True (encoder blocks): also return a handle on the INPUT x for the decoder's skip connection, whose
         gradient is then added inside this block's GroupNorm backward instead of by an autograd add.
         e = this block's FeatureWiseAffine Linear(emb), (S,Cout): all blocks' are computed in one grouped
@@ -60,13 +68,13 @@ class _ResBlock(nn.Module):
         if skip is not None:
             a, x1, x2 = ops.group_norm_cat_skip(x, skip, b1["0"].weight, b1["0"].bias, self.groups, silu=True)
             h = ops.conv2d(a, b1["3"], view_bias=e)
-            a = ops.group_norm(h, b2["0"].weight, b2["0"].bias, self.groups, silu=True)
+            a = self._drop(ops.group_norm(h, b2["0"].weight, b2["0"].bias, self.groups, silu=True), draws)
             return ops.conv2d(a, b2["3"], residual=ops.conv1x1_cat(x1, x2, self.res_conv), twin=self.res_conv)
         # x feeds both the first GroupNorm and the residual branch: the GN op hands x back so that
         # the residual gradient is summed inside its backward kernel
         a, xs, xt = ops.group_norm_skip(x, b1["0"].weight, b1["0"].bias, self.groups, silu=True, tap=True)
         h = ops.conv2d(a, b1["3"], view_bias=e)
-        a = ops.group_norm(h, b2["0"].weight, b2["0"].bias, self.groups, silu=True)
+        a = self._drop(ops.group_norm(h, b2["0"].weight, b2["0"].bias, self.groups, silu=True), draws)
         twin = None if isinstance(self.res_conv, nn.Identity) else self.res_conv
         skip = xs if twin is None else ops.conv2d(xs, twin)
         y = ops.conv2d(a, b2["3"], residual=skip, twin=twin)
@@ -90,19 +98,19 @@ class _SelfAttention(nn.Module):
 
 
 class _ResAttnBlock(nn.Module):
-    def __init__(self, cin, cout, emb_dim, groups, with_attn):
+    def __init__(self, cin, cout, emb_dim, groups, with_attn, dropout=0):
         super().__init__()
         self.with_attn = with_attn
-        self.res_block = _ResBlock(cin, cout, emb_dim, groups)
+        self.res_block = _ResBlock(cin, cout, emb_dim, groups, dropout)
         if with_attn:
             self.attn = _SelfAttention(cout, groups)
 
-    def forward(self, x, e, skip=None, tap=False):
+    def forward(self, x, e, skip=None, tap=False, draws=None):
         xt = None
         if tap:
-            x, xt = self.res_block(x, e, skip, tap=True)
+            x, xt = self.res_block(x, e, skip, tap=True, draws=draws)
         else:
-            x = self.res_block(x, e, skip)
+            x = self.res_block(x, e, skip, draws=draws)
         x = self.attn(x) if self.with_attn else x
         return (x, xt) if tap else x
 
@@ -123,10 +131,13 @@ class UNet(nn.Module):
                  channel_mults=(1, 2, 4, 8, 8), attn_res=(8,), res_blocks=3, dropout=0,
                  with_noise_level_emb=True, image_size=128):
         super().__init__()
-        if dropout != 0:
-            raise NotImplementedError("dropout != 0 is never used by the reference configs")
         if not with_noise_level_emb:
-            raise NotImplementedError("with_noise_level_emb=False is never used by the reference configs")
+            # the reference's own constructor fails on this branch: it builds FeatureWiseAffine(None, ...) ->
+            # nn.Linear(None, C) -> TypeError (unet.py:33-35, 52-58, 165); same error type here
+            raise TypeError("with_noise_level_emb=False: the reference UNet cannot be constructed without the "
+                            "noise-level embedding (nn.Linear(None, C) in FeatureWiseAffine, model/unet.py:165)")
+        if not 0 <= dropout < 1:
+            raise ValueError(f"dropout probability has to be in [0, 1), got {dropout}")
         self.inner_channel = inner_channel
         self.noise_level_mlp = _Named(**{"0": nn.Linear(inner_channel, inner_channel * 4),
                                          "2": nn.Linear(inner_channel * 4, inner_channel)})
@@ -139,7 +150,7 @@ class UNet(nn.Module):
         for lvl, mult in enumerate(channel_mults):
             width = inner_channel * mult
             for _ in range(res_blocks):
-                downs.append(_ResAttnBlock(ch, width, emb, norm_groups, res in attn_res))
+                downs.append(_ResAttnBlock(ch, width, emb, norm_groups, res in attn_res, dropout))
                 ch = width
                 skips.append(ch)
             if lvl != last:
@@ -147,13 +158,13 @@ class UNet(nn.Module):
                 skips.append(ch)
                 res //= 2
         self.downs = nn.ModuleList(downs)
-        self.mid = nn.ModuleList([_ResAttnBlock(ch, ch, emb, norm_groups, True),
-                                  _ResAttnBlock(ch, ch, emb, norm_groups, False)])
+        self.mid = nn.ModuleList([_ResAttnBlock(ch, ch, emb, norm_groups, True, dropout),
+                                  _ResAttnBlock(ch, ch, emb, norm_groups, False, dropout)])
         ups = []
         for lvl in reversed(range(len(channel_mults))):
             width = inner_channel * channel_mults[lvl]
             for _ in range(res_blocks + 1):
-                ups.append(_ResAttnBlock(ch + skips.pop(), width, emb, norm_groups, res in attn_res))
+                ups.append(_ResAttnBlock(ch + skips.pop(), width, emb, norm_groups, res in attn_res, dropout))
                 ch = width
             if lvl > 0:
                 ups.append(_Resample(ch, up=True))
@@ -207,9 +218,12 @@ class UNet(nn.Module):
             object.__setattr__(self, "_vf_affine", lst)
         return lst
 
-    def forward(self, x, angle, time):
-        """x (S,Cin,H,W), angle (S,1), time = noise level (S,1)  ->  (S,Cout,H,W)."""
+    def forward(self, x, angle, time, dropout_u=None):
+        """x (S,Cin,H,W), angle (S,1), time = noise level (S,1)  ->  (S,Cout,H,W).
+        dropout_u (extra, default None = torch's device RNG): the uniform draws of the residual blocks' Dropout
+        layers in execution order, for parity runs (only consulted when dropout > 0 and self.training)."""
         from . import ops
+        draws = iter(dropout_u) if dropout_u is not None else None
         if torch.is_grad_enabled() and self.final_conv["block"]["3"].weight.requires_grad:
             ops.pack_all(self, x.shape[0])   # training: all 103 conv layers re-packed (one launch per format)
         mlp = self.noise_level_mlp
@@ -224,7 +238,7 @@ class UNet(nn.Module):
         feats = []
         for layer in self.downs:
             if isinstance(layer, _ResAttnBlock):
-                x, xin = layer(x, next(es), tap=True)
+                x, xin = layer(x, next(es), tap=True, draws=draws)
                 if feats:
                     feats[-1] = xin
             elif isinstance(layer, _Resample):
@@ -235,13 +249,13 @@ class UNet(nn.Module):
         first = True
         for layer in self.mid:
             if first:
-                x, feats[-1] = layer(x, next(es), tap=True)
+                x, feats[-1] = layer(x, next(es), tap=True, draws=draws)
                 first = False
             else:
-                x = layer(x, next(es))
+                x = layer(x, next(es), draws=draws)
         for layer in self.ups:
             if isinstance(layer, _ResAttnBlock):
-                x = layer(x, next(es), feats.pop())
+                x = layer(x, next(es), feats.pop(), draws=draws)
             else:
                 x = layer(x)
         fc = self.final_conv["block"]

@@ -11,8 +11,9 @@ by a device prefix-sum of `view_count`; nothing on the path calls `.tolist()` / 
 `view_count` is handed over as a CPU tensor or list (as the reference's training loop does).
 
 Extras (default None = reference behaviour): `forward(..., t=, u=)` and
-`generate(..., z_seq=)` inject the random draws so that runs can be compared bit-for-bit
-against the CPU oracle; `sample()` is an alias of `generate()`.
+`generate(..., z_seq=)` / `forward(generate=True, y_t=, z_seq=)` inject the random draws so that
+runs -- also the sampler drivers, which reach generate() through forward() as the reference's
+do -- can be compared against the CPU oracle; `sample()` is an alias of `generate()`.
 """
 import torch
 from torch import nn
@@ -164,9 +165,10 @@ class ViewFusion(nn.Module):
     sample = generate
 
     # -- training ---------------------------------------------------------------------------
-    def forward(self, y_cond, view_count, angle, y_0=None, noise=None, generate=False, t=None, u=None):
+    def forward(self, y_cond, view_count, angle, y_0=None, noise=None, generate=False, t=None, u=None, y_t=None,
+                z_seq=None, use_graph=None):
         if generate:                      # generate() wrapped in forward for DDP, as in the reference
-            return self.generate(y_cond, view_count, angle)
+            return self.generate(y_cond, view_count, angle, y_t=y_t, z_seq=z_seq, use_graph=use_graph)
         from . import ops
         b = y_0.shape[0]
         dev = y_0.device
