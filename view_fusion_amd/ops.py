@@ -21,8 +21,13 @@ def _ptr(t, offset_elems=0):
     return ctypes.c_void_p(t.data_ptr() + 4 * offset_elems)
 
 
+def _raw_stream():
+    # torch.cuda.current_stream() builds a Python Stream object (~5 us); the raw handle is all a launcher needs
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+
+
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return ctypes.c_void_p(_raw_stream())
 
 
 def _check(*tensors):
@@ -63,7 +68,7 @@ _ws = {}
 
 
 def _workspace(device, nfloats):
-    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    key = (device, _raw_stream())
     buf = _ws.get(key)
     if buf is None or buf.numel() < nfloats:
         buf = torch.empty(int(nfloats), device=device, dtype=torch.float32)

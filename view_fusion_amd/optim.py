@@ -81,6 +81,7 @@ class FusedAdam(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         stream = torch.cuda.current_stream()
+        raw = ctypes.c_void_p(stream.cuda_stream)
         for gi, group in enumerate(self.param_groups):
             if not any(p.grad is not None for p in group["params"]):
                 continue
@@ -106,7 +107,7 @@ class FusedAdam(torch.optim.Optimizer):
                         b["done"][f], b["ptrs"][f] = ev, ptrs
                 ops._launch("adam", 0.0, "vf_adam_multi", ctypes.c_void_p(b["dev"][f].data_ptr()), len(grads), b["blocks"],
                             float(group["lr"]), float(b1), float(b2), float(group["eps"]), 1.0 - b1 ** t, 1.0 - b2 ** t,
-                            ctypes.c_void_p(stream.cuda_stream), nbytes=28.0 * b["numel"])   # 4 reads + 3 writes
+                            raw, nbytes=28.0 * b["numel"])   # 4 reads + 3 writes
                 # the kernel writes through raw pointers: tell autograd (and the packed-weight caches of ops.py,
                 # which are keyed on the version counter) that the parameters changed
                 torch.autograd.graph.increment_version(b["params"])

@@ -107,7 +107,8 @@ class Trainer:
         lr = self.sched.get_cur_lr(self.it)
         for gparam in self.opt.param_groups:
             gparam["lr"] = lr
-        self.model.train()
+        if not self.model.training:        # Module.train() walks all ~1400 submodules (2 ms): only when the mode changes
+            self.model.train()
         self.opt.zero_grad()
         loss = self.model(y_0=batch["y_0"], y_cond=batch["y_cond"], view_count=batch["view_count"],
                           angle=batch["angle"], **extra)
