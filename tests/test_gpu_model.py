@@ -266,7 +266,7 @@ def test_gradient_arena_matches_plain_training(dev):
         return vf, tr, copied
 
     plain, _, _ = run(1)
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    train.init_rccl_group(0, rank=0, world_size=1)            # the harness' own group setup (high-priority RCCL streams)
     try:
         vf, tr, copied = run(2)                          # world=2 only selects the reducer; the group has one rank
         a = tr.arena

@@ -22,12 +22,14 @@ for _ in range(steps):
 torch.cuda.synchronize()
 log, ops.KERNEL_LOG = ops.KERNEL_LOG, None
 agg = {}
-for kind, flops, e0, e1, tag, _name in log:
-    a = agg.setdefault((kind,) + tag, [0.0, 0.0, 0])
+for kind, flops, e0, e1, tag, name, _nb in log:
+    if tag is None:
+        continue
+    a = agg.setdefault((kind + ('/W' if name.startswith('vf_wino') else '/D'),) + tag, [0.0, 0.0, 0])
     a[0] += flops; a[1] += e0.elapsed_time(e1) * 1e-3; a[2] += 1
 tot = {}
 for k, (f, t, n) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-    print(f"{k[0]:11s} Cin={k[1]:4d} Cout={k[2]:4d} H={k[3]:3d} KS={k[4]} m={k[5]}  n/step={n // steps:3d} "
+    print(f"{k[0]:13s} Cin={k[1]:4d} Cout={k[2]:4d} H={k[3]:3d} KS={k[4]} m={k[5]}  n/step={n // steps:3d} "
           f"avg={t / n * 1e6:8.1f}us  tot/step={t / steps * 1e3:7.2f}ms  {f / t / 1e12:6.1f} TF")
     x = tot.setdefault(k[0], [0.0, 0.0]); x[0] += f; x[1] += t
 for k, (f, t) in tot.items():

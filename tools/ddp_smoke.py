@@ -25,7 +25,7 @@ def child(kind):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ["VF_REDUCER"] = kind
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        train.init_rccl_group(0, rank=0, world_size=1)
     model = train.build_model(device="cuda:0")
     tr = train.Trainer(model, world=2 if kind != "none" else 1, local_rank=0)   # world=2 only selects the reducer
     batch = train.synthetic_batch(16, 6, 64, torch.device("cuda:0"))

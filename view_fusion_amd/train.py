@@ -39,6 +39,23 @@ class LrScheduler:
         return self.peak_lr * self.decay_rate ** ((it - self.peak_it) / self.decay_it)
 
 
+def init_rccl_group(local_rank, rank=None, world_size=None):
+    """RCCL ("nccl" on ROCm) process group for one rank per GPU.  RCCL's kernels run on HIGH-PRIORITY streams: the
+    compute kernels of this engine (one 512-thread Winograd workgroup per CU, all of its LDS and registers) leave no
+    room for a collective's workgroups to co-reside, so the segment all-reduces that the gradient arena issues during
+    the backward pass can only run when a CU frees up between workgroup rounds -- with priority they get those CUs
+    first instead of queueing behind the whole next conv launch.  Knobs left to the environment (RCCL defaults are
+    kept): NCCL_ALGO / NCCL_PROTO / NCCL_MIN_NCHANNELS; the payload is 6 segments of ~22 MiB per step, so the
+    bandwidth-optimal ring / direct algorithms apply, not the latency ones."""
+    torch.cuda.set_device(local_rank)
+    kw = {} if rank is None else dict(rank=rank, world_size=world_size)
+    try:
+        opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+        dist.init_process_group(backend="nccl", pg_options=opts, device_id=torch.device("cuda", local_rank), **kw)
+    except (AttributeError, TypeError):          # a torch build without the option object
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), **kw)
+
+
 def init_distributed():
     """(rank, local_rank, world).  torchrun env -> process group; else single process.
 
@@ -53,8 +70,7 @@ def init_distributed():
     if os.environ.get("VF_SHARE_GPU") == "1" and torch.cuda.device_count() > 0:
         local_rank %= torch.cuda.device_count()
     if backend == "nccl":
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        init_rccl_group(local_rank)
     else:
         dist.init_process_group(backend=backend)
         if torch.cuda.device_count() > 0:
