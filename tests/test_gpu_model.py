@@ -593,3 +593,37 @@ def test_device_view_count_is_resolved_once(dev):
     assert ops.view_offsets(torch.tensor([2, 1, 3]), dev)[1:] == (6, 3)
     with pytest.raises(ValueError):
         ops.view_offsets([2, 0], dev)
+
+
+@pytest.mark.parametrize("hp,S", [
+    (dict(in_channel=6, out_channel=6, inner_channel=64, norm_groups=32, channel_mults=(1, 1, 2, 2), attn_res=(16,),
+          res_blocks=1, image_size=128), 2),          # the reference's default image size: 128x128 ... 16x16 maps
+          # (>= 2 channels per group everywhere: with one, biases in front of a GroupNorm have analytically-zero
+          # gradients that are pure round-off in the oracle and grow with the map size)
+    (dict(in_channel=6, out_channel=3, inner_channel=64, norm_groups=16, channel_mults=(1, 2), attn_res=(32, 16),
+          res_blocks=2, image_size=32), 5),           # out_channel 3 (no-weighting configs), 16 groups, attention at 32x32
+])
+def test_other_geometries_vs_oracle(dev, hp, S):
+    """Constructor envelopes beyond the shipped YAMLs: image_size 128 (the reference's default, unet.py:20) and 32,
+    another group count, attention on a 32x32 map (L = 1024: the generic attention path), out_channel 3 --
+    forward + every gradient vs the oracle."""
+    from oracle import unet_ref
+    net = make_unet(hp, dev)
+    g = torch.Generator().manual_seed(77)
+    hw = hp["image_size"]
+    x = torch.rand(S, 6, hw, hw, generator=g)
+    angle = 2 * np.pi / 24 * torch.randint(0, 24, (S, 1), generator=g).float()
+    level = torch.rand(S, 1, generator=g)
+    xg = x.to(dev).requires_grad_(True)
+    y = net(xg, angle.to(dev), level.to(dev))
+    gy = torch.randn(y.shape, generator=g)
+    (y * gy.to(dev)).sum().backward()
+    sd = cpu_sd(net)
+    xc = x.clone().requires_grad_(True)
+    yc = unet_ref.unet_forward(sd, hp, xc, angle, level)
+    (yc * gy).sum().backward()
+    np.testing.assert_allclose(y.detach().cpu().numpy(), yc.detach().numpy(), rtol=1e-4, atol=5e-5)
+    assert float((xg.grad.cpu() - xc.grad).norm() / xc.grad.norm()) < 1e-4
+    for k, p in net.named_parameters():
+        a, b = p.grad.detach().cpu().double(), sd[k].grad.double()
+        assert float((a - b).norm()) <= 1e-4 * float(b.norm()) + 3e-5 * b.numel() ** 0.5, k
