@@ -11,7 +11,8 @@ import os
 import torch  # noqa: F401  (loads libamdhip64 first)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libvf_hip.so")
+# VF_HIP_LIB: tuning aid -- load another build of the same C ABI (A/B timing of kernel variants in one process tree)
+LIB_PATH = os.environ.get("VF_HIP_LIB") or os.path.join(_HERE, "lib", "libvf_hip.so")
 
 _P, _I, _L, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
 

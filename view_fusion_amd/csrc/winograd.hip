@@ -35,7 +35,10 @@ struct WinoArgs {
     // computes the p-th K range of tile nfull + j and leaves a raw partial output in ws (wino_fixup_kernel)
     int nfull, tail_split;
     float* ws;
+    int npers;            // persistent workgroups = min(nfull, WINO_PERSIST); blocks >= npers are the tail parts
 };
+
+constexpr int WINO_PERSIST = 256;     // one persistent workgroup per CU
 
 template <int LOGW, int MODE>
 struct WGeo {
@@ -86,6 +89,13 @@ __device__ __forceinline__ float4 wino_load4(const float* __restrict__ x, int S,
 // the same block, so while one issues its staging / transform instructions the other keeps the
 // matrix pipe busy.  The output transform is linear in the rows, so each half produces a partial
 // 2x2 tile and the halves are summed through LDS once, in the epilogue.
+//
+// PERSISTENT over the whole tiles: the grid holds min(nfull, 256) workgroups (one per CU) and workgroup b computes the
+// tiles b, b + 256, ... -- the order the hardware would have dispatched them in.  What that buys: the first global
+// loads of the NEXT tile (U chunk 0, raw rows of chunks 0 and 1) are issued before the epilogue of the current one and
+// land while it runs, instead of a fresh workgroup starting with a load round trip (~4.5k cycles of a ~52k-cycle tile
+// on the 8-chunk 64->64 layers) with nothing else resident on its CU to cover it.  The K-split partial tiles of the
+// tail plan stay one-shot workgroups behind the persistent ones.
 template <int LOGW, int MODE>
 __global__ __launch_bounds__(512, 2) void wino_conv_kernel(WinoArgs a) {
     using G = WGeo<LOGW, MODE>;
@@ -111,61 +121,88 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(WinoArgs a) {
     const int cw = wid & 1, tw = (wid >> 1) & 1, kh = wid >> 2;
     const int li = lane & 31, lh = lane >> 5;
     const int ncot = a.CoutP / WTCO;
-    const bool partial = (int)blockIdx.x >= a.nfull;
-    const int tail_id = partial ? (int)blockIdx.x - a.nfull : 0;
-    const unsigned logical = partial ? a.nfull + tail_id / a.tail_split : xcd_remap(blockIdx.x, a.nfull);
-    const int cot = logical % ncot;
-    const int wg = logical / ncot;
-    const int s = G::g_view(wg);                        // first (for 8x8 maps: of four) view of this workgroup
-    const int r0 = G::g_row(wg);                        // first output row of this workgroup
-    const int co0 = cot * WTCO;
-    int c0 = 0, nch = a.CinP / WCK;                     // this workgroup's chunk range [c0, c0 + nch)
-    if (partial) {
+    const bool partial = (int)blockIdx.x >= a.npers;
+    const int tail_id = partial ? (int)blockIdx.x - a.npers : 0;
+    int c0 = 0, nch = a.CinP / WCK;                     // this workgroup's chunk range [c0, c0 + nch) (same for every
+    if (partial) {                                      // tile of a persistent workgroup: the whole K)
         const int per = (nch + a.tail_split - 1) / a.tail_split;
         c0 = (tail_id % a.tail_split) * per;
         nch = max(0, min(nch - c0, per));
     }
-
-#ifdef VF_CONV_STAMPS   // diagnostic build only (tools/wino_stamps.py)
-    long long st_[2] = {clock64(), 0}, rt0_ = wall_clock64();
-#endif
     const int clast = max(nch - 1, 0);
-    const float* usrc = a.u + ((size_t)cot * (a.CinP / WCK) + c0) * USZ;
-    // named registers + macros (not arrays behind lambdas: those end up in scratch memory)
-    float4 ur0, ur1, ur2, ur3;
-    float4 xr0 = make_float4(0.f, 0.f, 0.f, 0.f), xr1 = xr0;
-#define VF_ULOAD(I, C) ur##I = *reinterpret_cast<const float4*>(usrc + (size_t)(C) * USZ + 4 * (tid + (I) * NT_))
-#define VF_USTORE(I, BUF) *reinterpret_cast<float4*>(Ul + (BUF) * USZ + 4 * (tid + (I) * NT_)) = ur##I
-#define VF_ULOAD_ALL(C) { VF_ULOAD(0, C); VF_ULOAD(1, C); VF_ULOAD(2, C); VF_ULOAD(3, C); }
-#define VF_USTORE_ALL(BUF) { VF_USTORE(0, BUF); VF_USTORE(1, BUF); VF_USTORE(2, BUF); VF_USTORE(3, BUF); }
 
-    // per-thread staging descriptors of the raw input rows, fixed over the chunk loop
-    int xgo[2], xlo[2], xci[2];
-    bool xok[2];
+    // per-thread staging layout of the raw input rows: tile independent (element e = tid + 512 i of the patch ->
+    // (channel, patch row, float4 column)); only what the chunk loop touches is kept in registers
+    int xlo[2], xci[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int e = tid + i * NT_;
-        const int q = e % G::Q;
         const int t1 = e / G::Q;
-        const int pr = t1 % G::PH, ci = t1 / G::PH;
-        const int img = pr / G::RPI;
-        const int uy = r0 + pr % G::RPI - 1;
-        xok[i] = i < NXR && e < NX4 && s + img < a.S && uy >= 0 && uy < G::H;
-        xci[i] = ci;
-        xgo[i] = (img * a.Cin + ci) * (G::SH * G::SW) + (MODE == 0 ? uy * G::SW + 4 * q : (uy >> 1) * G::SW + 2 * q);
-        xlo[i] = ci * G::PS + pr * G::PW + 4 * q + 4;
+        xci[i] = t1 / G::PH;
+        xlo[i] = xci[i] * G::PS + (t1 % G::PH) * G::PW + 4 * (e % G::Q) + 4;
     }
-    const float* xsrc = a.x + (size_t)s * a.Cin * (G::SH * G::SW);
-    auto fetch_x = [&](int i, int c) -> float4 {
+
+    // what changes from tile to tile and is needed inside the chunk loop: the weight / input bases and this thread's
+    // source offsets (negative: row outside the image or the batch -> zeros).  The tile's position itself is
+    // re-derived from its linear id where the epilogue needs it.
+    struct Tile {
+        const float* usrc;
+        const float* xsrc;
+        int xgo0, xgo1;
+    };
+    auto tile_pos = [&](unsigned logical, int& s_, int& r0_, int& cot_) {
+        cot_ = logical % ncot;
+        const int wg = logical / ncot;
+        s_ = G::g_view(wg);                             // first (for 8x8 maps: of four) view of this tile
+        r0_ = G::g_row(wg);                             // first output row
+    };
+    auto make_tile = [&](unsigned logical) -> Tile {
+        Tile t;
+        int ts, tr0, cot;
+        tile_pos(logical, ts, tr0, cot);
+        t.usrc = a.u + ((size_t)cot * (a.CinP / WCK) + c0) * USZ;
+        t.xsrc = a.x + (size_t)ts * a.Cin * (G::SH * G::SW);
+        int go[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int e = tid + i * NT_;
+            const int q = e % G::Q, t1 = e / G::Q;
+            const int pr = t1 % G::PH, ci = t1 / G::PH;
+            const int img = pr / G::RPI;
+            const int uy = tr0 + pr % G::RPI - 1;
+            const bool ok = i < NXR && e < NX4 && ts + img < a.S && uy >= 0 && uy < G::H;
+            go[i] = ok ? (img * a.Cin + ci) * (G::SH * G::SW) + (MODE == 0 ? uy * G::SW + 4 * q : (uy >> 1) * G::SW + 2 * q)
+                       : -1;
+        }
+        t.xgo0 = go[0]; t.xgo1 = go[1];
+        return t;
+    };
+    auto fetch_x = [&](const Tile& t, int i, int c) -> float4 {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (xok[i] && (c0 + c) * WCK + xci[i] < a.Cin) {
-            const float* p = xsrc + (size_t)(c0 + c) * WCK * (G::SH * G::SW) + xgo[i];
+        const int go = i == 0 ? t.xgo0 : t.xgo1;
+        if (go >= 0 && (c0 + c) * WCK + xci[i] < a.Cin) {
+            const float* p = t.xsrc + (size_t)(c0 + c) * WCK * (G::SH * G::SW) + go;
             if (MODE == 0) v = *reinterpret_cast<const float4*>(p);
-            else { const float2 t = *reinterpret_cast<const float2*>(p); v = make_float4(t.x, t.x, t.y, t.y); }
+            else { const float2 h = *reinterpret_cast<const float2*>(p); v = make_float4(h.x, h.x, h.y, h.y); }
         }
         return v;
     };
-#define VF_XLOAD(C) { xr0 = fetch_x(0, (C)); if (NXR > 1) xr1 = fetch_x(1, (C)); }
+
+#ifdef VF_CONV_STAMPS   // diagnostic build only (tools/wino_stamps.py): clocks of the workgroup's FIRST tile
+    long long st_[2] = {clock64(), 0}, rt0_ = wall_clock64();
+#endif
+    unsigned lin = partial ? 0u : blockIdx.x;           // linear id of the current whole tile
+    const unsigned tail_logical = (unsigned)(a.nfull + tail_id / a.tail_split);
+    Tile cur = make_tile(partial ? tail_logical : xcd_remap(lin, a.nfull));
+
+    // named registers + macros (not arrays behind lambdas: those end up in scratch memory)
+    float4 ur0, ur1, ur2, ur3;
+    float4 xr0 = make_float4(0.f, 0.f, 0.f, 0.f), xr1 = xr0;
+#define VF_ULOAD(T, I, C) ur##I = *reinterpret_cast<const float4*>((T).usrc + (size_t)(C) * USZ + 4 * (tid + (I) * NT_))
+#define VF_USTORE(I, BUF) *reinterpret_cast<float4*>(Ul + (BUF) * USZ + 4 * (tid + (I) * NT_)) = ur##I
+#define VF_ULOAD_ALL(T, C) { VF_ULOAD(T, 0, C); VF_ULOAD(T, 1, C); VF_ULOAD(T, 2, C); VF_ULOAD(T, 3, C); }
+#define VF_USTORE_ALL(BUF) { VF_USTORE(0, BUF); VF_USTORE(1, BUF); VF_USTORE(2, BUF); VF_USTORE(3, BUF); }
+#define VF_XLOAD(T, C) { xr0 = fetch_x((T), 0, (C)); if (NXR > 1) xr1 = fetch_x((T), 1, (C)); }
 #define VF_XSTORE(BUF)                                                                                  \
     {                                                                                                   \
         if (tid < NX4) *reinterpret_cast<float4*>(Pl + (BUF) * PSZ + xlo[0]) = xr0;                      \
@@ -195,99 +232,221 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(WinoArgs a) {
         vo[(4 * r + 2) * WCK * WTT] = t[2] - t[1];
         vo[(4 * r + 3) * WCK * WTT] = t[1] - t[3];
     };
-
-    f32x16 acc[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) acc[k] = (f32x16){0};
-
-    // ---- prologue: U(0), rows(0), rows(1) staged; V(0) transformed; U(1), rows(2) in flight.  All three first
-    // loads are issued together (one round trip instead of two) and the next ones right after their registers are
-    // free, so they overlap the first input transform.
-    VF_ULOAD_ALL(0);
-    VF_XLOAD(0);
-    float4 yr0 = fetch_x(0, min(1, clast)), yr1 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (NXR > 1) yr1 = fetch_x(1, min(1, clast));
-    for (int i = tid; i < 2 * PSZ; i += NT_) Pl[i] = 0.f;    // halo columns stay zero in both buffers (under the loads)
-    __syncthreads();                                      // zero fill done
-    VF_USTORE_ALL(0);
-    VF_XSTORE(0);
-    if (tid < NX4) *reinterpret_cast<float4*>(Pl + PSZ + xlo[0]) = yr0;
-    if (NXR > 1 && tid + NT_ < NX4) *reinterpret_cast<float4*>(Pl + PSZ + xlo[1]) = yr1;
-    VF_ULOAD_ALL(min(1, clast));
-    VF_XLOAD(min(2, clast));
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 4; ++r) win_read_row(r, 0);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) win_write_row(r, 0);
-    __syncthreads();
-
     const int uoff = 8 * kh * WTCO * WCK + (cw * 32 + li) * WCK + 4 * (lh ^ ((li >> 4) & 1));
     const int voff = 8 * kh * WCK * WTT + 4 * lh * WTT + tw * 32 + li;
-    // The staging code of chunks c+1..c+3 runs unconditionally with the chunk index clamped to the last one
-    // (the final iterations redo harmless loads / LDS writes that nobody reads): without loop-tail branches
-    // the compiler counts outstanding loads exactly; with them it falls back to s_waitcnt vmcnt(0) in front of
-    // every staging access, i.e. a full load round trip per slice.
-    for (int c = 0; c < nch; ++c) {
-        const int cur = c & 1, nxt = cur ^ 1;
-        constexpr bool has1 = true, has2 = true, has3 = true;
-        const float* ub = Ul + cur * USZ + uoff;
-        const float* vb = Vl + cur * VSZ + voff;
-        float4 a_cur = *reinterpret_cast<const float4*>(ub);
-        float b_cur[4];
+
+    // ---- first loads of the first tile: U(0), rows(0), rows(1) -- all three issued together (one round trip)
+    VF_ULOAD_ALL(cur, 0);
+    VF_XLOAD(cur, 0);
+    float4 yr0 = fetch_x(cur, 0, min(1, clast)), yr1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (NXR > 1) yr1 = fetch_x(cur, 1, min(1, clast));
+    for (int i = tid; i < 2 * PSZ; i += NT_) Pl[i] = 0.f;    // halo columns stay zero in both buffers, for every tile
+
+    for (;;) {
+        f32x16 acc[8];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) b_cur[e] = vb[e * WTT];
+        for (int k = 0; k < 8; ++k) acc[k] = (f32x16){0};
+
+        // ---- prologue: U(0), rows(0), rows(1) staged; V(0) transformed; U(1), rows(2) in flight
+        __syncthreads();                                  // zero fill done / previous tile's epilogue done with the LDS
+        VF_USTORE_ALL(0);
+        VF_XSTORE(0);
+        if (tid < NX4) *reinterpret_cast<float4*>(Pl + PSZ + xlo[0]) = yr0;
+        if (NXR > 1 && tid + NT_ < NX4) *reinterpret_cast<float4*>(Pl + PSZ + xlo[1]) = yr1;
+        VF_ULOAD_ALL(cur, min(1, clast));
+        VF_XLOAD(cur, min(2, clast));
+        __syncthreads();
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            float4 a_nxt = a_cur;
-            float b_nxt[4];
-            // ---- side work of this slice, interleaved with the slice's own MFMAs: both waves of a SIMD run this
-            // code in phase, so side work placed in front of the MFMAs leaves the matrix pipe idle in both at once
-            // (measured: -1.35 ms per training step against "all side work, then four MFMAs").
-            // Each staging register is stored to LDS in slice i and re-loaded (two chunks ahead) in slice
-            // i+1: that leaves 7 of the 8 slices (~5000 cycles) between a global load and its use.
-            __builtin_amdgcn_sched_barrier(0);
-            acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.x, b_cur[0], acc[k], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (k + 1 < 8) {                                              // operand fragments of the next slice
-                a_nxt = *reinterpret_cast<const float4*>(ub + (k + 1) * WTCO * WCK);
+        for (int r = 0; r < 4; ++r) win_read_row(r, 0);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) b_nxt[e] = vb[(k + 1) * WCK * WTT + e * WTT];
-            }
-            if (has1) {
-                if (k < 4) win_read_row(k, nxt);                          // rows of chunk c+1
+        for (int r = 0; r < 4; ++r) win_write_row(r, 0);
+        __syncthreads();
+
+        // The staging code of chunks c+1..c+3 runs unconditionally with the chunk index clamped to the last one
+        // (the final iterations redo harmless loads / LDS writes that nobody reads): without loop-tail branches
+        // the compiler counts outstanding loads exactly; with them it falls back to s_waitcnt vmcnt(0) in front of
+        // every staging access, i.e. a full load round trip per slice.
+        for (int c = 0; c < nch; ++c) {
+            const int cb = c & 1, nxt = cb ^ 1;
+            const float* ub = Ul + cb * USZ + uoff;
+            const float* vb = Vl + cb * VSZ + voff;
+            float4 a_cur = *reinterpret_cast<const float4*>(ub);
+            float b_cur[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) b_cur[e] = vb[e * WTT];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                float4 a_nxt = a_cur;
+                float b_nxt[4];
+                // ---- side work of this slice, interleaved with the slice's own MFMAs: both waves of a SIMD run this
+                // code in phase, so side work placed in front of the MFMAs leaves the matrix pipe idle in both at once
+                // (measured: -1.35 ms per training step against "all side work, then four MFMAs").
+                // Each staging register is stored to LDS in slice i and re-loaded (two chunks ahead) in slice
+                // i+1: that leaves 7 of the 8 slices (~5000 cycles) between a global load and its use.
+                __builtin_amdgcn_sched_barrier(0);
+                acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.x, b_cur[0], acc[k], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (k + 1 < 8) {                                              // operand fragments of the next slice
+                    a_nxt = *reinterpret_cast<const float4*>(ub + (k + 1) * WTCO * WCK);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) b_nxt[e] = vb[(k + 1) * WCK * WTT + e * WTT];
+                }
+                if (k < 4) win_read_row(k, nxt);                              // rows of chunk c+1
                 if (k >= 4) win_write_row(k - 4, nxt);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.y, b_cur[1], acc[k], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (has1) {
+                __builtin_amdgcn_sched_barrier(0);
+                acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.y, b_cur[1], acc[k], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
                 if (k == 0) VF_USTORE(0, nxt);
                 if (k == 1) VF_USTORE(1, nxt);
                 if (k == 2) VF_USTORE(2, nxt);
                 if (k == 3) VF_USTORE(3, nxt);
-            }
-            if (k == 4 && has2) VF_XSTORE(cur);                           // rows of chunk c+2 -> buffer of chunk c
-            __builtin_amdgcn_sched_barrier(0);
-            acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.z, b_cur[2], acc[k], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (has2) {
-                if (k == 1) VF_ULOAD(0, min(c + 2, clast));
-                if (k == 2) VF_ULOAD(1, min(c + 2, clast));
-                if (k == 3) VF_ULOAD(2, min(c + 2, clast));
-                if (k == 4) VF_ULOAD(3, min(c + 2, clast));
-            }
-            if (k == 5 && has3) VF_XLOAD(min(c + 3, clast));
-            __builtin_amdgcn_sched_barrier(0);
-            acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.w, b_cur[3], acc[k], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (k + 1 < 8) {
-                a_cur = a_nxt;
+                if (k == 4) VF_XSTORE(cb);                                    // rows of chunk c+2 -> buffer of chunk c
+                __builtin_amdgcn_sched_barrier(0);
+                acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.z, b_cur[2], acc[k], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (k == 1) VF_ULOAD(cur, 0, min(c + 2, clast));
+                if (k == 2) VF_ULOAD(cur, 1, min(c + 2, clast));
+                if (k == 3) VF_ULOAD(cur, 2, min(c + 2, clast));
+                if (k == 4) VF_ULOAD(cur, 3, min(c + 2, clast));
+                if (k == 5) VF_XLOAD(cur, min(c + 3, clast));
+                __builtin_amdgcn_sched_barrier(0);
+                acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.w, b_cur[3], acc[k], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (k + 1 < 8) {
+                    a_cur = a_nxt;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) b_cur[e] = b_nxt[e];
+                    for (int e = 0; e < 4; ++e) b_cur[e] = b_nxt[e];
+                }
             }
+            __syncthreads();
+        }
+#ifdef VF_CONV_STAMPS
+        if (st_[1] == 0) st_[1] = clock64();
+#endif
+
+        const unsigned lin_next = lin + WINO_PERSIST;
+        const bool has_next = !partial && lin_next < (unsigned)a.nfull;      // workgroup-uniform
+        const unsigned logical_cur = partial ? tail_logical : xcd_remap(lin, a.nfull);
+        // ---- output transform Y = A^T M A.  This wave holds rows {2kh, 2kh+1} of M (acc[4*(i-2kh)+j]):
+        //   s0[j] = M0j+M1j (+M2j)      s1[j] = M1j (-M2j-M3j)     -> partial 2x2 tile, linear in the rows
+        float part[16][4];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float s0[4], s1[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float m0 = acc[j][r], m1 = acc[4 + j][r];          // rows 2kh, 2kh+1
+                s0[j] = kh == 0 ? m0 + m1 : m0;
+                s1[j] = kh == 0 ? m1 : -m0 - m1;
+            }
+            part[r][0] = s0[0] + s0[1] + s0[2];
+            part[r][1] = s0[1] - s0[2] - s0[3];
+            part[r][2] = s1[0] + s1[1] + s1[2];
+            part[r][3] = s1[1] - s1[2] - s1[3];
+        }
+        // ---- the next whole tile of this (persistent) workgroup: its first loads go out now (the accumulators are
+        // dead, so the staging registers are free) and land under the rest of the epilogue.  Issued unconditionally --
+        // the last tile re-reads its own first chunks, which nobody uses -- so that the staging registers are dead
+        // across the chunk loop instead of conditionally carried through it.
+        const Tile nx = make_tile(has_next ? xcd_remap(lin_next, a.nfull) : logical_cur);
+        VF_ULOAD_ALL(nx, 0);
+        VF_XLOAD(nx, 0);
+        yr0 = fetch_x(nx, 0, min(1, clast));
+        if (NXR > 1) yr1 = fetch_x(nx, 1, min(1, clast));
+        // The epilogue's per-lane index arithmetic is the same for every tile; left to itself the compiler hoists all of
+        // it (~50 registers) out of the tile loop and then spills it across the chunk loop.  An opaque copy of the lane
+        // id keeps it inside the epilogue, where the accumulators are dead and registers are plentiful.
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));
+        const int li_e = lane_e & 31, lh_e = lane_e >> 5;
+        float* xch = lds + (size_t)(wid & 3) * (64 * 64);                 // [value 64][lane 64] per (cw, tw) pair
+        if (kh == 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) xch[(r * 4 + q) * 64 + lane_e] = part[r][q];
         }
         __syncthreads();
+        int s, r0, cot_;
+        tile_pos(logical_cur, s, r0, cot_);
+        const int co0 = cot_ * WTCO;
+        if (kh == 0 && partial) {                            // raw partial tile: ws[tail_id][co 64][tile 64][2x2]
+            const int tl = tw * 32 + li_e;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int col = cw * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh_e;
+                float4 v;
+                v.x = part[r][0] + xch[(r * 4 + 0) * 64 + lane_e];
+                v.y = part[r][1] + xch[(r * 4 + 1) * 64 + lane_e];
+                v.z = part[r][2] + xch[(r * 4 + 2) * 64 + lane_e];
+                v.w = part[r][3] + xch[(r * 4 + 3) * 64 + lane_e];
+                *reinterpret_cast<float4*>(a.ws + (((size_t)tail_id * WTCO + col) * WTT + tl) * 4) = v;
+            }
+        } else if (kh == 0 && s + G::t_img(tw * 32 + li_e) < a.S) {
+            const int tl = tw * 32 + li_e;
+            const int sv = s + G::t_img(tl);
+            const int orow = r0 + 2 * G::t_row(tl), ocol = 2 * G::t_col(tl);
+            // every epilogue operand is fetched BEFORE the first store: loads and stores retire through one
+            // in-order counter, so a load issued after a store would wait for that store's round trip
+            float eb[16], ev[16];
+            float2 er[16][2];
+            // (one uniform branch per operand kind, the 16 loads of a kind back to back: a branch between two
+            // loads makes the compiler wait for the first before issuing the second)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                eb[r] = ev[r] = 0.f;
+                er[r][0] = er[r][1] = make_float2(0.f, 0.f);
+            }
+            if (a.bias) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co0 + cw * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh_e;
+                    eb[r] = a.bias[min(co, a.Cout - 1)];
+                }
+            }
+#ifndef VF_CONV_STAMPS
+            if (a.vbias) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co0 + cw * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh_e;
+                    ev[r] = a.vbias[(size_t)sv * a.Cout + min(co, a.Cout - 1)];
+                }
+            }
+#endif
+            if (a.res) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = min(co0 + cw * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh_e, a.Cout - 1);
+                    const size_t o = ((size_t)sv * a.Cout + co) * G::HW + (size_t)orow * G::W + ocol;
+                    er[r][0] = *reinterpret_cast<const float2*>(a.res + o);
+                    er[r][1] = *reinterpret_cast<const float2*>(a.res + o + G::W);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) eb[r] += ev[r];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + cw * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh_e;
+                if (co >= a.Cout) continue;
+                const size_t o = ((size_t)sv * a.Cout + co) * G::HW + (size_t)orow * G::W + ocol;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    float2 v = make_float2(part[r][2 * i] + xch[(r * 4 + 2 * i) * 64 + lane_e] + eb[r] + er[r][i].x,
+                                           part[r][2 * i + 1] + xch[(r * 4 + 2 * i + 1) * 64 + lane_e] + eb[r] + er[r][i].y);
+                    *reinterpret_cast<float2*>(a.y + o + i * G::W) = v;
+                }
+            }
+        }
+#ifdef VF_CONV_STAMPS
+        if (tid == 0 && a.bias == nullptr && a.vbias != nullptr && lin == blockIdx.x) {   // stamps ride in the vbias slot
+            long long* o = reinterpret_cast<long long*>(const_cast<float*>(a.vbias)) + (size_t)blockIdx.x * 8;
+            o[0] = st_[0]; o[1] = st_[1]; o[2] = clock64(); o[3] = 0; o[4] = 0; o[5] = st_[1] - st_[0];
+            o[6] = rt0_; o[7] = wall_clock64();
+        }
+#endif
+        if (!has_next) break;
+        cur = nx;
+        lin = lin_next;
     }
 #undef VF_ULOAD
 #undef VF_USTORE
@@ -295,109 +454,6 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(WinoArgs a) {
 #undef VF_USTORE_ALL
 #undef VF_XLOAD
 #undef VF_XSTORE
-#ifdef VF_CONV_STAMPS
-    st_[1] = clock64();
-#endif
-
-    // ---- output transform Y = A^T M A.  This wave holds rows {2kh, 2kh+1} of M (acc[4*(i-2kh)+j]):
-    //   s0[j] = M0j+M1j (+M2j)      s1[j] = M1j (-M2j-M3j)     -> partial 2x2 tile, linear in the rows
-    float part[16][4];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        float s0[4], s1[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float m0 = acc[j][r], m1 = acc[4 + j][r];          // rows 2kh, 2kh+1
-            s0[j] = kh == 0 ? m0 + m1 : m0;
-            s1[j] = kh == 0 ? m1 : -m0 - m1;
-        }
-        part[r][0] = s0[0] + s0[1] + s0[2];
-        part[r][1] = s0[1] - s0[2] - s0[3];
-        part[r][2] = s1[0] + s1[1] + s1[2];
-        part[r][3] = s1[1] - s1[2] - s1[3];
-    }
-    float* xch = lds + (size_t)(wid & 3) * (64 * 64);                 // [value 64][lane 64] per (cw, tw) pair
-    if (kh == 1) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) xch[(r * 4 + q) * 64 + lane] = part[r][q];
-    }
-    __syncthreads();
-    if (kh == 0 && partial) {                            // raw partial tile: ws[tail_id][co 64][tile 64][2x2]
-        const int tl = tw * 32 + li;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int col = cw * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            float4 v;
-            v.x = part[r][0] + xch[(r * 4 + 0) * 64 + lane];
-            v.y = part[r][1] + xch[(r * 4 + 1) * 64 + lane];
-            v.z = part[r][2] + xch[(r * 4 + 2) * 64 + lane];
-            v.w = part[r][3] + xch[(r * 4 + 3) * 64 + lane];
-            *reinterpret_cast<float4*>(a.ws + (((size_t)tail_id * WTCO + col) * WTT + tl) * 4) = v;
-        }
-    } else if (kh == 0 && s + G::t_img(tw * 32 + li) < a.S) {
-        const int tl = tw * 32 + li;
-        const int sv = s + G::t_img(tl);
-        const int orow = r0 + 2 * G::t_row(tl), ocol = 2 * G::t_col(tl);
-        // every epilogue operand is fetched BEFORE the first store: loads and stores retire through one
-        // in-order counter, so a load issued after a store would wait for that store's round trip
-        float eb[16], ev[16];
-        float2 er[16][2];
-        // (one uniform branch per operand kind, the 16 loads of a kind back to back: a branch between two
-        // loads makes the compiler wait for the first before issuing the second)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            eb[r] = ev[r] = 0.f;
-            er[r][0] = er[r][1] = make_float2(0.f, 0.f);
-        }
-        if (a.bias) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = co0 + cw * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                eb[r] = a.bias[min(co, a.Cout - 1)];
-            }
-        }
-#ifndef VF_CONV_STAMPS
-        if (a.vbias) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = co0 + cw * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                ev[r] = a.vbias[(size_t)sv * a.Cout + min(co, a.Cout - 1)];
-            }
-        }
-#endif
-        if (a.res) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = min(co0 + cw * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, a.Cout - 1);
-                const size_t o = ((size_t)sv * a.Cout + co) * G::HW + (size_t)orow * G::W + ocol;
-                er[r][0] = *reinterpret_cast<const float2*>(a.res + o);
-                er[r][1] = *reinterpret_cast<const float2*>(a.res + o + G::W);
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) eb[r] += ev[r];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = co0 + cw * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            if (co >= a.Cout) continue;
-            const size_t o = ((size_t)sv * a.Cout + co) * G::HW + (size_t)orow * G::W + ocol;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                float2 v = make_float2(part[r][2 * i] + xch[(r * 4 + 2 * i) * 64 + lane] + eb[r] + er[r][i].x,
-                                       part[r][2 * i + 1] + xch[(r * 4 + 2 * i + 1) * 64 + lane] + eb[r] + er[r][i].y);
-                *reinterpret_cast<float2*>(a.y + o + i * G::W) = v;
-            }
-        }
-    }
-#ifdef VF_CONV_STAMPS
-    if (tid == 0 && a.bias == nullptr && a.vbias != nullptr) {      // stamps ride in the vbias pointer slot
-        long long* o = reinterpret_cast<long long*>(const_cast<float*>(a.vbias)) + (size_t)blockIdx.x * 8;
-        o[0] = st_[0]; o[1] = st_[1]; o[2] = clock64(); o[3] = 0; o[4] = 0; o[5] = st_[1] - st_[0];
-        o[6] = rt0_; o[7] = wall_clock64();
-    }
-#endif
 }
 
 // OIHW -> transformed + packed forward  U[co tile][ci chunk][k][co 64][ci 8] = (G w G^T)_k
@@ -548,7 +604,8 @@ int launch_wino(WinoArgs a, size_t ws_floats, hipStream_t st) {
         a.tail_split = 1;
     }
     const int nt = T - a.nfull;
-    hipLaunchKernelGGL((wino_conv_kernel<LOGW, MODE>), dim3(a.nfull + nt * a.tail_split), dim3(512), 0, st, a);
+    a.npers = a.nfull < WINO_PERSIST ? a.nfull : WINO_PERSIST;
+    hipLaunchKernelGGL((wino_conv_kernel<LOGW, MODE>), dim3(a.npers + nt * a.tail_split), dim3(512), 0, st, a);
     if (nt > 0)
         hipLaunchKernelGGL((wino_fixup_kernel<LOGW>), dim3((nt * WTCO * WTT + 255) / 256), dim3(256), 0, st, a, nt);
     VF_RETURN_LAST_ERROR();
