@@ -104,7 +104,7 @@ __device__ __forceinline__ float4 load_patch4(const float* __restrict__ x, int S
 // is staged once for 64*NCO output channels -- a 64-channel workgroup of a 1x1 conv needs ~12 B/clk of
 // L2->LDS traffic per CU at full MFMA rate, which is the load path's limit.
 template <int KS, int LOGW, int MODE, int NPT, int NCO = 1>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, (KS == 1 && NPT == 1 && NCO == 1) ? 5 : 1) void conv_mfma_kernel(ConvArgs a) {
     constexpr int TPIX = 64 * NPT;            // each wave: 32 channels x (32*NPT) pixels
     using G = Geo<KS, LOGW, MODE, TPIX>;
     constexpr int CK = KS == 3 ? 8 : 32;      // input channels per K-chunk
