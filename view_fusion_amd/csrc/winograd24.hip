@@ -1,0 +1,663 @@
+// Fused Winograd convolution, forward and dgrad, for the stride-1 3x3 layers (reference model/unet.py:42,189,214):
+// the NESTED minimal filtering F(2,3) x F(4,3) -- two output rows by four output columns per tile:
+//
+//     Y (2x4) = A2^T [ sum_ci (G2 g G4^T) (.) (B2^T d B4) ] A4        d = 4x6 input window, 24 products per 8 outputs
+//
+// i.e. 3 multiplies per output pixel and (ci, co) pair instead of 4 for F(2x2,3x3) and 9 for the direct form.
+// fp32 throughout.  Per-layer error against an fp64 convolution (random data, K = 576 ... 2880): rel-L2 0.7-1.4e-6
+// (F(2x2): 0.3-0.6e-6, direct fp32: 0.2-0.3e-6, F(4x4): 1.7-3.7e-6) -- the 4-point transform is applied along ONE
+// axis only, so its constants (4, 5, 8, 1/6, 1/24) enter once, not squared.  The weight transform is evaluated in
+// double and rounded once.
+//
+// Everything is fused in one kernel -- no transformed tensor ever goes to HBM:
+//   * weights arrive pre-transformed + packed  U[co tile][chunk][slice 24][co 64][ci 8]  (pack kernel).  A wave's
+//     MFMA A operands are read STRAIGHT from that image into registers (one float4 per lane and slice: the lane's
+//     four k values): with all 32 tiles of the workgroup in one wave no two waves share a U element, so staging U
+//     through LDS (a third of the F(2x2) kernel's LDS traffic and 64 KB of its LDS) would only re-shuffle it;
+//   * per 8-channel chunk the raw haloed rows are staged in LDS, two threads per (channel, tile) transform the 4x6
+//     window (B2^T d B4) into the V[slice][ci][tile] image -- three 16-byte reads per window row, conflict-free;
+//   * 24 independent GEMM slices  D_s[co][tile] += U_s[co][ci] V_s[ci][tile]  on v_mfma_f32_32x32x2_f32.  Workgroup =
+//     8 waves = 64 co x 32 tiles (256 output pixels); wave (cw, a) owns 32 co x 32 tiles x the 6 slices of transformed
+//     row a = 96 accumulators.  ONE workgroup per CU, persistent over the whole tiles (next tile's first loads issued
+//     under the epilogue);
+//   * the epilogue applies A4 per wave in registers, the four row waves exchange their 2x4 partial tiles through LDS
+//     once (A2), every wave finishes a quarter of the channels: bias + per-view bias + residual, float4 row stores.
+// MODE 0: plain input; MODE 2: nearest-x2-upsampled input (Upsample conv), as in conv.hip.
+#include "common.h"
+
+namespace {
+
+constexpr int WTCO = 64;      // output channels per workgroup
+constexpr int WTT = 32;       // 2x4 output tiles per workgroup
+constexpr int WCK = 8;        // input channels per chunk
+constexpr int NSL = 24;       // Winograd slices (4 transformed rows x 6 transformed columns)
+constexpr int WINO_PERSIST = 256;     // one persistent workgroup per CU
+
+struct WinoArgs {
+    const float* x;
+    const float* u;       // packed transformed weights
+    const float* bias;
+    const float* vbias;
+    const float* res;
+    float* y;
+    int S, Cin, Cout, CinP, CoutP;
+    // tail splitting (small maps): tiles [0, nfull) are computed whole (by the persistent workgroups); workgroup
+    // npers + j*tail_split + p computes the p-th K range of tile nfull + j and leaves a raw partial output in ws
+    // (wino_fixup_kernel)
+    int nfull, tail_split;
+    float* ws;
+    int npers;            // persistent workgroups = min(nfull, WINO_PERSIST)
+};
+
+template <int LOGW, int MODE>
+struct WGeo {
+    static constexpr int W = 1 << LOGW, H = W, HW = W * H;
+    static constexpr int SH = MODE == 2 ? H / 2 : H, SW = MODE == 2 ? W / 2 : W;   // source size
+    static constexpr int TWC = W / 4;                // tiles per output row
+    static constexpr int THR = H / 2;                // tile rows per image
+    static constexpr int IPG = TWC * THR >= WTT ? 1 : WTT / (TWC * THR);   // images per workgroup (4 on 8x8 maps)
+    static constexpr int TR = IPG == 1 ? WTT / TWC : THR;               // tile rows per image in a workgroup
+    static constexpr int WPI = IPG == 1 ? THR / TR : 1;                 // workgroups per image (group)
+    static constexpr int RPI = 2 * TR + 2;                              // haloed patch rows per image
+    static constexpr int PH = IPG * RPI;
+    // patch row: idx 3 = left halo, 4.. = pixels, 4+W = right halo.  With several images per workgroup the
+    // row is W+4 wide and the right halo aliases the (never written, zero) idx 0 of the next row.
+    // Stride: 16 consecutive tiles of a b128 lane group span 16/TWC tile rows = patch rows 2 apart; their 16-byte
+    // reads must land on disjoint bank sets: 2*PW = 16*TWC mod 64 dwords (W = 32: 48 instead of 40; 64 and 16: W + 8).
+    static constexpr int PW = IPG == 1 ? (W == 32 ? 48 : W + 8) : W + 4;
+    static constexpr int PS = PH * PW + (IPG == 1 ? 0 : 8);
+    static constexpr int Q = W / 4;
+    static_assert(TR >= 1 && WPI >= 1 && IPG * TR * TWC == WTT, "unsupported map size for the 32-tile workgroup");
+    static __device__ __forceinline__ int t_img(int tl) { return tl / (TWC * TR); }
+    static __device__ __forceinline__ int t_row(int tl) { return (tl / TWC) % TR; }
+    static __device__ __forceinline__ int t_col(int tl) { return tl % TWC; }
+    static __device__ __forceinline__ int g_view(int wg) { return IPG == 1 ? wg / WPI : wg * IPG; }
+    static __device__ __forceinline__ int g_row(int wg) { return IPG == 1 ? (wg % WPI) * 2 * TR : 0; }
+    static int groups(int S) { return IPG == 1 ? S * WPI : (S + IPG - 1) / IPG; }
+};
+
+template <int LOGW, int MODE>
+__global__ __launch_bounds__(512, 2) void wino_conv_kernel(WinoArgs a) {
+    using G = WGeo<LOGW, MODE>;
+    constexpr int NT_ = 512;
+    constexpr int NX4 = WCK * G::PH * G::Q;
+    constexpr int NXR = (NX4 + NT_ - 1) / NT_;           // 1-2 per thread (tail predicated)
+    constexpr int UCH = NSL * WTCO * WCK;                // floats of one (co tile, chunk) block of U
+    constexpr int VSZ = NSL * WCK * WTT;
+    constexpr int PSZ = WCK * G::PS;
+    constexpr int XCH = 2 * 4 * 64 * 64;                 // epilogue exchange: [cw][row wave][value 64][lane 64]
+    constexpr int LDSF = 2 * PSZ + (2 * VSZ > XCH ? 2 * VSZ : XCH);
+    static_assert(NXR <= 2, "raw-row staging assumes at most two float4 per thread");
+    static_assert(LDSF * 4 <= 160 * 1024, "LDS budget");
+
+    // V and the raw rows are double buffered so that ONE barrier per chunk suffices: while the MFMAs of chunk c read
+    // V[c&1], the waves also store the raw rows of chunk c+2 and transform the rows of chunk c+1 into V[(c+1)&1].
+    // The raw-row buffers come first: their zero halo columns are written once per workgroup and must survive the
+    // epilogue's exchange buffer, which overlays the V buffers and the space behind them.
+    __shared__ __attribute__((aligned(16))) float lds[LDSF];
+    float* const Pl = lds;
+    float* const Vl = lds + 2 * PSZ;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int cw = wid & 1, wa = wid >> 1;               // channel half, transformed row of this wave
+    const int li = lane & 31, lh = lane >> 5;
+    const int ncot = a.CoutP / WTCO;
+    const bool partial = (int)blockIdx.x >= a.npers;
+    const int tail_id = partial ? (int)blockIdx.x - a.npers : 0;
+    int c0 = 0, nch = a.CinP / WCK;                     // this workgroup's chunk range [c0, c0 + nch)
+    if (partial) {
+        const int per = (nch + a.tail_split - 1) / a.tail_split;
+        c0 = (tail_id % a.tail_split) * per;
+        nch = max(0, min(nch - c0, per));
+    }
+    const int clast = max(nch - 1, 0);
+
+    // per-thread staging layout of the raw input rows: element e = tid + 512 i of the patch -> (channel, patch row,
+    // float4 column); only what the chunk loop touches is kept in registers
+    int xlo[2], xci[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int e = tid + i * NT_;
+        const int t1 = e / G::Q;
+        xci[i] = t1 / G::PH;
+        xlo[i] = xci[i] * G::PS + (t1 % G::PH) * G::PW + 4 * (e % G::Q) + 4;
+    }
+
+    struct Tile {                                        // what changes from tile to tile and the chunk loop needs
+        const float* usrc;
+        const float* xsrc;
+        int xgo0, xgo1;                                  // this thread's source offsets (negative: zeros)
+    };
+    auto tile_pos = [&](unsigned logical, int& s_, int& r0_, int& cot_) {
+        cot_ = logical % ncot;
+        const int wg = logical / ncot;
+        s_ = G::g_view(wg);                             // first (for 8x8 maps: of four) view of this tile
+        r0_ = G::g_row(wg);                             // first output row
+    };
+    auto make_tile = [&](unsigned logical) -> Tile {
+        Tile t;
+        int ts, tr0, cot;
+        tile_pos(logical, ts, tr0, cot);
+        // this wave's fragment of U: slices 6 wa .. 6 wa + 5, rows cw*32 + li, k half lh
+        t.usrc = a.u + ((size_t)cot * (a.CinP / WCK) + c0) * UCH + ((size_t)(wa * 6) * WTCO + cw * 32 + li) * WCK + 4 * lh;
+        t.xsrc = a.x + (size_t)ts * a.Cin * (G::SH * G::SW);
+        int go[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int e = tid + i * NT_;
+            const int q = e % G::Q, t1 = e / G::Q;
+            const int pr = t1 % G::PH, ci = t1 / G::PH;
+            const int img = pr / G::RPI;
+            const int uy = tr0 + pr % G::RPI - 1;
+            const bool ok = i < NXR && e < NX4 && ts + img < a.S && uy >= 0 && uy < G::H;
+            go[i] = ok ? (img * a.Cin + ci) * (G::SH * G::SW) + (MODE == 0 ? uy * G::SW + 4 * q : (uy >> 1) * G::SW + 2 * q)
+                       : -1;
+        }
+        t.xgo0 = go[0]; t.xgo1 = go[1];
+        return t;
+    };
+    auto fetch_x = [&](const Tile& t, int i, int c) -> float4 {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int go = i == 0 ? t.xgo0 : t.xgo1;
+        if (go >= 0 && (c0 + c) * WCK + xci[i] < a.Cin) {
+            const float* p = t.xsrc + (size_t)(c0 + c) * WCK * (G::SH * G::SW) + go;
+            if (MODE == 0) v = *reinterpret_cast<const float4*>(p);
+            else { const float2 h = *reinterpret_cast<const float2*>(p); v = make_float4(h.x, h.x, h.y, h.y); }
+        }
+        return v;
+    };
+
+    unsigned lin = partial ? 0u : blockIdx.x;           // linear id of the current whole tile
+    const unsigned tail_logical = (unsigned)(a.nfull + tail_id / a.tail_split);
+    auto logical_of = [&](unsigned l) -> unsigned { return partial ? tail_logical : xcd_remap(l, a.nfull); };
+    Tile cur = make_tile(logical_of(lin));
+
+    // named registers + macros (not arrays behind lambdas: those end up in scratch memory)
+    float4 ur0, ur1, ur2, ur3, ur4, ur5;                // U fragments of the six slices, current chunk
+    float4 xr0 = make_float4(0.f, 0.f, 0.f, 0.f), xr1 = xr0;
+#define VF_ULOAD(T, B, C) ur##B = *reinterpret_cast<const float4*>((T).usrc + (size_t)(C) * UCH + (B) * (WTCO * WCK))
+#define VF_ULOAD_ALL(T, C) { VF_ULOAD(T, 0, C); VF_ULOAD(T, 1, C); VF_ULOAD(T, 2, C); VF_ULOAD(T, 3, C); VF_ULOAD(T, 4, C); VF_ULOAD(T, 5, C); }
+#define VF_XLOAD(T, C) { xr0 = fetch_x((T), 0, (C)); if (NXR > 1) xr1 = fetch_x((T), 1, (C)); }
+#define VF_XSTORE(BUF)                                                                                  \
+    {                                                                                                   \
+        if (tid < NX4) *reinterpret_cast<float4*>(Pl + (BUF) * PSZ + xlo[0]) = xr0;                      \
+        if (NXR > 1 && tid + NT_ < NX4) *reinterpret_cast<float4*>(Pl + (BUF) * PSZ + xlo[1]) = xr1;     \
+    }
+
+    // input transform duty: channel tci, tile ttl, half th.  Half 0 reads window rows 0,1,2 and writes transformed
+    // rows 0,1; half 1 reads rows 1,2,3 and writes transformed rows 3,2 (B2^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]]).
+    // Tile of this lane: ds_read_b128 serves a wave in four groups of 16 lanes -- {0-3,12-15,20-27}, {4-11,16-19,28-31}
+    // and the same +32 (MI355X_MICROARCH.md, LDS table) -- and a window read is conflict-free only if the 16 lanes of a
+    // group cover 64 distinct banks.  The lanes of a group therefore take 16 CONSECUTIVE tiles (one tile row of a 64-wide
+    // map, two of a 32-wide one, ...), whose 16-byte reads tile the banks exactly (the patch row stride is chosen
+    // accordingly: WGeo::PW).
+    const int l5 = tid & 31;
+    const bool gB = (l5 >= 4 && l5 < 12) || (l5 >= 16 && l5 < 20) || l5 >= 28;
+    const int gpos = gB ? (l5 < 12 ? l5 - 4 : (l5 < 20 ? l5 - 8 : l5 - 16)) : (l5 < 4 ? l5 : (l5 < 16 ? l5 - 8 : l5 - 12));
+    const int tci = tid >> 6, ttl = (gB ? 16 : 0) + gpos, th = (tid >> 5) & 1;
+    const int wpo = tci * G::PS + (G::t_img(ttl) * G::RPI + 2 * G::t_row(ttl) + th) * G::PW + 4 * G::t_col(ttl);
+    const int wvx = ((th ? 18 : 0) * WCK + tci) * WTT + ttl;        // V slot of output X (transformed row 0 / 3), slice 0
+    const int wvy = ((th ? 12 : 6) * WCK + tci) * WTT + ttl;        // V slot of output Y (transformed row 1 / 2)
+    float cA[6], cB[6], cC[6];                           // column-transformed window rows R0, R1, R2
+    f32x4 qa0, qa1, qa2, qb0, qb1, qb2, qc0, qc1, qc2;   // raw window rows in flight (read in one MFMA gap, used in a later one)
+    // one window row (cols 4t-1 .. 4t+4 = patch idx 4t+3 .. 4t+8): three aligned 16-byte reads, conflict-free
+#define VF_WREAD(R, BUF, Q0, Q1, Q2)                                                     \
+    {                                                                                    \
+        const float* p_ = Pl + (BUF) * PSZ + wpo + (R) * G::PW;                          \
+        Q0 = *reinterpret_cast<const f32x4*>(p_);                                        \
+        Q1 = *reinterpret_cast<const f32x4*>(p_ + 4);                                    \
+        Q2 = *reinterpret_cast<const f32x4*>(p_ + 8);                                    \
+    }
+    // column transform B4^T of a window row
+    auto win_col = [&](f32x4& q0, f32x4& q1, f32x4& q2, float* c) {
+        // (only q0.w and q2.x are needed of the outer reads; left alone the compiler narrows the three 16-byte reads
+        // to ds_read2_b32 pairs, whose 4-dword lane stride is a 4-way bank conflict -- a ds_read_b128 at that stride
+        // is conflict-free.  The opaque use keeps all four components, and with them the wide read, alive.)
+        asm volatile("" : "+v"(q0), "+v"(q2));
+        const float d0 = q0[3], d1 = q1[0], d2 = q1[1], d3 = q1[2], d4 = q1[3], d5 = q2[0];
+        c[0] = 4.f * d0 - 5.f * d2 + d4;
+        c[1] = (d3 + d4) - 4.f * (d1 + d2);
+        c[2] = 4.f * (d1 - d2) + (d4 - d3);
+        c[3] = 2.f * (d3 - d1) + (d4 - d2);
+        c[4] = 2.f * (d1 - d3) + (d4 - d2);
+        c[5] = 4.f * d1 - 5.f * d3 + d5;
+    };
+    // half 0: X = R0 - R2 (row 0), Y = R1 + R2 (row 1); half 1 (rows 1,2,3): X = R0 - R2 (row 3), Y = R1 - R0 (row 2)
+    auto win_write = [&](int b, int buf) {
+        float* v = Vl + buf * VSZ;
+        v[wvx + b * (WCK * WTT)] = cA[b] - cC[b];
+        v[wvy + b * (WCK * WTT)] = cB[b] + (th ? -cA[b] : cC[b]);
+    };
+    const int voff = (wa * 6 * WCK + 4 * lh) * WTT + li;
+
+    // ---- first loads of the first tile: U(0), rows(0), rows(1) -- all issued together (one round trip)
+    VF_ULOAD_ALL(cur, 0);
+    VF_XLOAD(cur, 0);
+    float4 yr0 = fetch_x(cur, 0, min(1, clast)), yr1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (NXR > 1) yr1 = fetch_x(cur, 1, min(1, clast));
+    for (int i = tid; i < 2 * PSZ; i += NT_) Pl[i] = 0.f;    // halo columns stay zero in both buffers, for every tile
+
+    for (;;) {
+        f32x16 acc[6];
+#pragma unroll
+        for (int b = 0; b < 6; ++b) acc[b] = (f32x16){0};
+
+        // ---- prologue: rows(0), rows(1) staged; V(0) transformed; rows(2) in flight (U(0) is already in registers)
+        __syncthreads();                                  // zero fill done / previous tile's epilogue done with the LDS
+        VF_XSTORE(0);
+        if (tid < NX4) *reinterpret_cast<float4*>(Pl + PSZ + xlo[0]) = yr0;
+        if (NXR > 1 && tid + NT_ < NX4) *reinterpret_cast<float4*>(Pl + PSZ + xlo[1]) = yr1;
+        VF_XLOAD(cur, min(2, clast));
+        __syncthreads();
+        VF_WREAD(0, 0, qa0, qa1, qa2); VF_WREAD(1, 0, qb0, qb1, qb2); VF_WREAD(2, 0, qc0, qc1, qc2);
+        win_col(qa0, qa1, qa2, cA); win_col(qb0, qb1, qb2, cB); win_col(qc0, qc1, qc2, cC);
+#pragma unroll
+        for (int b = 0; b < 6; ++b) win_write(b, 0);
+        __syncthreads();
+
+        // The staging code of chunks c+1..c+3 runs unconditionally with the chunk index clamped to the last one
+        // (the final iterations redo harmless loads / LDS writes that nobody reads): no branch around a load, so the
+        // compiler counts the loads in flight instead of draining the queue.
+        for (int c = 0; c < nch; ++c) {
+            const int cb = c & 1, nxt = cb ^ 1;
+            const float* vb = Vl + cb * VSZ + voff;
+            float b_cur[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) b_cur[e] = vb[e * WTT];
+            // one slice = four MFMAs (K = 8) on accumulator B; side work goes BEHIND the slice's own MFMAs (both
+            // waves of a SIMD run this code in phase: side work in front would idle the matrix pipe in both at once)
+#define VF_SLICE(B, SIDE0, SIDE1, SIDE2)                                                                 \
+            {                                                                                            \
+                float b_nxt[4];                                                                          \
+                __builtin_amdgcn_sched_barrier(0);                                                       \
+                acc[B] = __builtin_amdgcn_mfma_f32_32x32x2f32(ur##B.x, b_cur[0], acc[B], 0, 0, 0);       \
+                __builtin_amdgcn_sched_barrier(0);                                                       \
+                if ((B) + 1 < 6) {                                                                       \
+                    _Pragma("unroll") for (int e = 0; e < 4; ++e) b_nxt[e] = vb[((B) + 1) * WCK * WTT + e * WTT]; \
+                }                                                                                        \
+                SIDE0;                                                                                   \
+                __builtin_amdgcn_sched_barrier(0);                                                       \
+                acc[B] = __builtin_amdgcn_mfma_f32_32x32x2f32(ur##B.y, b_cur[1], acc[B], 0, 0, 0);       \
+                __builtin_amdgcn_sched_barrier(0);                                                       \
+                SIDE1;                                                                                   \
+                __builtin_amdgcn_sched_barrier(0);                                                       \
+                acc[B] = __builtin_amdgcn_mfma_f32_32x32x2f32(ur##B.z, b_cur[2], acc[B], 0, 0, 0);       \
+                __builtin_amdgcn_sched_barrier(0);                                                       \
+                SIDE2;                                                                                   \
+                __builtin_amdgcn_sched_barrier(0);                                                       \
+                acc[B] = __builtin_amdgcn_mfma_f32_32x32x2f32(ur##B.w, b_cur[3], acc[B], 0, 0, 0);       \
+                __builtin_amdgcn_sched_barrier(0);                                                       \
+                VF_ULOAD(cur, B, min(c + 1, clast));      /* this slice's U of the NEXT chunk, in place */ \
+                if ((B) + 1 < 6) {                                                                       \
+                    _Pragma("unroll") for (int e = 0; e < 4; ++e) b_cur[e] = b_nxt[e];                   \
+                }                                                                                        \
+            }
+            // window rows of chunk c+1: read in slice 0, column-transformed in slice 1 (an MFMA gap never waits for
+            // the LDS reads it has just issued), combined + written to V[nxt] in slice 2
+            VF_SLICE(0, VF_WREAD(0, nxt, qa0, qa1, qa2), VF_WREAD(1, nxt, qb0, qb1, qb2), VF_WREAD(2, nxt, qc0, qc1, qc2));
+            VF_SLICE(1, win_col(qa0, qa1, qa2, cA), win_col(qb0, qb1, qb2, cB), win_col(qc0, qc1, qc2, cC));
+            VF_SLICE(2, { win_write(0, nxt); win_write(1, nxt); }, { win_write(2, nxt); win_write(3, nxt); },
+                     { win_write(4, nxt); win_write(5, nxt); });
+            VF_SLICE(3, VF_XSTORE(cb), (void)0, (void)0);                     // rows of chunk c+2 -> buffer of chunk c
+            VF_SLICE(4, VF_XLOAD(cur, min(c + 3, clast)), (void)0, (void)0);
+            VF_SLICE(5, (void)0, (void)0, (void)0);
+#undef VF_SLICE
+            __syncthreads();
+        }
+
+        const unsigned lin_next = lin + WINO_PERSIST;
+        const bool has_next = !partial && lin_next < (unsigned)a.nfull;      // workgroup-uniform
+        const unsigned logical_cur = logical_of(lin);
+
+        // ---- output transform, columns: this wave holds transformed row `wa`, M[b] = acc[b]:  t = A4^T M,
+        //   A4^T = [[1,1,1,1,1,0],[0,1,-1,2,-2,0],[0,1,1,4,4,0],[0,1,-1,8,-8,1]]
+        float part[16][4];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float m0 = acc[0][r], m1 = acc[1][r], m2 = acc[2][r], m3 = acc[3][r], m4 = acc[4][r], m5 = acc[5][r];
+            const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+            part[r][0] = m0 + s12 + s34;
+            part[r][1] = d12 + 2.f * d34;
+            part[r][2] = s12 + 4.f * s34;
+            part[r][3] = d12 + 8.f * d34 + m5;
+        }
+        // ---- the next whole tile of this (persistent) workgroup: its first loads go out now (the accumulators are
+        // dead, so the registers are free) and land under the rest of the epilogue.  Issued unconditionally -- the last
+        // tile re-reads its own first chunks, which nobody uses -- so that nothing is conditionally carried through
+        // the chunk loop.
+        const Tile nx = make_tile(has_next ? logical_of(lin_next) : logical_cur);
+        VF_ULOAD_ALL(nx, 0);
+        VF_XLOAD(nx, 0);
+        yr0 = fetch_x(nx, 0, min(1, clast));
+        if (NXR > 1) yr1 = fetch_x(nx, 1, min(1, clast));
+
+        // The epilogue's per-lane index arithmetic is the same for every tile; left to itself the compiler hoists all of
+        // it out of the tile loop and then spills it across the chunk loop.  An opaque copy of the lane id keeps it here.
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));
+        const int li_e = lane_e & 31, lh_e = lane_e >> 5;
+        // ---- rows: Y = A2^T T, A2^T = [[1,1,1,0],[0,1,-1,-1]].  Every wave publishes its 16 x 4 values, then finishes
+        // the four accumulator rows r = 4 wa .. 4 wa + 3 (channels co0 + cw*32 + 8 wa + rr + 4 lh) of all four row waves.
+        float* xch = Vl + (size_t)(cw * 4) * (64 * 64);
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xch[(size_t)wa * (64 * 64) + (r * 4 + j) * 64 + lane_e] = part[r][j];
+        __syncthreads();
+        float o0[4][4], o1[4][4];                        // [rr][column]: output rows 0 / 1 of the 2x4 tile
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float* q = xch + ((4 * wa + rr) * 4 + j) * 64 + lane_e;
+                const float t0 = q[0], t1 = q[64 * 64], t2 = q[2 * 64 * 64], t3 = q[3 * 64 * 64];
+                o0[rr][j] = t0 + t1 + t2;
+                o1[rr][j] = t1 - t2 - t3;
+            }
+        int s, r0, cot_;
+        tile_pos(logical_cur, s, r0, cot_);
+        const int co0 = cot_ * WTCO;
+        const int tl = li_e;
+        const int cob = co0 + cw * 32 + 8 * wa + 4 * lh_e;                  // + rr
+        if (partial) {                                       // raw partial tile: ws[tail_id][co 64][tile 32][2x4]
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int col = cw * 32 + 8 * wa + 4 * lh_e + rr;
+                float* w8 = a.ws + (((size_t)tail_id * WTCO + col) * WTT + tl) * 8;
+                *reinterpret_cast<float4*>(w8) = make_float4(o0[rr][0], o0[rr][1], o0[rr][2], o0[rr][3]);
+                *reinterpret_cast<float4*>(w8 + 4) = make_float4(o1[rr][0], o1[rr][1], o1[rr][2], o1[rr][3]);
+            }
+        } else if (s + G::t_img(tl) < a.S) {
+            const int sv = s + G::t_img(tl);
+            const int orow = r0 + 2 * G::t_row(tl), ocol = 4 * G::t_col(tl);
+            // every epilogue operand is fetched BEFORE the first store (loads and stores retire through one in-order
+            // counter); one uniform branch per operand kind with its loads back to back
+            float eb[4], ev[4];
+            float4 er[4][2];
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                eb[rr] = ev[rr] = 0.f;
+                er[rr][0] = er[rr][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            if (a.bias) {
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) eb[rr] = a.bias[min(cob + rr, a.Cout - 1)];
+            }
+            if (a.vbias) {
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) ev[rr] = a.vbias[(size_t)sv * a.Cout + min(cob + rr, a.Cout - 1)];
+            }
+            if (a.res) {
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const size_t o = ((size_t)sv * a.Cout + min(cob + rr, a.Cout - 1)) * G::HW + (size_t)orow * G::W + ocol;
+                    er[rr][0] = *reinterpret_cast<const float4*>(a.res + o);
+                    er[rr][1] = *reinterpret_cast<const float4*>(a.res + o + G::W);
+                }
+            }
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                if (cob + rr >= a.Cout) continue;
+                const float bb = eb[rr] + ev[rr];
+                const size_t o = ((size_t)sv * a.Cout + cob + rr) * G::HW + (size_t)orow * G::W + ocol;
+                *reinterpret_cast<float4*>(a.y + o) =
+                    make_float4(o0[rr][0] + bb + er[rr][0].x, o0[rr][1] + bb + er[rr][0].y,
+                                o0[rr][2] + bb + er[rr][0].z, o0[rr][3] + bb + er[rr][0].w);
+                *reinterpret_cast<float4*>(a.y + o + G::W) =
+                    make_float4(o1[rr][0] + bb + er[rr][1].x, o1[rr][1] + bb + er[rr][1].y,
+                                o1[rr][2] + bb + er[rr][1].z, o1[rr][3] + bb + er[rr][1].w);
+            }
+        }
+        if (!has_next) break;
+        cur = nx;
+        lin = lin_next;
+    }
+#undef VF_ULOAD
+#undef VF_ULOAD_ALL
+#undef VF_XLOAD
+#undef VF_XSTORE
+#undef VF_WREAD
+}
+
+// OIHW -> transformed + packed forward  U[co tile][ci chunk][slice][co 64][ci 8] = (G2 w G4^T)_slice, slice = 6 a + b,
+//        and backward (dgrad)          [ci tile][co chunk][slice][ci 64][co 8] of the 180-degree-rotated kernel.
+// One 512-thread workgroup per (tile, chunk) group = 12288 outputs: thread (m, k8) reads the nine taps of one
+// (co, ci) pair once (36 contiguous bytes) and writes its 24 slices, each slice a contiguous 2 KB line of the
+// workgroup.  Groups [0, nf/12288) are the forward pack, the rest the backward pack.  Evaluated in double.
+__device__ __forceinline__ void wino_pack_group(const float* __restrict__ w, float* __restrict__ uf,
+                                                float* __restrict__ ub, int Cout, int Cin, size_t nf, size_t nb,
+                                                size_t group) {
+    constexpr int GSZ = NSL * WTCO * WCK;
+    const size_t ngf = nf / GSZ;
+    const bool bwd = group >= ngf;
+    if (bwd) {
+        group -= ngf;
+        if (group >= nb / GSZ || !ub) return;
+    }
+    const int M = bwd ? Cin : Cout, K = bwd ? Cout : Cin;
+    const int nchunk = (K + WCK - 1) / WCK;
+    const int chunk = group % nchunk, mt = group / nchunk;
+    const int t = threadIdx.x;
+    const int m = t >> 3, k8 = t & 7;
+    const int mm = mt * 64 + m, kk = chunk * WCK + k8;
+    double g[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) g[i] = 0.0;
+    if (mm < M && kk < K) {
+        const int co = bwd ? kk : mm, ci = bwd ? mm : kk;
+        const float* p = w + ((size_t)co * Cin + ci) * 9;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) g[i] = (double)(bwd ? p[8 - i] : p[i]);
+    }
+    // rows: G2 = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]] applied to the kernel rows
+    double tq[4][3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const double h = 0.5 * (g[q] + g[6 + q]), e = 0.5 * g[3 + q];
+        tq[0][q] = g[q];
+        tq[1][q] = h + e;
+        tq[2][q] = h - e;
+        tq[3][q] = g[6 + q];
+    }
+    // columns: G4 = [[1/4,0,0],[-1/6,-1/6,-1/6],[-1/6,1/6,-1/6],[1/24,1/12,1/6],[1/24,-1/12,1/6],[0,0,1]]
+    float* out = (bwd ? ub : uf) + group * (size_t)GSZ + t;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const double x0 = tq[i][0], x1 = tq[i][1], x2 = tq[i][2];
+        const double a6 = -(x0 + x2) / 6.0, b6 = x1 / 6.0;
+        const double a24 = x0 / 24.0 + x2 / 6.0, b12 = x1 / 12.0;
+        out[(6 * i + 0) * (WTCO * WCK)] = (float)(x0 / 4.0);
+        out[(6 * i + 1) * (WTCO * WCK)] = (float)(a6 - b6);
+        out[(6 * i + 2) * (WTCO * WCK)] = (float)(a6 + b6);
+        out[(6 * i + 3) * (WTCO * WCK)] = (float)(a24 + b12);
+        out[(6 * i + 4) * (WTCO * WCK)] = (float)(a24 - b12);
+        out[(6 * i + 5) * (WTCO * WCK)] = (float)x2;
+    }
+}
+
+__global__ __launch_bounds__(512) void wino_pack_kernel(const float* __restrict__ w, float* __restrict__ uf,
+                                                        float* __restrict__ ub, int Cout, int Cin, size_t nf,
+                                                        size_t nb) {
+    wino_pack_group(w, uf, ub, Cout, Cin, nf, nb, blockIdx.x);
+}
+
+constexpr int PACK_BLOCKS = NSL * WTCO * WCK / 256;     // 256-output units per pack group (48)
+
+struct WPackDesc {
+    const float* w;
+    float* uf;
+    float* ub;
+    long long Cout, Cin, nf, nb, first_block;         // first_block in units of 256 outputs (48 per group)
+};
+__global__ __launch_bounds__(512) void wino_pack_multi_kernel(const WPackDesc* __restrict__ desc, int nlayers) {
+    const long long vb = (long long)blockIdx.x * PACK_BLOCKS;
+    int lo = 0, hi = nlayers;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (desc[mid].first_block <= vb) lo = mid; else hi = mid;
+    }
+    const WPackDesc d = desc[lo];
+    wino_pack_group(d.w, d.uf, d.ub, (int)d.Cout, (int)d.Cin, (size_t)d.nf, (size_t)d.nb,
+                    (size_t)((vb - d.first_block) / PACK_BLOCKS));
+}
+
+inline int rup(int v, int m) { return (v + m - 1) / m * m; }
+
+// Sums the K-range partials of the tail tiles in a fixed order and applies the epilogue
+// (bias + per-view bias + residual).  One thread per (tail tile, co, 2x4 tile).
+template <int LOGW>
+__global__ __launch_bounds__(256) void wino_fixup_kernel(WinoArgs a, int ntail) {
+    using G = WGeo<LOGW, 0>;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int tl = idx % WTT;
+    const int col = (idx / WTT) % WTCO;
+    const int j = idx / (WTT * WTCO);
+    if (j >= ntail) return;
+    const int ncot = a.CoutP / WTCO;
+    const int logical = a.nfull + j;
+    const int cot = logical % ncot, wg = logical / ncot;
+    const int s = G::g_view(wg) + G::t_img(tl), r0 = G::g_row(wg);
+    const int co = cot * WTCO + col;
+    if (s >= a.S || co >= a.Cout) return;
+    float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+    for (int p = 0; p < a.tail_split; ++p) {
+        const float* w8 = a.ws + ((((size_t)j * a.tail_split + p) * WTCO + col) * WTT + tl) * 8;
+        const float4 t0 = *reinterpret_cast<const float4*>(w8), t1 = *reinterpret_cast<const float4*>(w8 + 4);
+        v0.x += t0.x; v0.y += t0.y; v0.z += t0.z; v0.w += t0.w;
+        v1.x += t1.x; v1.y += t1.y; v1.z += t1.z; v1.w += t1.w;
+    }
+    float b = 0.f;
+    if (a.bias) b += a.bias[co];
+    if (a.vbias) b += a.vbias[(size_t)s * a.Cout + co];
+    const int orow = r0 + 2 * G::t_row(tl), ocol = 4 * G::t_col(tl);
+    const size_t o = ((size_t)s * a.Cout + co) * G::HW + (size_t)orow * G::W + ocol;
+    v0.x += b; v0.y += b; v0.z += b; v0.w += b;
+    v1.x += b; v1.y += b; v1.z += b; v1.w += b;
+    if (a.res) {
+        const float4 q0 = *reinterpret_cast<const float4*>(a.res + o);
+        const float4 q1 = *reinterpret_cast<const float4*>(a.res + o + G::W);
+        v0.x += q0.x; v0.y += q0.y; v0.z += q0.z; v0.w += q0.w;
+        v1.x += q1.x; v1.y += q1.y; v1.z += q1.z; v1.w += q1.w;
+    }
+    *reinterpret_cast<float4*>(a.y + o) = v0;
+    *reinterpret_cast<float4*>(a.y + o + G::W) = v1;
+}
+
+constexpr int WINO_SLOTS = 256;       // one workgroup per CU
+
+// How a grid of T equal tiles is finished when T is not a multiple of the slot count: the last R = T mod 256
+// tiles are split over K into `split` parts each; the parts run in ceil(R*split/256) rounds of 1/split tile
+// time.  `split` is the value in [1, min(8, nch/4)] that wastes the least CU time (ties: fewer parts).
+inline double wino_tail_time(int R, int sp) { return (double)((R * sp + WINO_SLOTS - 1) / WINO_SLOTS) / sp; }
+
+inline void wino_tail_plan(int T, int nch, int* nfull, int* split) {
+    *nfull = T;
+    *split = 1;
+    const int R = T % WINO_SLOTS;
+    if (R == 0 || T / WINO_SLOTS >= 3) return;          // tail round costs < 1/4 of the launch: leave it
+    int best = 1;
+    for (int sp = 2; sp <= 8 && sp <= nch / 4; ++sp) {    // at least 4 chunks per part
+        const int per = (nch + sp - 1) / sp;              // the kernel gives each part `per` chunks:
+        if ((nch + per - 1) / per != sp) continue;        // no part may start beyond the last chunk
+        if (wino_tail_time(R, sp) < wino_tail_time(R, best) - 1e-9) best = sp;
+    }
+    if (best < 2) return;
+    *nfull = T - R;
+    *split = best;
+}
+
+// tiles of a launch: groups of 32 output tiles (256 pixels) x 64-channel tiles
+inline int wino_groups(int S, int H, int W) {
+    const int tiles = (H / 2) * (W / 4);
+    return tiles >= WTT ? S * (tiles / WTT) : (S + WTT / tiles - 1) / (WTT / tiles);
+}
+
+template <int LOGW, int MODE>
+int launch_wino(WinoArgs a, size_t ws_floats, hipStream_t st) {
+    using G = WGeo<LOGW, MODE>;
+    const int T = G::groups(a.S) * (a.CoutP / WTCO);
+    wino_tail_plan(T, a.CinP / WCK, &a.nfull, &a.tail_split);
+    const int ntail = T - a.nfull;
+    if ((size_t)ntail * a.tail_split * WTCO * WTT * 8 > ws_floats || !a.ws) {   // no room: plain grid
+        a.nfull = T;
+        a.tail_split = 1;
+    }
+    const int nt = T - a.nfull;
+    a.npers = a.nfull < WINO_PERSIST ? a.nfull : WINO_PERSIST;
+    hipLaunchKernelGGL((wino_conv_kernel<LOGW, MODE>), dim3(a.npers + nt * a.tail_split), dim3(512), 0, st, a);
+    if (nt > 0)
+        hipLaunchKernelGGL((wino_fixup_kernel<LOGW>), dim3((nt * WTCO * WTT + 255) / 256), dim3(256), 0, st, a, nt);
+    VF_RETURN_LAST_ERROR();
+}
+
+}  // namespace
+
+extern "C" {
+
+int vf_wino_pack_sizes(int Cout, int Cin, long* fwd_floats, long* bwd_floats) {
+    *fwd_floats = (long)NSL * rup(Cin, WCK) * rup(Cout, WTCO);
+    *bwd_floats = (long)NSL * rup(Cout, WCK) * rup(Cin, WTCO);
+    return 0;
+}
+
+int vf_wino_pack_weights(const float* w_oihw, float* u_fwd, float* u_bwd, int Cout, int Cin, void* stream) {
+    const size_t nf = (size_t)NSL * rup(Cin, WCK) * rup(Cout, WTCO);
+    const size_t nb = u_bwd ? (size_t)NSL * rup(Cout, WCK) * rup(Cin, WTCO) : 0;
+    hipLaunchKernelGGL(wino_pack_kernel, dim3((unsigned)((nf + nb) / (NSL * WTCO * WCK))), dim3(512), 0,
+                       (hipStream_t)stream, w_oihw, u_fwd, u_bwd, Cout, Cin, nf, nb);
+    VF_RETURN_LAST_ERROR();
+}
+
+// desc: device int64 [nlayers][8] rows {w, u_fwd, u_bwd, Cout, Cin, fwd_floats, bwd_floats, first_block}
+int vf_wino_pack_weights_multi(const void* desc, int nlayers, long total_blocks, void* stream) {
+    if (nlayers <= 0 || total_blocks <= 0) return 0;
+    hipLaunchKernelGGL(wino_pack_multi_kernel, dim3((unsigned)(total_blocks / PACK_BLOCKS)), dim3(512), 0,
+                       (hipStream_t)stream, (const WPackDesc*)desc, nlayers);
+    VF_RETURN_LAST_ERROR();
+}
+
+// 1 if vf_wino_conv_fwd supports this (output) size / mode: 3x3 stride 1, H = W in {8, 16, 32, 64}, modes 0 / 2.
+int vf_wino_supported(int H, int W, int mode) {
+    return (H == W && (W == 8 || W == 16 || W == 32 || W == 64) && (mode == 0 || mode == 2)) ? 1 : 0;
+}
+
+// workspace floats vf_wino_conv_fwd wants for its split tail tiles (0 when the grid divides evenly)
+long vf_wino_conv_ws_floats(int S, int Cin, int Cout, int H, int W) {
+    const int T = wino_groups(S, H, W) * (rup(Cout, WTCO) / WTCO);
+    int nfull, split;
+    wino_tail_plan(T, rup(Cin, WCK) / WCK, &nfull, &split);
+    return (long)(T - nfull) * split * WTCO * WTT * 8;
+}
+
+// Expected CU fill (percent) of vf_wino_conv_fwd at this shape under its tail plan, and the tile count;
+// hosts use it to choose between this path and the direct kernel.
+int vf_wino_conv_fill_pct(int S, int Cin, int Cout, int H, int W, int* tiles_out) {
+    const int T = wino_groups(S, H, W) * (rup(Cout, WTCO) / WTCO);
+    int nfull, split;
+    wino_tail_plan(T, rup(Cin, WCK) / WCK, &nfull, &split);
+    if (tiles_out) *tiles_out = T;
+    if (T <= 0) return 0;
+    const double time = (nfull + WINO_SLOTS - 1) / WINO_SLOTS + (T > nfull ? wino_tail_time(T - nfull, split) : 0.0);
+    return (int)(100.0 * T / WINO_SLOTS / time);
+}
+
+// y = conv3x3(x) (+bias +view_bias +residual), pad 1, stride 1, via the fused nested Winograd F(2,3) x F(4,3).
+// u_packed from vf_wino_pack_weights (forward pack for the conv, backward pack for its dgrad).
+int vf_wino_conv_fwd(const float* x, const float* u_packed, const float* bias, const float* view_bias,
+                     const float* residual, float* y, float* ws, long ws_floats, int S, int Cin, int Cout, int H,
+                     int W, int mode, void* stream) {
+    if (S <= 0) return 0;
+    if (!vf_wino_supported(H, W, mode)) return (int)hipErrorInvalidValue;
+    WinoArgs a;
+    a.x = x; a.u = u_packed; a.bias = bias; a.vbias = view_bias; a.res = residual; a.y = y;
+    a.S = S; a.Cin = Cin; a.Cout = Cout; a.CinP = rup(Cin, WCK); a.CoutP = rup(Cout, WTCO);
+    a.ws = ws;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t nws = ws ? (size_t)ws_floats : 0;
+    if (W == 8) return mode == 0 ? launch_wino<3, 0>(a, nws, st) : launch_wino<3, 2>(a, nws, st);
+    if (W == 16) return mode == 0 ? launch_wino<4, 0>(a, nws, st) : launch_wino<4, 2>(a, nws, st);
+    if (W == 32) return mode == 0 ? launch_wino<5, 0>(a, nws, st) : launch_wino<5, 2>(a, nws, st);
+    return mode == 0 ? launch_wino<6, 0>(a, nws, st) : launch_wino<6, 2>(a, nws, st);
+}
+
+}  // extern "C"
