@@ -152,7 +152,8 @@ def pmc_traffic():
 
 # kind (ops._launch) -> (label, binding roof).  Events bracket the C-ABI launcher, i.e. the kernel family it enqueues.
 FAMILIES = {
-    "wino_conv": ("wino_conv_kernel<LOGW,MODE> (+ tail fixup): forward + dgrad of every stride-1 3x3 layer", "mfma"),
+    "wino_conv": ("wino_conv_kernel<LOGW,MODE> (nested Winograd F(2,3)xF(4,3), + tail fixup): forward + dgrad of every "
+                  "stride-1 3x3 layer", "mfma"),
     "direct_conv": ("conv_mfma_kernel<KS,LOGW,MODE,NPT>: forward + dgrad of the 1x1 / stride-2 layers", "mfma"),
     "wino_wgrad": ("wino_wgrad_kernel (+ slab sum, finish): weight gradient of the stride-1 3x3 layers", "mfma"),
     "direct_wgrad": ("conv1x1_wgrad_kernel / conv_wgrad_kernel (+ reduce): weight gradient of the 1x1 / stride-2 layers", "mfma"),
@@ -162,6 +163,11 @@ FAMILIES = {
     "gn_bwd": ("gn_bwd_fused_kernel (+ fused residual / skip gradient adds)", "hbm"),
     "adam": ("adam_multi_kernel", "hbm"),
 }
+
+
+# direct-convolution multiplies per multiply the Winograd kernels execute: forward / dgrad run the nested
+# F(2,3) x F(4,3) (24 products per 2x4 outputs x 9 taps = 72 direct ones), the weight gradient F(2x2,3x3) (16 per 36)
+WINO_REDUCTION = {"wino_conv": 3.0, "wino_wgrad": 2.25}
 
 
 def _family(kind, name):
@@ -175,8 +181,8 @@ def _family(kind, name):
 def roofline(trainer, batch, S, ms_step, steps=2):
     """Per-launch HIP-event timing (events recorded on the launch stream) of the kernel families over `steps` extra
     iterations after the timed region.  The headline `frac` is the EXECUTED fp32-MFMA fraction of the dominant
-    kernel, wino_conv_kernel: its launches' algorithmic direct-convolution FLOPs / 2.25 (Winograd F(2x2,3x3)
-    multiplies 16 values per 2x2 outputs x 9 taps = 36 direct ones) / its own event time / 157.3 TF."""
+    kernel, wino_conv_kernel: its launches' algorithmic direct-convolution FLOPs / 3 (the nested Winograd F(2,3)xF(4,3)
+    multiplies 24 values per 2x4 outputs x 9 taps = 72 direct ones) / its own event time / 157.3 TF."""
     ops.KERNEL_LOG = []
     for _ in range(steps):
         trainer.step(batch)
@@ -193,7 +199,7 @@ def roofline(trainer, batch, S, ms_step, steps=2):
     table = {}
     for fam, (f, s, n, nb) in agg.items():
         label, bound = FAMILIES.get(fam, (fam, "hbm"))
-        executed = f / 2.25 if fam.startswith("wino") else f
+        executed = f / WINO_REDUCTION.get(fam, 1.0)
         row = dict(kernel=label, bound=bound, launches_per_step=n // steps, ms_per_step=s / steps * 1e3,
                    avg_launch_us=s / n * 1e6)
         if f:
@@ -204,15 +210,17 @@ def roofline(trainer, batch, S, ms_step, steps=2):
                        algorithmic_mb_per_launch=nb / n / 1e6)
         table[fam] = row
     f, s, n, _ = agg["wino_conv"]
-    executed = f / 2.25
+    executed = f / WINO_REDUCTION["wino_conv"]
     # floor of the whole step: every conv at the fp32 MFMA peak, the stride-1 3x3 layers at Winograd's multiply count
+    # (forward + dgrad: nested F(2,3)xF(4,3); weight gradient: F(2x2,3x3))
     step_tflop_direct = GFLOP_PER_VIEW_TRAIN * S / 1e3
-    step_tflop_wino = step_tflop_direct - 3 * GFLOP_3X3_S1_PER_VIEW_FWD * S / 1e3 * (1 - 1 / 2.25)
+    g3 = GFLOP_3X3_S1_PER_VIEW_FWD * S / 1e3
+    step_tflop_wino = step_tflop_direct - 2 * g3 * (1 - 1 / WINO_REDUCTION["wino_conv"]) - g3 * (1 - 1 / WINO_REDUCTION["wino_wgrad"])
     floor_ms = step_tflop_wino / PEAK_FP32_MATRIX_TFLOPS * 1e3
     out = dict(bound="mfma", kernel=FAMILIES["wino_conv"][0], achieved=executed / s / 1e12, peak=PEAK_FP32_MATRIX_TFLOPS,
                unit="TFLOP/s", frac=executed / s / 1e12 / PEAK_FP32_MATRIX_TFLOPS,
                note="achieved = multiplies the matrix cores EXECUTE: algorithmic direct-convolution FLOPs "
-                    "(2*S*Cout*Cin*9*H*W per launch) / 2.25 / HIP-event time of the vf_wino_conv_fwd launches "
+                    "(2*S*Cout*Cin*9*H*W per launch) / 3 / HIP-event time of the vf_wino_conv_fwd launches "
                     "(forward + dgrad); direct_equivalent_tflops prices the same launches at the direct count",
                direct_equivalent_tflops=f / s / 1e12, launches_per_step=n // steps, avg_launch_us=s / n * 1e6,
                algorithmic_gflop_per_launch=f / n / 1e9, executed_gflop_per_launch=executed / n / 1e9,

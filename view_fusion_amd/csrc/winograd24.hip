@@ -150,21 +150,24 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(WinoArgs a) {
             const int img = pr / G::RPI;
             const int uy = tr0 + pr % G::RPI - 1;
             const bool ok = i < NXR && e < NX4 && ts + img < a.S && uy >= 0 && uy < G::H;
-            go[i] = ok ? (img * a.Cin + ci) * (G::SH * G::SW) + (MODE == 0 ? uy * G::SW + 4 * q : (uy >> 1) * G::SW + 2 * q)
-                       : -1;
+            (void)ci;                                    // (the channel is added per chunk, clamped: fetch_x)
+            go[i] = ok ? img * a.Cin * (G::SH * G::SW) + (MODE == 0 ? uy * G::SW + 4 * q : (uy >> 1) * G::SW + 2 * q) : -1;
         }
         t.xgo0 = go[0]; t.xgo1 = go[1];
         return t;
     };
+    // (branch-free: the load is unconditional on a clamped address and the value is zeroed by a select afterwards --
+    // a load inside an `if` costs a saveexec / branch pair and makes the compiler drain the load queue)
+    const int cin_last = a.Cin - 1;
     auto fetch_x = [&](const Tile& t, int i, int c) -> float4 {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         const int go = i == 0 ? t.xgo0 : t.xgo1;
-        if (go >= 0 && (c0 + c) * WCK + xci[i] < a.Cin) {
-            const float* p = t.xsrc + (size_t)(c0 + c) * WCK * (G::SH * G::SW) + go;
-            if (MODE == 0) v = *reinterpret_cast<const float4*>(p);
-            else { const float2 h = *reinterpret_cast<const float2*>(p); v = make_float4(h.x, h.x, h.y, h.y); }
-        }
-        return v;
+        const int ch = (c0 + c) * WCK + xci[i];                       // absolute input channel of this element
+        const bool ok = go >= 0 && ch <= cin_last;
+        const float* p = t.xsrc + (size_t)min(ch, cin_last) * (G::SH * G::SW) + max(go, 0);
+        float4 v;
+        if (MODE == 0) v = *reinterpret_cast<const float4*>(p);
+        else { const float2 h = *reinterpret_cast<const float2*>(p); v = make_float4(h.x, h.x, h.y, h.y); }
+        return ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
     };
 
     unsigned lin = partial ? 0u : blockIdx.x;           // linear id of the current whole tile
@@ -261,46 +264,44 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(WinoArgs a) {
         for (int c = 0; c < nch; ++c) {
             const int cb = c & 1, nxt = cb ^ 1;
             const float* vb = Vl + cb * VSZ + voff;
-            float b_cur[4];
+            // B fragments ping-pong between two register sets (no copies): slice B multiplies from set B & 1 while the
+            // reads of slice B + 1 land in the other one
+            float bf0[4], bf1[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) b_cur[e] = vb[e * WTT];
+            for (int e = 0; e < 4; ++e) bf0[e] = vb[e * WTT];
             // one slice = four MFMAs (K = 8) on accumulator B; side work goes BEHIND the slice's own MFMAs (both
             // waves of a SIMD run this code in phase: side work in front would idle the matrix pipe in both at once)
-#define VF_SLICE(B, SIDE0, SIDE1, SIDE2)                                                                 \
+#define VF_SLICE(B, BC, BN, SIDE0, SIDE1, SIDE2)                                                         \
             {                                                                                            \
-                float b_nxt[4];                                                                          \
                 __builtin_amdgcn_sched_barrier(0);                                                       \
-                acc[B] = __builtin_amdgcn_mfma_f32_32x32x2f32(ur##B.x, b_cur[0], acc[B], 0, 0, 0);       \
+                acc[B] = __builtin_amdgcn_mfma_f32_32x32x2f32(ur##B.x, BC[0], acc[B], 0, 0, 0);          \
                 __builtin_amdgcn_sched_barrier(0);                                                       \
                 if ((B) + 1 < 6) {                                                                       \
-                    _Pragma("unroll") for (int e = 0; e < 4; ++e) b_nxt[e] = vb[((B) + 1) * WCK * WTT + e * WTT]; \
+                    _Pragma("unroll") for (int e = 0; e < 4; ++e) BN[e] = vb[((B) + 1) * WCK * WTT + e * WTT]; \
                 }                                                                                        \
                 SIDE0;                                                                                   \
                 __builtin_amdgcn_sched_barrier(0);                                                       \
-                acc[B] = __builtin_amdgcn_mfma_f32_32x32x2f32(ur##B.y, b_cur[1], acc[B], 0, 0, 0);       \
+                acc[B] = __builtin_amdgcn_mfma_f32_32x32x2f32(ur##B.y, BC[1], acc[B], 0, 0, 0);          \
                 __builtin_amdgcn_sched_barrier(0);                                                       \
                 SIDE1;                                                                                   \
                 __builtin_amdgcn_sched_barrier(0);                                                       \
-                acc[B] = __builtin_amdgcn_mfma_f32_32x32x2f32(ur##B.z, b_cur[2], acc[B], 0, 0, 0);       \
+                acc[B] = __builtin_amdgcn_mfma_f32_32x32x2f32(ur##B.z, BC[2], acc[B], 0, 0, 0);          \
                 __builtin_amdgcn_sched_barrier(0);                                                       \
                 SIDE2;                                                                                   \
                 __builtin_amdgcn_sched_barrier(0);                                                       \
-                acc[B] = __builtin_amdgcn_mfma_f32_32x32x2f32(ur##B.w, b_cur[3], acc[B], 0, 0, 0);       \
+                acc[B] = __builtin_amdgcn_mfma_f32_32x32x2f32(ur##B.w, BC[3], acc[B], 0, 0, 0);          \
                 __builtin_amdgcn_sched_barrier(0);                                                       \
                 VF_ULOAD(cur, B, min(c + 1, clast));      /* this slice's U of the NEXT chunk, in place */ \
-                if ((B) + 1 < 6) {                                                                       \
-                    _Pragma("unroll") for (int e = 0; e < 4; ++e) b_cur[e] = b_nxt[e];                   \
-                }                                                                                        \
             }
             // window rows of chunk c+1: read in slice 0, column-transformed in slice 1 (an MFMA gap never waits for
             // the LDS reads it has just issued), combined + written to V[nxt] in slice 2
-            VF_SLICE(0, VF_WREAD(0, nxt, qa0, qa1, qa2), VF_WREAD(1, nxt, qb0, qb1, qb2), VF_WREAD(2, nxt, qc0, qc1, qc2));
-            VF_SLICE(1, win_col(qa0, qa1, qa2, cA), win_col(qb0, qb1, qb2, cB), win_col(qc0, qc1, qc2, cC));
-            VF_SLICE(2, { win_write(0, nxt); win_write(1, nxt); }, { win_write(2, nxt); win_write(3, nxt); },
+            VF_SLICE(0, bf0, bf1, VF_WREAD(0, nxt, qa0, qa1, qa2), VF_WREAD(1, nxt, qb0, qb1, qb2), VF_WREAD(2, nxt, qc0, qc1, qc2));
+            VF_SLICE(1, bf1, bf0, win_col(qa0, qa1, qa2, cA), win_col(qb0, qb1, qb2, cB), win_col(qc0, qc1, qc2, cC));
+            VF_SLICE(2, bf0, bf1, { win_write(0, nxt); win_write(1, nxt); }, { win_write(2, nxt); win_write(3, nxt); },
                      { win_write(4, nxt); win_write(5, nxt); });
-            VF_SLICE(3, VF_XSTORE(cb), (void)0, (void)0);                     // rows of chunk c+2 -> buffer of chunk c
-            VF_SLICE(4, VF_XLOAD(cur, min(c + 3, clast)), (void)0, (void)0);
-            VF_SLICE(5, (void)0, (void)0, (void)0);
+            VF_SLICE(3, bf1, bf0, VF_XSTORE(cb), (void)0, (void)0);           // rows of chunk c+2 -> buffer of chunk c
+            VF_SLICE(4, bf0, bf1, VF_XLOAD(cur, min(c + 3, clast)), (void)0, (void)0);
+            VF_SLICE(5, bf1, bf0, (void)0, (void)0, (void)0);
 #undef VF_SLICE
             __syncthreads();
         }
