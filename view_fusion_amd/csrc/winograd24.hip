@@ -76,6 +76,38 @@ struct WGeo {
     static int groups(int S) { return IPG == 1 ? S * WPI : (S + IPG - 1) / IPG; }
 };
 
+// Packed fp32 (two lanes of a 64-bit register pair per instruction).  Written as instructions: the compiler's cost
+// model splits <2 x float> arithmetic with swizzles back into scalar ops + moves, and under fp32 MFMAs every vector
+// instruction counts (tools/mfma_valu.hip).
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {              // a - b
+    f32x2 d;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) {     // a * b + c
+    f32x2 d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ f32x2 pk_nmul4_add(f32x2 a, f32x2 c) {        // c - 4 a
+    f32x2 d;
+    asm("v_pk_fma_f32 %0, %1, 4.0, %2 op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(d) : "v"(a), "v"(c));
+    return d;
+}
+__device__ __forceinline__ f32x2 pk_hi_pm_lo(f32x2 p) {                  // [p.y + p.x, p.y - p.x]
+    f32x2 d;
+    asm("v_pk_add_f32 %0, %1, %1 op_sel:[1,0] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(d) : "v"(p));
+    return d;
+}
+__device__ __forceinline__ f32x2 pk_hi_pm_2lo(f32x2 q) {                 // [q.y + 2 q.x, q.y - 2 q.x]
+    f32x2 d;
+    asm("v_pk_fma_f32 %0, %1, 2.0, %1 op_sel:[0,0,1] op_sel_hi:[0,0,1] neg_hi:[1,0,0]" : "=v"(d) : "v"(q));
+    return d;
+}
+
+#ifdef VF_STAMPS
+__device__ unsigned long long g_stamps[16];     // debug build only: shader-clock sums of prologue / chunk loop / epilogue, tiles
+#endif
 template <int LOGW, int MODE>
 __global__ __launch_bounds__(512, 2) void wino_conv_kernel(WinoArgs a) {
     using G = WGeo<LOGW, MODE>;
@@ -124,9 +156,9 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(WinoArgs a) {
     }
 
     struct Tile {                                        // what changes from tile to tile and the chunk loop needs
-        const float* usrc;
-        const float* xsrc;
-        int xgo0, xgo1;                                  // this thread's source offsets (negative: zeros)
+        const char* ubase;                               // workgroup-uniform: U block of (co tile, first chunk)
+        const char* xbase;                               // workgroup-uniform: first view of the tile
+        int xgo0, xgo1;                                  // this thread's source byte offsets at channel xci (negative: outside the image)
     };
     auto tile_pos = [&](unsigned logical, int& s_, int& r0_, int& cot_) {
         cot_ = logical % ncot;
@@ -138,36 +170,40 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(WinoArgs a) {
         Tile t;
         int ts, tr0, cot;
         tile_pos(logical, ts, tr0, cot);
-        // this wave's fragment of U: slices 6 wa .. 6 wa + 5, rows cw*32 + li, k half lh
-        t.usrc = a.u + ((size_t)cot * (a.CinP / WCK) + c0) * UCH + ((size_t)(wa * 6) * WTCO + cw * 32 + li) * WCK + 4 * lh;
-        t.xsrc = a.x + (size_t)ts * a.Cin * (G::SH * G::SW);
+        t.ubase = reinterpret_cast<const char*>(a.u + ((size_t)cot * (a.CinP / WCK) + c0) * UCH);
+        t.xbase = reinterpret_cast<const char*>(a.x + (size_t)ts * a.Cin * (G::SH * G::SW));
         int go[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int e = tid + i * NT_;
             const int q = e % G::Q, t1 = e / G::Q;
-            const int pr = t1 % G::PH, ci = t1 / G::PH;
+            const int pr = t1 % G::PH;
             const int img = pr / G::RPI;
             const int uy = tr0 + pr % G::RPI - 1;
             const bool ok = i < NXR && e < NX4 && ts + img < a.S && uy >= 0 && uy < G::H;
-            (void)ci;                                    // (the channel is added per chunk, clamped: fetch_x)
-            go[i] = ok ? img * a.Cin * (G::SH * G::SW) + (MODE == 0 ? uy * G::SW + 4 * q : (uy >> 1) * G::SW + 2 * q) : -1;
+            go[i] = ok ? 4 * ((img * a.Cin + xci[i]) * (G::SH * G::SW) + (MODE == 0 ? uy * G::SW + 4 * q : (uy >> 1) * G::SW + 2 * q)) : -1;
         }
         t.xgo0 = go[0]; t.xgo1 = go[1];
         return t;
     };
-    // (branch-free: the load is unconditional on a clamped address and the value is zeroed by a select afterwards --
-    // a load inside an `if` costs a saveexec / branch pair and makes the compiler drain the load queue)
-    const int cin_last = a.Cin - 1;
-    auto fetch_x = [&](const Tile& t, int i, int c) -> float4 {
+    // Under fp32 MFMAs every VALU instruction costs its full issue time (tools/mfma_valu.hip: VALU and the matrix pipe
+    // do not overlap on a SIMD), so the loads of the chunk loop carry as little vector arithmetic as possible: a
+    // uniform base in SGPRs + one 32-bit byte offset per thread (the saddr form of global_load).  A raw row outside
+    // the image is not loaded at all: its LDS slot is zeroed once per tile (prologue) and the chunk loop's load /
+    // store of that slot are masked off.  Channels beyond Cin (last chunk of a Cin that is no multiple of 8) read the
+    // clamped last channel -- finite values whose packed weights are zero:
+    //   min(8 c + xci, Cin - 1) = min(8 c, Cin - 1 - xci) + xci,  the "+ xci" part folded into the tile's offset.
+    const int xlim[2] = {a.Cin - 1 - xci[0], a.Cin - 1 - xci[1]};
+    const unsigned uoffb = 4u * (unsigned)(((wa * 6) * WTCO + cw * 32 + li) * WCK + 4 * lh);    // this wave's fragment of U:
+                                                                          // slices 6 wa .., rows cw*32 + li, k half lh
+    auto fetch_x = [&](const Tile& t, int i, int c, float4& v) {
         const int go = i == 0 ? t.xgo0 : t.xgo1;
-        const int ch = (c0 + c) * WCK + xci[i];                       // absolute input channel of this element
-        const bool ok = go >= 0 && ch <= cin_last;
-        const float* p = t.xsrc + (size_t)min(ch, cin_last) * (G::SH * G::SW) + max(go, 0);
-        float4 v;
-        if (MODE == 0) v = *reinterpret_cast<const float4*>(p);
-        else { const float2 h = *reinterpret_cast<const float2*>(p); v = make_float4(h.x, h.x, h.y, h.y); }
-        return ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (go >= 0) {
+            const unsigned off = (unsigned)(min((c0 + c) * WCK, xlim[i]) * (4 * G::SH * G::SW) + go);
+            const char* p = t.xbase + off;
+            if (MODE == 0) v = *reinterpret_cast<const float4*>(p);
+            else { const float2 h = *reinterpret_cast<const float2*>(p); v = make_float4(h.x, h.x, h.y, h.y); }
+        }
     };
 
     unsigned lin = partial ? 0u : blockIdx.x;           // linear id of the current whole tile
@@ -176,19 +212,45 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(WinoArgs a) {
     Tile cur = make_tile(logical_of(lin));
 
     // named registers + macros (not arrays behind lambdas: those end up in scratch memory)
-    float4 ur0, ur1, ur2, ur3, ur4, ur5;                // U fragments of the six slices, current chunk
+    f32x4 ur0, ur1, ur2, ur3, ur4, ur5;                // U fragments of the six slices, current chunk
     float4 xr0 = make_float4(0.f, 0.f, 0.f, 0.f), xr1 = xr0;
-#define VF_ULOAD(T, B, C) ur##B = *reinterpret_cast<const float4*>((T).usrc + (size_t)(C) * UCH + (B) * (WTCO * WCK))
-#define VF_ULOAD_ALL(T, C) { VF_ULOAD(T, 0, C); VF_ULOAD(T, 1, C); VF_ULOAD(T, 2, C); VF_ULOAD(T, 3, C); VF_ULOAD(T, 4, C); VF_ULOAD(T, 5, C); }
-#define VF_XLOAD(T, C) { xr0 = fetch_x((T), 0, (C)); if (NXR > 1) xr1 = fetch_x((T), 1, (C)); }
-#define VF_XSTORE(BUF)                                                                                  \
+    // (the opaque copy keeps the uniform part of the address in an SGPR pair of its own: global_load ..., v_off, s[base]
+    // offset:imm -- otherwise the six loads share one 64-bit VGPR base and pay v_add_co / v_addc pairs)
+#define VF_ULOAD(T, B, C)                                                                               \
     {                                                                                                   \
-        if (tid < NX4) *reinterpret_cast<float4*>(Pl + (BUF) * PSZ + xlo[0]) = xr0;                      \
-        if (NXR > 1 && tid + NT_ < NX4) *reinterpret_cast<float4*>(Pl + (BUF) * PSZ + xlo[1]) = xr1;     \
+        const char* ub_ = (T).ubase + ((size_t)(C) * UCH + ((B) & ~1) * (WTCO * WCK)) * 4;              \
+        unsigned uo_ = uoffb;                                                                           \
+        asm("" : "+s"(ub_), "+v"(uo_));      /* (the offset too: its zero-extension must stay in this block) */ \
+        ur##B = *(const __attribute__((address_space(1))) f32x4*)(                                      \
+            (const __attribute__((address_space(1))) char*)ub_ + uo_ + ((B) & 1) * (WTCO * WCK * 4));  \
+    }
+#define VF_ULOAD_ALL(T, C) { VF_ULOAD(T, 0, C); VF_ULOAD(T, 1, C); VF_ULOAD(T, 2, C); VF_ULOAD(T, 3, C); VF_ULOAD(T, 4, C); VF_ULOAD(T, 5, C); }
+#define VF_XLOAD(T, C, R0, R1) { fetch_x((T), 0, (C), R0); if (NXR > 1) fetch_x((T), 1, (C), R1); }
+#define VF_XSTORE(T, BUF, R0, R1)                                                                       \
+    {                                                                                                   \
+        if ((T).xgo0 >= 0) *reinterpret_cast<float4*>(Pl + (BUF) * PSZ + xlo[0]) = R0;                   \
+        if (NXR > 1 && (T).xgo1 >= 0) *reinterpret_cast<float4*>(Pl + (BUF) * PSZ + xlo[1]) = R1;        \
+    }
+    // rows of the tile that lie outside the image (or past the last view): zero in both raw-row buffers
+#define VF_XZERO(T)                                                                                     \
+    {                                                                                                   \
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);                                              \
+        if ((T).xgo0 < 0 && tid < NX4) {                                                                \
+            *reinterpret_cast<float4*>(Pl + xlo[0]) = z4; *reinterpret_cast<float4*>(Pl + PSZ + xlo[0]) = z4; \
+        }                                                                                               \
+        if (NXR > 1 && (T).xgo1 < 0 && tid + NT_ < NX4) {                                               \
+            *reinterpret_cast<float4*>(Pl + xlo[1]) = z4; *reinterpret_cast<float4*>(Pl + PSZ + xlo[1]) = z4; \
+        }                                                                                               \
     }
 
-    // input transform duty: channel tci, tile ttl, half th.  Half 0 reads window rows 0,1,2 and writes transformed
-    // rows 0,1; half 1 reads rows 1,2,3 and writes transformed rows 3,2 (B2^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]]).
+    // input transform duty: channel tci, tile ttl, half th (B2^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]]).
+    //   half 0 reads window rows (A,B,C) = (0,1,2) and writes transformed rows 0 = A - C and 1 = B + C;
+    //   half 1 reads window rows (A,B,C) = (3,2,1) and writes transformed rows 3 and 2 = B - C -- and, with the SAME
+    //   instruction as half 0, A - C = -(row 3): the packed weights of transformed row 3 carry the opposite sign
+    //   (wino_pack_group), the products are bit-identical.
+    // The rows are combined FIRST (on the raw 6-wide rows), the B4^T column transform then runs on two rows instead of
+    // three, and both use packed fp32 (v_pk_add_f32 / v_pk_fma_f32 on the aligned pairs (d1,d2), (d3,d4)): 24 vector
+    // instructions per thread and chunk instead of 66.
     // Tile of this lane: ds_read_b128 serves a wave in four groups of 16 lanes -- {0-3,12-15,20-27}, {4-11,16-19,28-31}
     // and the same +32 (MI355X_MICROARCH.md, LDS table) -- and a window read is conflict-free only if the 16 lanes of a
     // group cover 64 distinct banks.  The lanes of a group therefore take 16 CONSECUTIVE tiles (one tile row of a 64-wide
@@ -198,65 +260,80 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(WinoArgs a) {
     const bool gB = (l5 >= 4 && l5 < 12) || (l5 >= 16 && l5 < 20) || l5 >= 28;
     const int gpos = gB ? (l5 < 12 ? l5 - 4 : (l5 < 20 ? l5 - 8 : l5 - 16)) : (l5 < 4 ? l5 : (l5 < 16 ? l5 - 8 : l5 - 12));
     const int tci = tid >> 6, ttl = (gB ? 16 : 0) + gpos, th = (tid >> 5) & 1;
-    const int wpo = tci * G::PS + (G::t_img(ttl) * G::RPI + 2 * G::t_row(ttl) + th) * G::PW + 4 * G::t_col(ttl);
+    const int wpo = tci * G::PS + (G::t_img(ttl) * G::RPI + 2 * G::t_row(ttl)) * G::PW + 4 * G::t_col(ttl);
+    const int wpoA = wpo + (th ? 3 : 0) * G::PW, wpoB = wpo + (th ? 2 : 1) * G::PW, wpoC = wpo + (th ? 1 : 2) * G::PW;
     const int wvx = ((th ? 18 : 0) * WCK + tci) * WTT + ttl;        // V slot of output X (transformed row 0 / 3), slice 0
     const int wvy = ((th ? 12 : 6) * WCK + tci) * WTT + ttl;        // V slot of output Y (transformed row 1 / 2)
-    float cA[6], cB[6], cC[6];                           // column-transformed window rows R0, R1, R2
+    const f32x2 sgy = th ? (f32x2){-1.f, -1.f} : (f32x2){1.f, 1.f};
+    f32x2 xj0, x12, x34, x5j, yj0, y12, y34, y5j;        // combined rows X, Y: [junk, d0], [d1, d2], [d3, d4], [d5, junk]
+    float cX[6], cY[6];                                  // their column transforms
     f32x4 qa0, qa1, qa2, qb0, qb1, qb2, qc0, qc1, qc2;   // raw window rows in flight (read in one MFMA gap, used in a later one)
     // one window row (cols 4t-1 .. 4t+4 = patch idx 4t+3 .. 4t+8): three aligned 16-byte reads, conflict-free
-#define VF_WREAD(R, BUF, Q0, Q1, Q2)                                                     \
+#define VF_WREAD(WPO, BUF, Q0, Q1, Q2)                                                   \
     {                                                                                    \
-        const float* p_ = Pl + (BUF) * PSZ + wpo + (R) * G::PW;                          \
+        const float* p_ = Pl + (BUF) * PSZ + (WPO);                                      \
         Q0 = *reinterpret_cast<const f32x4*>(p_);                                        \
         Q1 = *reinterpret_cast<const f32x4*>(p_ + 4);                                    \
         Q2 = *reinterpret_cast<const f32x4*>(p_ + 8);                                    \
     }
-    // column transform B4^T of a window row
-    auto win_col = [&](f32x4& q0, f32x4& q1, f32x4& q2, float* c) {
-        // (only q0.w and q2.x are needed of the outer reads; left alone the compiler narrows the three 16-byte reads
-        // to ds_read2_b32 pairs, whose 4-dword lane stride is a 4-way bank conflict -- a ds_read_b128 at that stride
-        // is conflict-free.  The opaque use keeps all four components, and with them the wide read, alive.)
-        asm volatile("" : "+v"(q0), "+v"(q2));
-        const float d0 = q0[3], d1 = q1[0], d2 = q1[1], d3 = q1[2], d4 = q1[3], d5 = q2[0];
-        c[0] = 4.f * d0 - 5.f * d2 + d4;
-        c[1] = (d3 + d4) - 4.f * (d1 + d2);
-        c[2] = 4.f * (d1 - d2) + (d4 - d3);
-        c[3] = 2.f * (d3 - d1) + (d4 - d2);
-        c[4] = 2.f * (d1 - d3) + (d4 - d2);
-        c[5] = 4.f * d1 - 5.f * d3 + d5;
+    auto win_rows = [&]() {
+        // (only .w of the first and .x of the last read are needed; left alone the compiler narrows the 16-byte reads
+        // to 8 / 4-byte ones, whose 4-dword lane stride is a bank conflict -- a ds_read_b128 at that stride is
+        // conflict-free.  The opaque use keeps all four components, and with them the wide read, alive.)
+        asm volatile("" : "+v"(qa0), "+v"(qa2), "+v"(qb0), "+v"(qb2), "+v"(qc0), "+v"(qc2));
+        xj0 = pk_sub(qa0.zw, qc0.zw); x12 = pk_sub(qa1.xy, qc1.xy); x34 = pk_sub(qa1.zw, qc1.zw); x5j = pk_sub(qa2.xy, qc2.xy);
+        yj0 = pk_fma(qc0.zw, sgy, qb0.zw); y12 = pk_fma(qc1.xy, sgy, qb1.xy); y34 = pk_fma(qc1.zw, sgy, qb1.zw);
+        y5j = pk_fma(qc2.xy, sgy, qb2.xy);
     };
-    // half 0: X = R0 - R2 (row 0), Y = R1 + R2 (row 1); half 1 (rows 1,2,3): X = R0 - R2 (row 3), Y = R1 - R0 (row 2)
+    // column transform B4^T of a combined row d0..d5 (4 packed + 4 scalar instructions):
+    //   c0 = 4 d0 + (d4 - 5 d2)    c1 = (d4 - 4 d2) + (d3 - 4 d1)      c2 = (d4 - 4 d2) - (d3 - 4 d1)
+    //   c5 = 4 d1 + (d5 - 5 d3)    c3 = (d4 - d2) + 2 (d3 - d1)        c4 = (d4 - d2) - 2 (d3 - d1)
+    auto win_col = [&](const f32x2& vj0, const f32x2& v12, const f32x2& v34, const f32x2& v5j, float* c) {
+        const f32x2 c12 = pk_hi_pm_lo(pk_nmul4_add(v12, v34));       // p = [d3 - 4 d1, d4 - 4 d2]
+        const f32x2 c34 = pk_hi_pm_2lo(pk_sub(v34, v12));            // q = [d3 - d1,   d4 - d2]
+        c[0] = __builtin_fmaf(4.f, vj0.y, __builtin_fmaf(-5.f, v12.y, v34.y));
+        c[1] = c12.x; c[2] = c12.y; c[3] = c34.x; c[4] = c34.y;
+        c[5] = __builtin_fmaf(4.f, v12.x, __builtin_fmaf(-5.f, v34.x, v5j.x));
+    };
     auto win_write = [&](int b, int buf) {
         float* v = Vl + buf * VSZ;
-        v[wvx + b * (WCK * WTT)] = cA[b] - cC[b];
-        v[wvy + b * (WCK * WTT)] = cB[b] + (th ? -cA[b] : cC[b]);
+        v[wvx + b * (WCK * WTT)] = cX[b];
+        v[wvy + b * (WCK * WTT)] = cY[b];
     };
     const int voff = (wa * 6 * WCK + 4 * lh) * WTT + li;
 
     // ---- first loads of the first tile: U(0), rows(0), rows(1) -- all issued together (one round trip)
+    float4 yr0 = xr0, yr1 = xr0;
     VF_ULOAD_ALL(cur, 0);
-    VF_XLOAD(cur, 0);
-    float4 yr0 = fetch_x(cur, 0, min(1, clast)), yr1 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (NXR > 1) yr1 = fetch_x(cur, 1, min(1, clast));
+    VF_XLOAD(cur, 0, xr0, xr1);
+    VF_XLOAD(cur, min(1, clast), yr0, yr1);
     for (int i = tid; i < 2 * PSZ; i += NT_) Pl[i] = 0.f;    // halo columns stay zero in both buffers, for every tile
 
+#ifdef VF_STAMPS
+    unsigned long long st_pro = 0, st_loop = 0, st_epi = 0, st_tiles = 0, st_ea = 0, st_eb = 0, st_ec = 0, st_sl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define VF_STAMP(V) const unsigned long long V = __builtin_amdgcn_s_memtime()
+#else
+#define VF_STAMP(V)
+#endif
     for (;;) {
+        VF_STAMP(t_0);
         f32x16 acc[6];
 #pragma unroll
         for (int b = 0; b < 6; ++b) acc[b] = (f32x16){0};
 
         // ---- prologue: rows(0), rows(1) staged; V(0) transformed; rows(2) in flight (U(0) is already in registers)
         __syncthreads();                                  // zero fill done / previous tile's epilogue done with the LDS
-        VF_XSTORE(0);
-        if (tid < NX4) *reinterpret_cast<float4*>(Pl + PSZ + xlo[0]) = yr0;
-        if (NXR > 1 && tid + NT_ < NX4) *reinterpret_cast<float4*>(Pl + PSZ + xlo[1]) = yr1;
-        VF_XLOAD(cur, min(2, clast));
+        VF_XZERO(cur);
+        VF_XSTORE(cur, 0, xr0, xr1);
+        VF_XSTORE(cur, 1, yr0, yr1);
+        VF_XLOAD(cur, min(2, clast), xr0, xr1);
         __syncthreads();
-        VF_WREAD(0, 0, qa0, qa1, qa2); VF_WREAD(1, 0, qb0, qb1, qb2); VF_WREAD(2, 0, qc0, qc1, qc2);
-        win_col(qa0, qa1, qa2, cA); win_col(qb0, qb1, qb2, cB); win_col(qc0, qc1, qc2, cC);
+        VF_WREAD(wpoA, 0, qa0, qa1, qa2); VF_WREAD(wpoB, 0, qb0, qb1, qb2); VF_WREAD(wpoC, 0, qc0, qc1, qc2);
+        win_rows(); win_col(xj0, x12, x34, x5j, cX); win_col(yj0, y12, y34, y5j, cY);
 #pragma unroll
         for (int b = 0; b < 6; ++b) win_write(b, 0);
         __syncthreads();
+        VF_STAMP(t_1);
 
         // The staging code of chunks c+1..c+3 runs unconditionally with the chunk index clamped to the last one
         // (the final iterations redo harmless loads / LDS writes that nobody reads): no branch around a load, so the
@@ -295,17 +372,32 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(WinoArgs a) {
             }
             // window rows of chunk c+1: read in slice 0, column-transformed in slice 1 (an MFMA gap never waits for
             // the LDS reads it has just issued), combined + written to V[nxt] in slice 2
-            VF_SLICE(0, bf0, bf1, VF_WREAD(0, nxt, qa0, qa1, qa2), VF_WREAD(1, nxt, qb0, qb1, qb2), VF_WREAD(2, nxt, qc0, qc1, qc2));
-            VF_SLICE(1, bf1, bf0, win_col(qa0, qa1, qa2, cA), win_col(qb0, qb1, qb2, cB), win_col(qc0, qc1, qc2, cC));
+            VF_STAMP(ts0);
+            VF_SLICE(0, bf0, bf1, VF_WREAD(wpoA, nxt, qa0, qa1, qa2), VF_WREAD(wpoB, nxt, qb0, qb1, qb2), VF_WREAD(wpoC, nxt, qc0, qc1, qc2));
+            VF_STAMP(ts1);
+            VF_SLICE(1, bf1, bf0, win_rows(), win_col(xj0, x12, x34, x5j, cX), win_col(yj0, y12, y34, y5j, cY));
+            VF_STAMP(ts2);
             VF_SLICE(2, bf0, bf1, { win_write(0, nxt); win_write(1, nxt); }, { win_write(2, nxt); win_write(3, nxt); },
                      { win_write(4, nxt); win_write(5, nxt); });
-            VF_SLICE(3, bf1, bf0, VF_XSTORE(cb), (void)0, (void)0);           // rows of chunk c+2 -> buffer of chunk c
-            VF_SLICE(4, bf0, bf1, VF_XLOAD(cur, min(c + 3, clast)), (void)0, (void)0);
+            VF_STAMP(ts3);
+            VF_SLICE(3, bf1, bf0, VF_XSTORE(cur, cb, xr0, xr1), (void)0, (void)0);           // rows of chunk c+2 -> buffer of chunk c
+            VF_STAMP(ts4);
+            VF_SLICE(4, bf0, bf1, VF_XLOAD(cur, min(c + 3, clast), xr0, xr1), (void)0, (void)0);
+            VF_STAMP(ts5);
             VF_SLICE(5, bf1, bf0, (void)0, (void)0, (void)0);
 #undef VF_SLICE
+            VF_STAMP(ts6);
             __syncthreads();
+#ifdef VF_STAMPS
+            {
+                const unsigned long long ts7 = __builtin_amdgcn_s_memtime();
+                st_sl[0] += ts1 - ts0; st_sl[1] += ts2 - ts1; st_sl[2] += ts3 - ts2; st_sl[3] += ts4 - ts3;
+                st_sl[4] += ts5 - ts4; st_sl[5] += ts6 - ts5; st_sl[6] += ts7 - ts6; st_sl[7] += 1;
+            }
+#endif
         }
 
+        VF_STAMP(t_2);
         const unsigned lin_next = lin + WINO_PERSIST;
         const bool has_next = !partial && lin_next < (unsigned)a.nfull;      // workgroup-uniform
         const unsigned logical_cur = logical_of(lin);
@@ -328,12 +420,12 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(WinoArgs a) {
         // the chunk loop.
         const Tile nx = make_tile(has_next ? logical_of(lin_next) : logical_cur);
         VF_ULOAD_ALL(nx, 0);
-        VF_XLOAD(nx, 0);
-        yr0 = fetch_x(nx, 0, min(1, clast));
-        if (NXR > 1) yr1 = fetch_x(nx, 1, min(1, clast));
+        VF_XLOAD(nx, 0, xr0, xr1);
+        VF_XLOAD(nx, min(1, clast), yr0, yr1);
 
         // The epilogue's per-lane index arithmetic is the same for every tile; left to itself the compiler hoists all of
         // it out of the tile loop and then spills it across the chunk loop.  An opaque copy of the lane id keeps it here.
+        VF_STAMP(t_a);
         int lane_e = lane;
         asm volatile("" : "+v"(lane_e));
         const int li_e = lane_e & 31, lh_e = lane_e >> 5;
@@ -345,6 +437,7 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(WinoArgs a) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) xch[(size_t)wa * (64 * 64) + (r * 4 + j) * 64 + lane_e] = part[r][j];
         __syncthreads();
+        VF_STAMP(t_b);
         float o0[4][4], o1[4][4];                        // [rr][column]: output rows 0 / 1 of the 2x4 tile
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr)
@@ -355,6 +448,7 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(WinoArgs a) {
                 o0[rr][j] = t0 + t1 + t2;
                 o1[rr][j] = t1 - t2 - t3;
             }
+        VF_STAMP(t_c);
         int s, r0, cot_;
         tile_pos(logical_cur, s, r0, cot_);
         const int co0 = cot_ * WTCO;
@@ -409,14 +503,29 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(WinoArgs a) {
                                 o1[rr][2] + bb + er[rr][1].z, o1[rr][3] + bb + er[rr][1].w);
             }
         }
+#ifdef VF_STAMPS
+        {
+            const unsigned long long t_3 = __builtin_amdgcn_s_memtime();
+            st_pro += t_1 - t_0; st_loop += t_2 - t_1; st_epi += t_3 - t_2; st_tiles += 1; st_ea += t_a - t_2; st_eb += t_b - t_a; st_ec += t_c - t_b;
+        }
+#endif
         if (!has_next) break;
         cur = nx;
         lin = lin_next;
     }
+#ifdef VF_STAMPS
+    if (tid == 0 && !partial) {
+        atomicAdd(&g_stamps[0], st_pro); atomicAdd(&g_stamps[1], st_loop); atomicAdd(&g_stamps[2], st_epi);
+        atomicAdd(&g_stamps[3], st_tiles); atomicAdd(&g_stamps[4], st_ea); atomicAdd(&g_stamps[5], st_eb); atomicAdd(&g_stamps[6], st_ec);
+        for (int i = 0; i < 8; ++i) atomicAdd(&g_stamps[8 + i], st_sl[i]);
+    }
+#endif
+#undef VF_STAMP
 #undef VF_ULOAD
 #undef VF_ULOAD_ALL
 #undef VF_XLOAD
 #undef VF_XSTORE
+#undef VF_XZERO
 #undef VF_WREAD
 }
 
@@ -464,7 +573,8 @@ __device__ __forceinline__ void wino_pack_group(const float* __restrict__ w, flo
     float* out = (bwd ? ub : uf) + group * (size_t)GSZ + t;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const double x0 = tq[i][0], x1 = tq[i][1], x2 = tq[i][2];
+        // (transformed row 3 is stored NEGATED: the conv kernel's input transform produces -(row 3), see there)
+        const double x0 = i == 3 ? -tq[i][0] : tq[i][0], x1 = i == 3 ? -tq[i][1] : tq[i][1], x2 = i == 3 ? -tq[i][2] : tq[i][2];
         const double a6 = -(x0 + x2) / 6.0, b6 = x1 / 6.0;
         const double a24 = x0 / 24.0 + x2 / 6.0, b12 = x1 / 12.0;
         out[(6 * i + 0) * (WTCO * WCK)] = (float)(x0 / 4.0);
@@ -662,3 +772,10 @@ int vf_wino_conv_fwd(const float* x, const float* u_packed, const float* bias, c
 }
 
 }  // extern "C"
+
+#ifdef VF_STAMPS
+extern "C" void vf_debug_stamps(unsigned long long* out8, int reset) {
+    if (out8) (void)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_stamps), 128);
+    if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, 128); }
+}
+#endif
