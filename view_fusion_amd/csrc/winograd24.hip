@@ -194,7 +194,7 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(WinoArgs a) {
     // clamped last channel -- finite values whose packed weights are zero:
     //   min(8 c + xci, Cin - 1) = min(8 c, Cin - 1 - xci) + xci,  the "+ xci" part folded into the tile's offset.
     const int xlim[2] = {a.Cin - 1 - xci[0], a.Cin - 1 - xci[1]};
-    const unsigned uoffb = 4u * (unsigned)(((wa * 6) * WTCO + cw * 32 + li) * WCK + 4 * lh);    // this wave's fragment of U:
+    unsigned uoffb = 4u * (unsigned)(((wa * 6) * WTCO + cw * 32 + li) * WCK + 4 * lh);    // this wave's fragment of U:
                                                                           // slices 6 wa .., rows cw*32 + li, k half lh
     auto fetch_x = [&](const Tile& t, int i, int c, float4& v) {
         const int go = i == 0 ? t.xgo0 : t.xgo1;
@@ -219,10 +219,9 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(WinoArgs a) {
 #define VF_ULOAD(T, B, C)                                                                               \
     {                                                                                                   \
         const char* ub_ = (T).ubase + ((size_t)(C) * UCH + ((B) & ~1) * (WTCO * WCK)) * 4;              \
-        unsigned uo_ = uoffb;                                                                           \
-        asm("" : "+s"(ub_), "+v"(uo_));      /* (the offset too: its zero-extension must stay in this block) */ \
+        asm("" : "+s"(ub_), "+v"(uoffb));    /* (the offset too: its zero-extension must stay in this block) */ \
         ur##B = *(const __attribute__((address_space(1))) f32x4*)(                                      \
-            (const __attribute__((address_space(1))) char*)ub_ + uo_ + ((B) & 1) * (WTCO * WCK * 4));  \
+            (const __attribute__((address_space(1))) char*)ub_ + uoffb + ((B) & 1) * (WTCO * WCK * 4)); \
     }
 #define VF_ULOAD_ALL(T, C) { VF_ULOAD(T, 0, C); VF_ULOAD(T, 1, C); VF_ULOAD(T, 2, C); VF_ULOAD(T, 3, C); VF_ULOAD(T, 4, C); VF_ULOAD(T, 5, C); }
 #define VF_XLOAD(T, C, R0, R1) { fetch_x((T), 0, (C), R0); if (NXR > 1) fetch_x((T), 1, (C), R1); }
@@ -262,8 +261,13 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(WinoArgs a) {
     const int tci = tid >> 6, ttl = (gB ? 16 : 0) + gpos, th = (tid >> 5) & 1;
     const int wpo = tci * G::PS + (G::t_img(ttl) * G::RPI + 2 * G::t_row(ttl)) * G::PW + 4 * G::t_col(ttl);
     const int wpoA = wpo + (th ? 3 : 0) * G::PW, wpoB = wpo + (th ? 2 : 1) * G::PW, wpoC = wpo + (th ? 1 : 2) * G::PW;
-    const int wvx = ((th ? 18 : 0) * WCK + tci) * WTT + ttl;        // V slot of output X (transformed row 0 / 3), slice 0
-    const int wvy = ((th ? 12 : 6) * WCK + tci) * WTT + ttl;        // V slot of output Y (transformed row 1 / 2)
+    // V[ci & 3][slice 24][ci >> 2][tile 32]: the MFMA lane (tile li, k half lh) reads channel 4 lh + e of slice s at
+    // dword (e * 24 + s) * 64 + lane -- every fragment a multiple of 64 dwords from one per-lane base
+    // (ds_read2st64_b32 with immediate offsets, no address arithmetic in the loop); a transform thread writes its
+    // channel's 12 values the same way.
+    const int wvb = ((tci & 3) * NSL) * 64 + (tci >> 2) * WTT + ttl;
+    const int wvx = wvb + (th ? 18 : 0) * 64;                       // V slot of output X (transformed row 0 / 3), slice 0
+    const int wvy = wvb + (th ? 12 : 6) * 64;                       // V slot of output Y (transformed row 1 / 2)
     const f32x2 sgy = th ? (f32x2){-1.f, -1.f} : (f32x2){1.f, 1.f};
     f32x2 xj0, x12, x34, x5j, yj0, y12, y34, y5j;        // combined rows X, Y: [junk, d0], [d1, d2], [d3, d4], [d5, junk]
     float cX[6], cY[6];                                  // their column transforms
@@ -297,10 +301,10 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(WinoArgs a) {
     };
     auto win_write = [&](int b, int buf) {
         float* v = Vl + buf * VSZ;
-        v[wvx + b * (WCK * WTT)] = cX[b];
-        v[wvy + b * (WCK * WTT)] = cY[b];
+        v[wvx + b * 64] = cX[b];
+        v[wvy + b * 64] = cY[b];
     };
-    const int voff = (wa * 6 * WCK + 4 * lh) * WTT + li;
+    const int voff = (wa * 6) * 64 + lane;
 
     // ---- first loads of the first tile: U(0), rows(0), rows(1) -- all issued together (one round trip)
     float4 yr0 = xr0, yr1 = xr0;
@@ -310,16 +314,66 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(WinoArgs a) {
     for (int i = tid; i < 2 * PSZ; i += NT_) Pl[i] = 0.f;    // halo columns stay zero in both buffers, for every tile
 
 #ifdef VF_STAMPS
-    unsigned long long st_pro = 0, st_loop = 0, st_epi = 0, st_tiles = 0, st_ea = 0, st_eb = 0, st_ec = 0, st_sl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_pro = 0, st_loop = 0, st_epi = 0, st_tiles = 0, st_ea = 0, st_eb = 0, st_ec = 0;
 #define VF_STAMP(V) const unsigned long long V = __builtin_amdgcn_s_memtime()
 #else
 #define VF_STAMP(V)
 #endif
+    // One slice = four MFMAs (K = 8) on accumulator B; side work goes BEHIND the slice's own MFMAs (both waves of a SIMD
+    // run this code in phase: side work in front would idle the matrix pipe in both at once).  FIRST: the accumulator
+    // starts from the literal 0 (no 96 v_mov per tile).
+#define VF_SLICE(C, FIRST, B, BC, SIDE0, SIDE1, SIDE2)                                                   \
+    {                                                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+        acc[B] = __builtin_amdgcn_mfma_f32_32x32x2f32(ur##B.x, BC[0], (FIRST) ? (f32x16){0} : acc[B], 0, 0, 0); \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+        SIDE0;                                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+        acc[B] = __builtin_amdgcn_mfma_f32_32x32x2f32(ur##B.y, BC[1], acc[B], 0, 0, 0);                  \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+        SIDE1;                                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+        acc[B] = __builtin_amdgcn_mfma_f32_32x32x2f32(ur##B.z, BC[2], acc[B], 0, 0, 0);                  \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+        SIDE2;                                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+        acc[B] = __builtin_amdgcn_mfma_f32_32x32x2f32(ur##B.w, BC[3], acc[B], 0, 0, 0);                  \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+        VF_ULOAD(cur, B, min((C) + 1, clast));            /* this slice's U of the NEXT chunk, in place */ \
+    }
+    // B fragments of slice S_ of V buffer BUF_ -> register set D
+#define VF_BFRAG(D, BUF_, S_)                                                                            \
+    { _Pragma("unroll") for (int e = 0; e < 4; ++e) D[e] = Vl[(BUF_) * VSZ + voff + ((S_) + e * NSL) * 64]; }
+    // One chunk, PAR = chunk parity = its V buffer (compile time: every LDS address of the loop is one per-thread base
+    // + an immediate).  The B fragments rotate through three register sets; slice 0's are loaded by the previous chunk.
+    //   slice 0: window rows of chunk C+1 read from P[PAR^1]        slice 1: their transform (24 vector instructions)
+    //   slice 2: 12 values -> V[PAR^1]                              slice 3: raw rows of chunk C+2 -> P[PAR];
+    //   ... the chunk's ONE barrier sits here, behind slice 3, with the fragments of slices 4 and 5 already in registers:
+    //   slice 4: raw rows of chunk C+3 requested                    slice 5: slice-0 fragments of chunk C+1 from V[PAR^1]
+    // so that no wave waits for LDS at a chunk boundary.  Hazards: V[PAR] is rewritten in slice 2 of chunk C+1 (behind
+    // this barrier, all its reads are in front); P[PAR^1] is rewritten in slice 3 of chunk C+1, read in slice 0 of C.
+    // The staging code of chunks C+1..C+3 runs unconditionally with the chunk index clamped to the last one (the final
+    // iterations redo harmless loads / LDS writes that nobody reads).
+#define VF_CHUNK(C, PAR, FIRST)                                                                          \
+    {                                                                                                    \
+        VF_SLICE(C, FIRST, 0, bfA, { VF_BFRAG(bfB, PAR, 1); VF_WREAD(wpoA, (PAR) ^ 1, qa0, qa1, qa2); }, \
+                 VF_WREAD(wpoB, (PAR) ^ 1, qb0, qb1, qb2), VF_WREAD(wpoC, (PAR) ^ 1, qc0, qc1, qc2));    \
+        VF_SLICE(C, FIRST, 1, bfB, { VF_BFRAG(bfA, PAR, 2); win_rows(); }, win_col(xj0, x12, x34, x5j, cX), \
+                 win_col(yj0, y12, y34, y5j, cY));                                                       \
+        VF_SLICE(C, FIRST, 2, bfA, { VF_BFRAG(bfB, PAR, 3); win_write(0, (PAR) ^ 1); win_write(1, (PAR) ^ 1); }, \
+                 { win_write(2, (PAR) ^ 1); win_write(3, (PAR) ^ 1); },                                  \
+                 { win_write(4, (PAR) ^ 1); win_write(5, (PAR) ^ 1); });                                 \
+        VF_SLICE(C, FIRST, 3, bfB, { VF_BFRAG(bfA, PAR, 4); VF_BFRAG(bfC, PAR, 5); },                    \
+                 VF_XSTORE(cur, PAR, xr0, xr1), (void)0);                                                \
+        __syncthreads();                                                                                 \
+        VF_SLICE(C, FIRST, 4, bfA, VF_XLOAD(cur, min((C) + 3, clast), xr0, xr1), (void)0, (void)0);      \
+        VF_SLICE(C, FIRST, 5, bfC, VF_BFRAG(bfA, (PAR) ^ 1, 0), (void)0, (void)0);                       \
+    }
+
     for (;;) {
         VF_STAMP(t_0);
         f32x16 acc[6];
-#pragma unroll
-        for (int b = 0; b < 6; ++b) acc[b] = (f32x16){0};
+        float bfA[4], bfB[4], bfC[4];
 
         // ---- prologue: rows(0), rows(1) staged; V(0) transformed; rows(2) in flight (U(0) is already in registers)
         __syncthreads();                                  // zero fill done / previous tile's epilogue done with the LDS
@@ -333,68 +387,23 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(WinoArgs a) {
 #pragma unroll
         for (int b = 0; b < 6; ++b) win_write(b, 0);
         __syncthreads();
+        VF_BFRAG(bfA, 0, 0);
         VF_STAMP(t_1);
 
-        // The staging code of chunks c+1..c+3 runs unconditionally with the chunk index clamped to the last one
-        // (the final iterations redo harmless loads / LDS writes that nobody reads): no branch around a load, so the
-        // compiler counts the loads in flight instead of draining the queue.
-        for (int c = 0; c < nch; ++c) {
-            const int cb = c & 1, nxt = cb ^ 1;
-            const float* vb = Vl + cb * VSZ + voff;
-            // B fragments ping-pong between two register sets (no copies): slice B multiplies from set B & 1 while the
-            // reads of slice B + 1 land in the other one
-            float bf0[4], bf1[4];
+        // chunk 0 apart (zero accumulators), then pairs (odd, even), then the odd one left over
+        if (nch > 0) {
+            VF_CHUNK(0, 0, 1);
+        } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) bf0[e] = vb[e * WTT];
-            // one slice = four MFMAs (K = 8) on accumulator B; side work goes BEHIND the slice's own MFMAs (both
-            // waves of a SIMD run this code in phase: side work in front would idle the matrix pipe in both at once)
-#define VF_SLICE(B, BC, BN, SIDE0, SIDE1, SIDE2)                                                         \
-            {                                                                                            \
-                __builtin_amdgcn_sched_barrier(0);                                                       \
-                acc[B] = __builtin_amdgcn_mfma_f32_32x32x2f32(ur##B.x, BC[0], acc[B], 0, 0, 0);          \
-                __builtin_amdgcn_sched_barrier(0);                                                       \
-                if ((B) + 1 < 6) {                                                                       \
-                    _Pragma("unroll") for (int e = 0; e < 4; ++e) BN[e] = vb[((B) + 1) * WCK * WTT + e * WTT]; \
-                }                                                                                        \
-                SIDE0;                                                                                   \
-                __builtin_amdgcn_sched_barrier(0);                                                       \
-                acc[B] = __builtin_amdgcn_mfma_f32_32x32x2f32(ur##B.y, BC[1], acc[B], 0, 0, 0);          \
-                __builtin_amdgcn_sched_barrier(0);                                                       \
-                SIDE1;                                                                                   \
-                __builtin_amdgcn_sched_barrier(0);                                                       \
-                acc[B] = __builtin_amdgcn_mfma_f32_32x32x2f32(ur##B.z, BC[2], acc[B], 0, 0, 0);          \
-                __builtin_amdgcn_sched_barrier(0);                                                       \
-                SIDE2;                                                                                   \
-                __builtin_amdgcn_sched_barrier(0);                                                       \
-                acc[B] = __builtin_amdgcn_mfma_f32_32x32x2f32(ur##B.w, BC[3], acc[B], 0, 0, 0);          \
-                __builtin_amdgcn_sched_barrier(0);                                                       \
-                VF_ULOAD(cur, B, min(c + 1, clast));      /* this slice's U of the NEXT chunk, in place */ \
+            for (int b = 0; b < 6; ++b) acc[b] = (f32x16){0};
+        }
+        {
+            int c = 1;
+            for (; c + 1 < nch; c += 2) {
+                VF_CHUNK(c, 1, 0);
+                VF_CHUNK(c + 1, 0, 0);
             }
-            // window rows of chunk c+1: read in slice 0, column-transformed in slice 1 (an MFMA gap never waits for
-            // the LDS reads it has just issued), combined + written to V[nxt] in slice 2
-            VF_STAMP(ts0);
-            VF_SLICE(0, bf0, bf1, VF_WREAD(wpoA, nxt, qa0, qa1, qa2), VF_WREAD(wpoB, nxt, qb0, qb1, qb2), VF_WREAD(wpoC, nxt, qc0, qc1, qc2));
-            VF_STAMP(ts1);
-            VF_SLICE(1, bf1, bf0, win_rows(), win_col(xj0, x12, x34, x5j, cX), win_col(yj0, y12, y34, y5j, cY));
-            VF_STAMP(ts2);
-            VF_SLICE(2, bf0, bf1, { win_write(0, nxt); win_write(1, nxt); }, { win_write(2, nxt); win_write(3, nxt); },
-                     { win_write(4, nxt); win_write(5, nxt); });
-            VF_STAMP(ts3);
-            VF_SLICE(3, bf1, bf0, VF_XSTORE(cur, cb, xr0, xr1), (void)0, (void)0);           // rows of chunk c+2 -> buffer of chunk c
-            VF_STAMP(ts4);
-            VF_SLICE(4, bf0, bf1, VF_XLOAD(cur, min(c + 3, clast), xr0, xr1), (void)0, (void)0);
-            VF_STAMP(ts5);
-            VF_SLICE(5, bf1, bf0, (void)0, (void)0, (void)0);
-#undef VF_SLICE
-            VF_STAMP(ts6);
-            __syncthreads();
-#ifdef VF_STAMPS
-            {
-                const unsigned long long ts7 = __builtin_amdgcn_s_memtime();
-                st_sl[0] += ts1 - ts0; st_sl[1] += ts2 - ts1; st_sl[2] += ts3 - ts2; st_sl[3] += ts4 - ts3;
-                st_sl[4] += ts5 - ts4; st_sl[5] += ts6 - ts5; st_sl[6] += ts7 - ts6; st_sl[7] += 1;
-            }
-#endif
+            if (c < nch) VF_CHUNK(c, 1, 0);
         }
 
         VF_STAMP(t_2);
@@ -517,7 +526,6 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(WinoArgs a) {
     if (tid == 0 && !partial) {
         atomicAdd(&g_stamps[0], st_pro); atomicAdd(&g_stamps[1], st_loop); atomicAdd(&g_stamps[2], st_epi);
         atomicAdd(&g_stamps[3], st_tiles); atomicAdd(&g_stamps[4], st_ea); atomicAdd(&g_stamps[5], st_eb); atomicAdd(&g_stamps[6], st_ec);
-        for (int i = 0; i < 8; ++i) atomicAdd(&g_stamps[8 + i], st_sl[i]);
     }
 #endif
 #undef VF_STAMP
@@ -526,6 +534,9 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(WinoArgs a) {
 #undef VF_XLOAD
 #undef VF_XSTORE
 #undef VF_XZERO
+#undef VF_SLICE
+#undef VF_BFRAG
+#undef VF_CHUNK
 #undef VF_WREAD
 }
 
