@@ -41,5 +41,7 @@ for Cin, Cout, H in [(64, 64, 64), (128, 64, 64), (128, 128, 32), (256, 128, 32)
           f" | cycles per tile: prologue {pro / tiles:6.0f}  loop {loop / tiles:6.0f} ({loop / tiles / nch:5.0f}/chunk)"
           f"  epilogue {epi / tiles:6.0f} = columns+prefetch {ea / tiles:5.0f} + publish+barrier {eb / tiles:5.0f}"
           f" + read+rows {ec / tiles:5.0f} + operands+stores {(epi - ea - eb - ec) / tiles:5.0f}", flush=True)
-    sl = [float(v) for v in out][8:16]
-    print("      chunk, cycles per slice 0..5 + barrier: " + " ".join(f"{v / sl[7]:6.0f}" for v in sl[:7]), flush=True)
+    x = [float(v) for v in out][8:16]
+    if x[6]:
+        print("      epilogue tail, cycles: operand loads %5.0f | stage rows of next tile %5.0f | barrier %5.0f | stores %5.0f | stage V(0) %5.0f | barrier %5.0f"
+              % tuple(v / x[6] for v in x[:6]), flush=True)

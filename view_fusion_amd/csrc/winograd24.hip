@@ -84,6 +84,22 @@ __device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {              // a - 
     asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
     return d;
 }
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {              // a + b
+    f32x2 d;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+template <int K>
+__device__ __forceinline__ f32x2 pk_fmak(f32x2 a, f32x2 c) {             // K a + c, K in {2, 4, 8} (inline constants)
+    f32x2 d;
+    if (K == 2) asm("v_pk_fma_f32 %0, %1, 2.0, %2 op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "v"(c));
+    else if (K == 4) asm("v_pk_fma_f32 %0, %1, 4.0, %2 op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "v"(c));
+    else {
+        const f32x2 a2 = pk_add(a, a);
+        asm("v_pk_fma_f32 %0, %1, 4.0, %2 op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a2), "v"(c));
+    }
+    return d;
+}
 __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) {     // a * b + c
     f32x2 d;
     asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
@@ -314,7 +330,7 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(WinoArgs a) {
     for (int i = tid; i < 2 * PSZ; i += NT_) Pl[i] = 0.f;    // halo columns stay zero in both buffers, for every tile
 
 #ifdef VF_STAMPS
-    unsigned long long st_pro = 0, st_loop = 0, st_epi = 0, st_tiles = 0, st_ea = 0, st_eb = 0, st_ec = 0;
+    unsigned long long st_pro = 0, st_loop = 0, st_epi = 0, st_tiles = 0, st_ea = 0, st_eb = 0, st_ec = 0, st_x[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define VF_STAMP(V) const unsigned long long V = __builtin_amdgcn_s_memtime()
 #else
 #define VF_STAMP(V)
@@ -370,23 +386,33 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(WinoArgs a) {
         VF_SLICE(C, FIRST, 5, bfC, VF_BFRAG(bfA, (PAR) ^ 1, 0), (void)0, (void)0);                       \
     }
 
+    // Staging of a tile's first chunks: rows(0), rows(1) -> P[0], P[1] (rows(2) requested), then V(0) from P[0].
+    // For the first tile of the workgroup it runs here; for every later tile it runs INSIDE the previous tile's
+    // epilogue (the raw-row buffers are not part of the exchange area; V[0] is free once every wave has read its
+    // exchanged values), where it overlaps with the output stores.
+#define VF_STAGE_ROWS(T)                                                                                 \
+    {                                                                                                    \
+        VF_XZERO(T);                                                                                     \
+        VF_XSTORE(T, 0, xr0, xr1);                                                                       \
+        VF_XSTORE(T, 1, yr0, yr1);                                                                       \
+        VF_XLOAD(T, min(2, clast), xr0, xr1);                                                            \
+    }
+#define VF_STAGE_V0()                                                                                    \
+    {                                                                                                    \
+        VF_WREAD(wpoA, 0, qa0, qa1, qa2); VF_WREAD(wpoB, 0, qb0, qb1, qb2); VF_WREAD(wpoC, 0, qc0, qc1, qc2); \
+        win_rows(); win_col(xj0, x12, x34, x5j, cX); win_col(yj0, y12, y34, y5j, cY);                    \
+        _Pragma("unroll") for (int b = 0; b < 6; ++b) win_write(b, 0);                                   \
+    }
+    __syncthreads();                                      // zero fill done
+    VF_STAGE_ROWS(cur);
+    __syncthreads();
+    VF_STAGE_V0();
+    __syncthreads();
+
     for (;;) {
         VF_STAMP(t_0);
         f32x16 acc[6];
         float bfA[4], bfB[4], bfC[4];
-
-        // ---- prologue: rows(0), rows(1) staged; V(0) transformed; rows(2) in flight (U(0) is already in registers)
-        __syncthreads();                                  // zero fill done / previous tile's epilogue done with the LDS
-        VF_XZERO(cur);
-        VF_XSTORE(cur, 0, xr0, xr1);
-        VF_XSTORE(cur, 1, yr0, yr1);
-        VF_XLOAD(cur, min(2, clast), xr0, xr1);
-        __syncthreads();
-        VF_WREAD(wpoA, 0, qa0, qa1, qa2); VF_WREAD(wpoB, 0, qb0, qb1, qb2); VF_WREAD(wpoC, 0, qc0, qc1, qc2);
-        win_rows(); win_col(xj0, x12, x34, x5j, cX); win_col(yj0, y12, y34, y5j, cY);
-#pragma unroll
-        for (int b = 0; b < 6; ++b) win_write(b, 0);
-        __syncthreads();
         VF_BFRAG(bfA, 0, 0);
         VF_STAMP(t_1);
 
@@ -413,15 +439,21 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(WinoArgs a) {
 
         // ---- output transform, columns: this wave holds transformed row `wa`, M[b] = acc[b]:  t = A4^T M,
         //   A4^T = [[1,1,1,1,1,0],[0,1,-1,2,-2,0],[0,1,1,4,4,0],[0,1,-1,8,-8,1]]
-        float part[16][4];
+        // (packed fp32 on the register pairs (r, r+1) of the accumulators: 10 instructions per pair)
+        f32x2 part[8][4];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float m0 = acc[0][r], m1 = acc[1][r], m2 = acc[2][r], m3 = acc[3][r], m4 = acc[4][r], m5 = acc[5][r];
-            const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
-            part[r][0] = m0 + s12 + s34;
-            part[r][1] = d12 + 2.f * d34;
-            part[r][2] = s12 + 4.f * s34;
-            part[r][3] = d12 + 8.f * d34 + m5;
+        for (int k = 0; k < 8; ++k) {
+            const f32x2 m0 = (f32x2){acc[0][2 * k], acc[0][2 * k + 1]};
+            const f32x2 m1 = (f32x2){acc[1][2 * k], acc[1][2 * k + 1]};
+            const f32x2 m2 = (f32x2){acc[2][2 * k], acc[2][2 * k + 1]};
+            const f32x2 m3 = (f32x2){acc[3][2 * k], acc[3][2 * k + 1]};
+            const f32x2 m4 = (f32x2){acc[4][2 * k], acc[4][2 * k + 1]};
+            const f32x2 m5 = (f32x2){acc[5][2 * k], acc[5][2 * k + 1]};
+            const f32x2 s12 = pk_add(m1, m2), d12 = pk_sub(m1, m2), s34 = pk_add(m3, m4), d34 = pk_sub(m3, m4);
+            part[k][0] = pk_add(pk_add(m0, s12), s34);
+            part[k][1] = pk_fmak<2>(d34, d12);
+            part[k][2] = pk_fmak<4>(s34, s12);
+            part[k][3] = pk_add(pk_fmak<8>(d34, d12), m5);
         }
         // ---- the next whole tile of this (persistent) workgroup: its first loads go out now (the accumulators are
         // dead, so the registers are free) and land under the rest of the epilogue.  Issued unconditionally -- the last
@@ -444,7 +476,7 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(WinoArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) xch[(size_t)wa * (64 * 64) + (r * 4 + j) * 64 + lane_e] = part[r][j];
+            for (int j = 0; j < 4; ++j) xch[(size_t)wa * (64 * 64) + (r * 4 + j) * 64 + lane_e] = part[r >> 1][j][r & 1];
         __syncthreads();
         VF_STAMP(t_b);
         float o0[4][4], o1[4][4];                        // [rr][column]: output rows 0 / 1 of the 2x4 tile
@@ -463,26 +495,19 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(WinoArgs a) {
         const int co0 = cot_ * WTCO;
         const int tl = li_e;
         const int cob = co0 + cw * 32 + 8 * wa + 4 * lh_e;                  // + rr
-        if (partial) {                                       // raw partial tile: ws[tail_id][co 64][tile 32][2x4]
+        const int sv = s + G::t_img(tl);
+        const int orow = r0 + 2 * G::t_row(tl), ocol = 4 * G::t_col(tl);
+        const bool ok_out = !partial && sv < a.S;
+        // every epilogue operand is fetched BEFORE the first store (loads and stores retire through one in-order
+        // counter); one uniform branch per operand kind with its loads back to back
+        float eb[4], ev[4];
+        float4 er[4][2];
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                const int col = cw * 32 + 8 * wa + 4 * lh_e + rr;
-                float* w8 = a.ws + (((size_t)tail_id * WTCO + col) * WTT + tl) * 8;
-                *reinterpret_cast<float4*>(w8) = make_float4(o0[rr][0], o0[rr][1], o0[rr][2], o0[rr][3]);
-                *reinterpret_cast<float4*>(w8 + 4) = make_float4(o1[rr][0], o1[rr][1], o1[rr][2], o1[rr][3]);
-            }
-        } else if (s + G::t_img(tl) < a.S) {
-            const int sv = s + G::t_img(tl);
-            const int orow = r0 + 2 * G::t_row(tl), ocol = 4 * G::t_col(tl);
-            // every epilogue operand is fetched BEFORE the first store (loads and stores retire through one in-order
-            // counter); one uniform branch per operand kind with its loads back to back
-            float eb[4], ev[4];
-            float4 er[4][2];
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                eb[rr] = ev[rr] = 0.f;
-                er[rr][0] = er[rr][1] = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
+        for (int rr = 0; rr < 4; ++rr) {
+            eb[rr] = ev[rr] = 0.f;
+            er[rr][0] = er[rr][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (ok_out) {
             if (a.bias) {
 #pragma unroll
                 for (int rr = 0; rr < 4; ++rr) eb[rr] = a.bias[min(cob + rr, a.Cout - 1)];
@@ -499,6 +524,23 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(WinoArgs a) {
                     er[rr][1] = *reinterpret_cast<const float4*>(a.res + o + G::W);
                 }
             }
+        }
+        // ---- next tile, staged under this tile's stores: raw rows now (P is outside the exchange area), V(0) once
+        // every wave has taken its values out of the exchange area
+        VF_STAMP(t_d);
+        if (has_next) VF_STAGE_ROWS(nx);
+        VF_STAMP(t_e);
+        __syncthreads();
+        VF_STAMP(t_f);
+        if (partial) {                                       // raw partial tile: ws[tail_id][co 64][tile 32][2x4]
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int col = cw * 32 + 8 * wa + 4 * lh_e + rr;
+                float* w8 = a.ws + (((size_t)tail_id * WTCO + col) * WTT + tl) * 8;
+                *reinterpret_cast<float4*>(w8) = make_float4(o0[rr][0], o0[rr][1], o0[rr][2], o0[rr][3]);
+                *reinterpret_cast<float4*>(w8 + 4) = make_float4(o1[rr][0], o1[rr][1], o1[rr][2], o1[rr][3]);
+            }
+        } else if (ok_out) {
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
                 if (cob + rr >= a.Cout) continue;
@@ -519,6 +561,16 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(WinoArgs a) {
         }
 #endif
         if (!has_next) break;
+        VF_STAMP(t_g);
+        VF_STAGE_V0();
+        VF_STAMP(t_h);
+        __syncthreads();                                  // V(0) of the next tile complete
+#ifdef VF_STAMPS
+        {
+            const unsigned long long t_i = __builtin_amdgcn_s_memtime();
+            st_x[0] += t_d - t_c; st_x[1] += t_e - t_d; st_x[2] += t_f - t_e; st_x[3] += t_g - t_f; st_x[4] += t_h - t_g; st_x[5] += t_i - t_h; st_x[6] += 1;
+        }
+#endif
         cur = nx;
         lin = lin_next;
     }
@@ -526,6 +578,7 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(WinoArgs a) {
     if (tid == 0 && !partial) {
         atomicAdd(&g_stamps[0], st_pro); atomicAdd(&g_stamps[1], st_loop); atomicAdd(&g_stamps[2], st_epi);
         atomicAdd(&g_stamps[3], st_tiles); atomicAdd(&g_stamps[4], st_ea); atomicAdd(&g_stamps[5], st_eb); atomicAdd(&g_stamps[6], st_ec);
+        for (int i = 0; i < 8; ++i) atomicAdd(&g_stamps[8 + i], st_x[i]);
     }
 #endif
 #undef VF_STAMP
@@ -534,6 +587,8 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(WinoArgs a) {
 #undef VF_XLOAD
 #undef VF_XSTORE
 #undef VF_XZERO
+#undef VF_STAGE_ROWS
+#undef VF_STAGE_V0
 #undef VF_SLICE
 #undef VF_BFRAG
 #undef VF_CHUNK
