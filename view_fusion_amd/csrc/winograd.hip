@@ -68,175 +68,251 @@ __global__ __launch_bounds__(512, 2) void wino_wgrad_kernel(WinoWgradArgs a) {
     const int tch = tid >> 3, tt = tid & 7;
     const int ttr = tt / TPR, ttc = tt % TPR;         // tile row / column inside the chunk
     const int tsw = tt ^ (((tch >> 4) & 1) << 2);     // LDS slot: 16-B halves swapped on rows 16-31, 48-63 (b128 banks)
+
+    // fp32 MFMAs and VALU instructions do not overlap on a SIMD (tools/mfma_valu.hip), so the chunk loop carries as
+    // little vector arithmetic as possible:
+    //  * every global address is a workgroup-uniform base (SGPR pair, moved per chunk by scalar code) + a 32-bit byte
+    //    offset that is a per-thread CONSTANT -- the saddr form of global_load, no address VALU;
+    //  * rows / columns outside the image are not loaded (uniform-and-constant predicates = scalar exec masks); their
+    //    LDS slots get zeros from a branch only the edge chunks take;
+    //  * both transforms run on packed fp32 (v_pk_add_f32 with op_sel / neg modifiers);
+    //  * the chunk loop is unrolled by buffer parity: every LDS address is a per-thread base + an immediate.
     // raw x staging duty: NX4 float4 (<= 2 per thread), e -> (ci, row, q) = (e / (NR*QPR), (e / QPR) % NR, e % QPR);
     // with HALO 64*4*2 = 512 halo scalars, one per thread: (ci, row, side) = (tid >> 3, (tid >> 1) & 3, tid & 1)
-    float4 xr0, xr1;
-    float xh;
-    float2 dy0, dy1;
-    auto chunk_pos = [&](int c, int& s, int& p, int& q0) {
-        s = c / CPI;
-        const int r = c - s * CPI;
-        p = (r / CPR) * TR;                            // first tile row
-        q0 = (r % CPR) * TPR;                          // first tile column
+    unsigned xoffb[2];
+    int xsl[2];
+    bool xok[2], xtop[2], xbot[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int e = tid + 512 * i;
+        const int ci = e / (NR * QPR), row = (e / QPR) % NR, q = e % QPR;
+        xok[i] = e < NX4 && ci0 + ci < a.Cin;
+        xtop[i] = row == 0;
+        xbot[i] = row == NR - 1;
+        // source row gy = 2p - 1 + row (MODE 2: stored row (gy >> 1) = p - 1 + ((row + 1) >> 1)); the chunk-dependent
+        // part, including the "- 1", lives in the uniform base
+        xoffb[i] = 4u * (unsigned)(MODE == 2 ? ci * (SH * SW) + ((row + 1) >> 1) * SW + 2 * q : ci * (H * W) + row * W + 4 * q);
+        xsl[i] = ci * XCS + row * GXW + 4 + 4 * q;
+    }
+    const int hci = tid >> 3, hrow = (tid >> 1) & 3, hside = tid & 1;
+    const bool hok = HALO && ci0 + hci < a.Cin, htop = hrow == 0, hbot = hrow == NR - 1;
+    // halo pixel gx = 2 q0 - 1 (left) or 2 q0 + 2 TPR (right); the "2 q0 - 1" is in the base
+    unsigned hoffb = 4u * (unsigned)(MODE == 2 ? hci * (SH * SW) + ((hrow + 1) >> 1) * SW + (hside ? TPR + 1 : 0)
+                                                     : hci * (H * W) + hrow * W + (hside ? 2 * TPR + 1 : 0));
+    const int hsl = hci * XCS + hrow * GXW + (hside ? 4 + 2 * TPR : 3);
+    const bool dyok = co0 + tch < a.Cout;
+    unsigned dyoffb = 4u * (unsigned)(tch * (H * W) + 2 * ttr * W + 2 * ttc);
+
+    // the predicates as wave masks in SGPRs: "uniform flag AND per-thread constant" is scalar mask arithmetic, applied
+    // to the exec mask directly (inverse ballot) -- written with bools the compiler evaluates it per lane in VALU
+    typedef unsigned long long mask_t;
+    const mask_t m_x[2] = {__builtin_amdgcn_ballot_w64(xok[0]), __builtin_amdgcn_ballot_w64(xok[1])};
+    const mask_t m_xtop[2] = {__builtin_amdgcn_ballot_w64(xok[0] && xtop[0]), __builtin_amdgcn_ballot_w64(xok[1] && xtop[1])};
+    const mask_t m_xbot[2] = {__builtin_amdgcn_ballot_w64(xok[0] && xbot[0]), __builtin_amdgcn_ballot_w64(xok[1] && xbot[1])};
+    const mask_t m_h = __builtin_amdgcn_ballot_w64(hok), m_htop = __builtin_amdgcn_ballot_w64(hok && htop),
+                 m_hbot = __builtin_amdgcn_ballot_w64(hok && hbot), m_hleft = __builtin_amdgcn_ballot_w64(hok && !hside),
+                 m_hright = __builtin_amdgcn_ballot_w64(hok && hside);
+    const mask_t m_dy = __builtin_amdgcn_ballot_w64(dyok);
+#define VF_LANES(M) __builtin_amdgcn_inverse_ballot_w64(M)
+
+    f32x4 xr0 = (f32x4){0.f, 0.f, 0.f, 0.f}, xr1 = xr0;
+    float xh = 0.f;
+    f32x2 dy0 = (f32x2){0.f, 0.f}, dy1 = dy0;
+
+    struct Chunk {                                     // uniform: position of a chunk and its edge flags
+        const char* xb;                                // base of the x loads (points one row / pixel before the strip)
+        const char* hb;
+        const char* db;
+        bool top, bot, left, right;
     };
-    auto load_x = [&](int c) {
-        int s, p, q0;
-        chunk_pos(c, s, p, q0);
+    auto chunk_at = [&](int c) -> Chunk {
+        const int s = c / CPI;
+        const int r = c - s * CPI;
+        const int p = (r / CPR) * TR;                  // first tile row
+        const int q0 = (r % CPR) * TPR;                // first tile column
+        Chunk k;
+        const long long img = ((long long)s * a.Cin + ci0) * (SH * SW);
+        const long long xo = MODE == 2 ? img + (long long)(p - 1) * SW + q0 : img + (long long)(2 * p - 1) * W + 2 * q0;
+        k.xb = uniform_ptr(reinterpret_cast<const char*>(a.x) + 4 * xo);
+        k.hb = k.xb - 4;
+        k.db = uniform_ptr(reinterpret_cast<const char*>(a.dy) + 4 * ((((long long)s * a.Cout + co0) * H + 2 * p) * W + 2 * q0));
+        k.top = p == 0;
+        k.bot = p + TR == H / 2;
+        k.left = q0 == 0;
+        k.right = q0 + TPR == W / 2;
+        return k;
+    };
+#define VF_G1 __attribute__((address_space(1)))
+    // (the opaque copies keep base and offset apart until instruction selection: SGPR base + zero-extended VGPR offset)
+    auto load_x = [&](const Chunk& k) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int e = tid + 512 * i;
-            const int ci = e / (NR * QPR), row = (e / QPR) % NR, q = e % QPR;
-            const int gy = 2 * p - 1 + row;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (e < NX4 && ci0 + ci < a.Cin && gy >= 0 && gy < H) {
+            const mask_t edge = (k.top ? m_xtop[i] : 0ull) | (k.bot ? m_xbot[i] : 0ull);
+            if (VF_LANES(m_x[i] & ~edge)) {
+                const char* b = k.xb;
+                unsigned& o = xoffb[i];
+                asm("" : "+s"(b), "+v"(o));
                 if (MODE == 2) {
-                    const float2 h = *reinterpret_cast<const float2*>(
-                        a.x + (((size_t)s * a.Cin + ci0 + ci) * SH + (gy >> 1)) * SW + q0 + 2 * q);
-                    v = make_float4(h.x, h.x, h.y, h.y);
+                    const f32x2 h = *(const VF_G1 f32x2*)((const VF_G1 char*)b + o);
+                    if (i == 0) xr0 = (f32x4){h.x, h.x, h.y, h.y}; else xr1 = (f32x4){h.x, h.x, h.y, h.y};
                 } else {
-                    v = *reinterpret_cast<const float4*>(a.x + (((size_t)s * a.Cin + ci0 + ci) * H + gy) * W + 2 * q0 + 4 * q);
+                    if (i == 0) xr0 = *(const VF_G1 f32x4*)((const VF_G1 char*)b + o);
+                    else xr1 = *(const VF_G1 f32x4*)((const VF_G1 char*)b + o);
                 }
             }
-            if (i == 0) xr0 = v; else xr1 = v;
         }
         if (HALO) {
-            const int ci = tid >> 3, row = (tid >> 1) & 3, side = tid & 1;
-            const int gy = 2 * p - 1 + row, gx = side ? 2 * q0 + 2 * TPR : 2 * q0 - 1;
-            xh = 0.f;
-            if (ci0 + ci < a.Cin && gy >= 0 && gy < H && gx >= 0 && gx < W)
-                xh = MODE == 2 ? a.x[(((size_t)s * a.Cin + ci0 + ci) * SH + (gy >> 1)) * SW + (gx >> 1)]
-                               : a.x[(((size_t)s * a.Cin + ci0 + ci) * H + gy) * W + gx];
+            const mask_t edge = (k.top ? m_htop : 0ull) | (k.bot ? m_hbot : 0ull) | (k.left ? m_hleft : 0ull) |
+                                (k.right ? m_hright : 0ull);
+            if (VF_LANES(m_h & ~edge)) {
+                const char* hb = k.hb;
+                unsigned& o = hoffb;
+                asm("" : "+s"(hb), "+v"(o));
+                xh = *(const VF_G1 float*)((const VF_G1 char*)hb + o);
+            }
         }
     };
-    auto store_x = [&]() {
+    auto store_x = [&](const Chunk& k) {               // k: the chunk the registers hold
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int e = tid + 512 * i;
-            if (e < NX4)
-                *reinterpret_cast<float4*>(Xl + (e / (NR * QPR)) * XCS + ((e / QPR) % NR) * GXW + 4 + 4 * (e % QPR)) = i == 0 ? xr0 : xr1;
+            const mask_t edge = (k.top ? m_xtop[i] : 0ull) | (k.bot ? m_xbot[i] : 0ull);
+            f32x4* dst = reinterpret_cast<f32x4*>(Xl + xsl[i]);
+            // (the empty asm keeps the rarely taken zero store a branch: merged with the data store it becomes four
+            // selects per chunk)
+            if (VF_LANES(edge)) { asm volatile(""); *dst = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+            if (VF_LANES(m_x[i] & ~edge)) *dst = i == 0 ? xr0 : xr1;
         }
-        if (HALO) Xl[(tid >> 3) * XCS + ((tid >> 1) & 3) * GXW + ((tid & 1) ? 4 + 2 * TPR : 3)] = xh;
-    };
-    if (!HALO) {                                       // the strip spans the map: both halo columns are padding
-        for (int e = tid; e < 64 * NR * 2; e += 512)
-            Xl[(e / (2 * NR)) * XCS + ((e >> 1) % NR) * GXW + ((e & 1) ? 4 + 2 * TPR : 3)] = 0.f;
-    }
-    auto load_dy = [&](int c) {
-        int s, p, q0;
-        chunk_pos(c, s, p, q0);
-        dy0 = dy1 = make_float2(0.f, 0.f);
-        if (co0 + tch < a.Cout) {
-            const float* g = a.dy + (((size_t)s * a.Cout + co0 + tch) * H + 2 * (p + ttr)) * W + 2 * (q0 + ttc);
-            dy0 = *reinterpret_cast<const float2*>(g);
-            dy1 = *reinterpret_cast<const float2*>(g + W);
+        if (HALO) {
+            const mask_t edge = (k.top ? m_htop : 0ull) | (k.bot ? m_hbot : 0ull) | (k.left ? m_hleft : 0ull) |
+                                (k.right ? m_hright : 0ull);
+            if (VF_LANES(edge)) { asm volatile(""); Xl[hsl] = 0.f; }
+            if (VF_LANES(m_h & ~edge)) Xl[hsl] = xh;
         }
     };
-    float bias_acc = 0.f;                              // sum of this thread's dY tiles (the bias gradient rides along)
-    auto xform_dy = [&](int buf) {                     // dM = A dY A^T, A^T = [[1,1,1,0],[0,1,-1,-1]]
-        bias_acc += (dy0.x + dy0.y) + (dy1.x + dy1.y);
-        const float r[4][2] = {{dy0.x, dy0.y}, {dy0.x + dy1.x, dy0.y + dy1.y}, {dy0.x - dy1.x, dy0.y - dy1.y},
-                               {-dy1.x, -dy1.y}};
+    // the strip is zeroed once: channels beyond Cin stay zero, and (no HALO) so do both halo columns
+    for (int e = tid; e < XSZ; e += 512) Xl[e] = 0.f;
+    auto load_dy = [&](const Chunk& k) {
+        if (VF_LANES(m_dy)) {
+            const char* b = k.db;
+            unsigned& o = dyoffb;
+            asm("" : "+s"(b), "+v"(o));
+            dy0 = *(const VF_G1 f32x2*)((const VF_G1 char*)b + o);
+            dy1 = *(const VF_G1 f32x2*)((const VF_G1 char*)b + o + 4 * W);
+        }
+    };
+    // dM' = A' dY A'^T with A'^T = [[1,1,1,0],[0,1,-1,1]]: the transpose of the output transform with its last row
+    // POSITIVE (no negations here); wino_wgrad_finish_kernel flips the sign of the slices (3, j < 3) and (i < 3, 3).
+    f32x2 bias2 = (f32x2){0.f, 0.f};                   // sums of this thread's dY tiles (the bias gradient rides along)
+    auto xform_dy = [&](int buf, bool count) {         // count (uniform): false for the clamped repeats of the last chunk
+        const f32x2 r1 = pk_add(dy0, dy1), r2 = pk_sub(dy0, dy1);
+        if (count) bias2 = pk_add(bias2, r1);
+        const f32x2 u0 = pk_lo_pm_hi(dy0, dy0), u1 = pk_lo_pm_hi(r1, r1), u2 = pk_lo_pm_hi(r2, r2), u3 = pk_lo_pm_hi(dy1, dy1);
         float* mo = Ml + buf * MSZ + tch * GT + tsw;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            mo[(4 * i + 0) * 64 * GT] = r[i][0];
-            mo[(4 * i + 1) * 64 * GT] = r[i][0] + r[i][1];
-            mo[(4 * i + 2) * 64 * GT] = r[i][0] - r[i][1];
-            mo[(4 * i + 3) * 64 * GT] = -r[i][1];
-        }
+        mo[0 * 64 * GT] = dy0.x; mo[1 * 64 * GT] = u0.x; mo[2 * 64 * GT] = u0.y; mo[3 * 64 * GT] = dy0.y;
+        mo[4 * 64 * GT] = r1.x;  mo[5 * 64 * GT] = u1.x; mo[6 * 64 * GT] = u1.y; mo[7 * 64 * GT] = r1.y;
+        mo[8 * 64 * GT] = r2.x;  mo[9 * 64 * GT] = u2.x; mo[10 * 64 * GT] = u2.y; mo[11 * 64 * GT] = r2.y;
+        mo[12 * 64 * GT] = dy1.x; mo[13 * 64 * GT] = u3.x; mo[14 * 64 * GT] = u3.y; mo[15 * 64 * GT] = dy1.y;
     };
-    float d[16];
+    // V = B^T d B, B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]]: rows as packed pairs (columns 0,1 / 2,3), then per
+    // row  [v0, v3] = [c0 - c2, c1 - c3]  and  [v1, v2] = [c2 + c1, c2 - c1]:  16 packed instructions per window
+    f32x2 da[4], db_[4];                               // window rows: columns (0,1) and (2,3)
     auto xform_x_read = [&](int r) {
         const float* p = Xl + tch * XCS + (2 * ttr + r) * GXW + 2 * ttc + 3;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) d[r * 4 + c] = p[c];
+        da[r] = (f32x2){p[0], p[1]};
+        db_[r] = (f32x2){p[2], p[3]};
     };
-    auto xform_x_write = [&](int r, int buf) {         // V = B^T d B
+    auto xform_x_write = [&](int buf) {
         float* vo = Vl + buf * MSZ + tch * GT + tsw;
-        float t[4];
+        const f32x2 ta[4] = {pk_sub(da[0], da[2]), pk_add(da[1], da[2]), pk_sub(da[2], da[1]), pk_sub(da[1], da[3])};
+        const f32x2 tb[4] = {pk_sub(db_[0], db_[2]), pk_add(db_[1], db_[2]), pk_sub(db_[2], db_[1]), pk_sub(db_[1], db_[3])};
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const float d0 = d[c], d1 = d[4 + c], d2 = d[8 + c], d3 = d[12 + c];
-            t[c] = r == 0 ? d0 - d2 : (r == 1 ? d1 + d2 : (r == 2 ? d2 - d1 : d1 - d3));
+        for (int r = 0; r < 4; ++r) {
+            const f32x2 v03 = pk_sub(ta[r], tb[r]), v12 = pk_lo_pm_hi(tb[r], ta[r]);
+            vo[(4 * r + 0) * 64 * GT] = v03.x;
+            vo[(4 * r + 1) * 64 * GT] = v12.x;
+            vo[(4 * r + 2) * 64 * GT] = v12.y;
+            vo[(4 * r + 3) * 64 * GT] = v03.y;
         }
-        vo[(4 * r + 0) * 64 * GT] = t[0] - t[2];
-        vo[(4 * r + 1) * 64 * GT] = t[1] + t[2];
-        vo[(4 * r + 2) * 64 * GT] = t[2] - t[1];
-        vo[(4 * r + 3) * 64 * GT] = t[1] - t[3];
     };
 
     f32x16 acc[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) acc[k] = (f32x16){0};
 
+    const int clast = c_end - 1;
     if (n > 0) {
         // ---- prologue: chunk 0 transformed into buffer 0; chunk 1 raw data in registers
-        load_x(c_begin);
-        load_dy(c_begin);
-        store_x();
+        const Chunk k0 = chunk_at(c_begin), k1 = chunk_at(min(c_begin + 1, clast));
+        load_x(k0);
+        load_dy(k0);
+        __syncthreads();                               // strip zero fill done
+        store_x(k0);
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < 4; ++r) xform_x_read(r);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) xform_x_write(r, 0);
-        xform_dy(0);
-        if (n > 1) { load_x(c_begin + 1); load_dy(c_begin + 1); }
+        xform_x_write(0);
+        xform_dy(0, true);
+        load_x(k1);
+        load_dy(k1);
         __syncthreads();
     }
 
     const int aoff = 8 * kh * 64 * GT + (cw * 32 + li) * GT + 4 * (lh ^ ((li >> 4) & 1));
     const int boff = 8 * kh * 64 * GT + (ciw * 32 + li) * GT + 4 * (lh ^ ((li >> 4) & 1));
-    for (int c = 0; c < n; ++c) {
-        const int cur = c & 1, nxt = cur ^ 1;
-        const bool has1 = c + 1 < n, has2 = c + 2 < n;
-        const float* ab = Ml + cur * MSZ + aoff;
-        const float* bb = Vl + cur * MSZ + boff;
-        float4 a_cur = *reinterpret_cast<const float4*>(ab);
-        float4 b_cur = *reinterpret_cast<const float4*>(bb);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            float4 a_nxt = a_cur, b_nxt = b_cur;
-            // ---- side work (raw strip of chunk c+1 -> LDS in slice 0, barrier, transforms in slices 4-7; spreading
-            // them over slices 2-6 measured the same),
-            // interleaved with the slice's own MFMAs: the two waves of a SIMD run in phase, side work in front of
-            // the MFMAs would idle the matrix pipe in both at once
-            __builtin_amdgcn_sched_barrier(0);
-            acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.x, b_cur.x, acc[k], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (k + 1 < 8) {
-                a_nxt = *reinterpret_cast<const float4*>(ab + (k + 1) * 64 * GT);
-                b_nxt = *reinterpret_cast<const float4*>(bb + (k + 1) * 64 * GT);
-            }
-            if (k == 0 && has1) store_x();
-            if (k == 1 && has2) load_x(c_begin + c + 2);
-            if (k == 4) __syncthreads();               // raw strip of chunk c+1 visible to every thread
-            if (has1) {
-                if (k == 4) xform_x_read(0);
-                if (k == 5) xform_x_read(2);
-                if (k == 6) xform_x_write(0, nxt);
-                if (k == 7) xform_x_write(2, nxt);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.y, b_cur.y, acc[k], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (has1) {
-                if (k == 4) xform_x_read(1);
-                if (k == 5) xform_x_read(3);
-                if (k == 6) xform_x_write(1, nxt);
-                if (k == 7) xform_x_write(3, nxt);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.z, b_cur.z, acc[k], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (k == 5 && has1) xform_dy(nxt);
-            if (k == 6 && has2) load_dy(c_begin + c + 2);
-            __builtin_amdgcn_sched_barrier(0);
-            acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.w, b_cur.w, acc[k], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            a_cur = a_nxt; b_cur = b_nxt;
-        }
-        __syncthreads();
+    // One chunk, PAR = its buffer parity (compile time).  Side work of chunk C+1 (raw strip -> LDS in slice 0, barrier,
+    // transforms in slices 4-7) and the loads of chunk C+2, interleaved with the slices' own MFMAs (the two waves of a
+    // SIMD run in phase: side work in front of the MFMAs would idle the matrix pipe in both at once).  Chunk indices
+    // beyond the slice are clamped: the last iterations redo harmless loads / LDS writes that nobody reads.
+#define VF_WG_CHUNK(C, PAR)                                                                               \
+    {                                                                                                     \
+        const Chunk kn1 = chunk_at(min((C) + 1, clast)), kn2 = chunk_at(min((C) + 2, clast));             \
+        const float* ab = Ml + (PAR) * MSZ + aoff;                                                        \
+        const float* bb = Vl + (PAR) * MSZ + boff;                                                        \
+        f32x4 a_cur = *reinterpret_cast<const f32x4*>(ab);                                                \
+        f32x4 b_cur = *reinterpret_cast<const f32x4*>(bb);                                                \
+        _Pragma("unroll") for (int k = 0; k < 8; ++k) {                                                   \
+            f32x4 a_nxt = a_cur, b_nxt = b_cur;                                                           \
+            __builtin_amdgcn_sched_barrier(0);                                                            \
+            acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.x, b_cur.x, acc[k], 0, 0, 0);             \
+            __builtin_amdgcn_sched_barrier(0);                                                            \
+            if (k + 1 < 8) {                                                                              \
+                a_nxt = *reinterpret_cast<const f32x4*>(ab + (k + 1) * 64 * GT);                          \
+                b_nxt = *reinterpret_cast<const f32x4*>(bb + (k + 1) * 64 * GT);                          \
+            }                                                                                             \
+            if (k == 0) store_x(kn1);                                                                     \
+            if (k == 1) load_x(kn2);                                                                      \
+            if (k == 4) { __syncthreads(); xform_x_read(0); }   /* raw strip of chunk C+1 visible */        \
+            if (k == 5) xform_x_read(2);                                                                  \
+            __builtin_amdgcn_sched_barrier(0);                                                            \
+            acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.y, b_cur.y, acc[k], 0, 0, 0);             \
+            __builtin_amdgcn_sched_barrier(0);                                                            \
+            if (k == 4) xform_x_read(1);                                                                  \
+            if (k == 5) xform_x_read(3);                                                                  \
+            if (k == 6) xform_x_write((PAR) ^ 1);                                                         \
+            __builtin_amdgcn_sched_barrier(0);                                                            \
+            acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.z, b_cur.z, acc[k], 0, 0, 0);             \
+            __builtin_amdgcn_sched_barrier(0);                                                            \
+            if (k == 5) xform_dy((PAR) ^ 1, (C) + 1 <= clast);                                                          \
+            if (k == 6) load_dy(kn2);                                                                     \
+            __builtin_amdgcn_sched_barrier(0);                                                            \
+            acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.w, b_cur.w, acc[k], 0, 0, 0);             \
+            __builtin_amdgcn_sched_barrier(0);                                                            \
+            a_cur = a_nxt; b_cur = b_nxt;                                                                 \
+        }                                                                                                 \
+        __syncthreads();                                                                                  \
     }
+    {
+        int c = c_begin;
+        for (; c + 1 < c_end; c += 2) {
+            VF_WG_CHUNK(c, 0);
+            VF_WG_CHUNK(c + 1, 1);
+        }
+        if (c < c_end) VF_WG_CHUNK(c, 0);
+    }
+#undef VF_WG_CHUNK
+#undef VF_G1
+#undef VF_LANES
+    const float bias_acc = bias2.x + bias2.y;
 
     // partial dU of this slice: rows k = 8kh .. 8kh+7
     const int slab = bz;
@@ -325,7 +401,10 @@ __global__ __launch_bounds__(256) void wino_wgrad_finish_kernel(const float* __r
     const float* p = du + (size_t)co * CinQ + ci;
     float u[16];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) u[k] = p[k * kstride];
+    for (int k = 0; k < 16; ++k) {                        // (the wgrad kernel's dY transform keeps its last row positive:
+        const float v = p[k * kstride];                   //  slices (3, j < 3) and (i < 3, 3) come with the opposite sign)
+        u[k] = ((k >> 2) == 3) != ((k & 3) == 3) ? -v : v;
+    }
     // G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]] : rows first, then columns
     float t[3][4];
 #pragma unroll

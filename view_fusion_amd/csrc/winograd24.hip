@@ -76,51 +76,6 @@ struct WGeo {
     static int groups(int S) { return IPG == 1 ? S * WPI : (S + IPG - 1) / IPG; }
 };
 
-// Packed fp32 (two lanes of a 64-bit register pair per instruction).  Written as instructions: the compiler's cost
-// model splits <2 x float> arithmetic with swizzles back into scalar ops + moves, and under fp32 MFMAs every vector
-// instruction counts (tools/mfma_valu.hip).
-__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {              // a - b
-    f32x2 d;
-    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
-    return d;
-}
-__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {              // a + b
-    f32x2 d;
-    asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
-    return d;
-}
-template <int K>
-__device__ __forceinline__ f32x2 pk_fmak(f32x2 a, f32x2 c) {             // K a + c, K in {2, 4, 8} (inline constants)
-    f32x2 d;
-    if (K == 2) asm("v_pk_fma_f32 %0, %1, 2.0, %2 op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "v"(c));
-    else if (K == 4) asm("v_pk_fma_f32 %0, %1, 4.0, %2 op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "v"(c));
-    else {
-        const f32x2 a2 = pk_add(a, a);
-        asm("v_pk_fma_f32 %0, %1, 4.0, %2 op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a2), "v"(c));
-    }
-    return d;
-}
-__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) {     // a * b + c
-    f32x2 d;
-    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-    return d;
-}
-__device__ __forceinline__ f32x2 pk_nmul4_add(f32x2 a, f32x2 c) {        // c - 4 a
-    f32x2 d;
-    asm("v_pk_fma_f32 %0, %1, 4.0, %2 op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(d) : "v"(a), "v"(c));
-    return d;
-}
-__device__ __forceinline__ f32x2 pk_hi_pm_lo(f32x2 p) {                  // [p.y + p.x, p.y - p.x]
-    f32x2 d;
-    asm("v_pk_add_f32 %0, %1, %1 op_sel:[1,0] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(d) : "v"(p));
-    return d;
-}
-__device__ __forceinline__ f32x2 pk_hi_pm_2lo(f32x2 q) {                 // [q.y + 2 q.x, q.y - 2 q.x]
-    f32x2 d;
-    asm("v_pk_fma_f32 %0, %1, 2.0, %1 op_sel:[0,0,1] op_sel_hi:[0,0,1] neg_hi:[1,0,0]" : "=v"(d) : "v"(q));
-    return d;
-}
-
 #ifdef VF_STAMPS
 __device__ unsigned long long g_stamps[16];     // debug build only: shader-clock sums of prologue / chunk loop / epilogue, tiles
 #endif
