@@ -15,6 +15,10 @@ __global__ __launch_bounds__(512, 2) void k(const float* __restrict__ src, float
     for (int i = 0; i < 6; ++i) acc[i] = (f32x16){0};
     float a = src[lane], b = src[64 + lane];
     float v[32];
+    typedef float f32x4q __attribute__((ext_vector_type(4)));
+    f32x4q bq[2];                                        // 8 bf16 each (contents irrelevant here)
+    bq[0] = (f32x4q){src[lane], src[lane + 1], src[lane + 2], src[lane + 3]};
+    bq[1] = (f32x4q){src[lane + 4], src[lane + 5], src[lane + 6], src[lane + 7]};
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     f32x2 pk[9];
     int sc = 0;
@@ -31,7 +35,8 @@ __global__ __launch_bounds__(512, 2) void k(const float* __restrict__ src, float
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 __builtin_amdgcn_sched_barrier(0);
-                if (AG) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[s]) : "v"(a), "v"(b));   // accumulators in AGPRs
+                if (AG == 2) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[s]) : "v"(bq[0]), "v"(bq[1]));  // bf16, 8 passes
+                else if (AG) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[s]) : "v"(a), "v"(b));   // accumulators in AGPRs
                 else acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[s], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -72,7 +77,7 @@ void run(const float* src, float* d) {
     const double mf = (double)iters * 24;                 // MFMAs per wave
     // cycles per MFMA per SIMD at the achieved rate, assuming 2.4 GHz is NOT known -> report ns per (2 MFMAs) and TF
     const double tf = blocks * 8 * mf * 4096.0 / best / 1e9;
-    printf("%s%s x %2d per MFMA: %8.3f ms  %6.1f TFLOP/s  (%.1f ns per MFMA pair)\n", AG ? "acc in AGPRs, " : "", KIND == 0 ? "v_fma " : KIND == 1 ? "v_add " : KIND == 2 ? "s_add " : KIND == 3 ? "v_pk_fma " : KIND == 4 ? "ds_read+v_add " : KIND == 5 ? "ds_write " : "v_mov ", NV, best, tf,
+    printf("%s%s x %2d per MFMA: %8.3f ms  %6.1f TFLOP/s  (%.1f ns per MFMA pair)\n", AG == 2 ? "bf16 32x32x16 MFMA, " : AG ? "acc in AGPRs, " : "", KIND == 0 ? "v_fma " : KIND == 1 ? "v_add " : KIND == 2 ? "s_add " : KIND == 3 ? "v_pk_fma " : KIND == 4 ? "ds_read+v_add " : KIND == 5 ? "ds_write " : "v_mov ", NV, best, tf,
            best * 1e6 / mf);
 }
 
@@ -86,6 +91,7 @@ int main() {
     run<4, 1>(src, d); run<8, 1>(src, d); run<16, 1>(src, d); run<32, 1>(src, d);
     run<8, 2>(src, d); run<32, 2>(src, d); run<4, 3>(src, d); run<8, 3>(src, d); run<16, 3>(src, d);
     run<4, 4>(src, d); run<8, 4>(src, d); run<4, 5>(src, d); run<8, 5>(src, d); run<8, 6>(src, d); run<16, 6>(src, d);
+    run<0, 1, 2>(src, d); run<4, 1, 2>(src, d); run<8, 1, 2>(src, d); run<16, 1, 2>(src, d);
     run<0, 1, 1>(src, d); run<4, 1, 1>(src, d); run<8, 1, 1>(src, d); run<16, 1, 1>(src, d); run<32, 1, 1>(src, d);
     return 0;
 }
