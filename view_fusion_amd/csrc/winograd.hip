@@ -268,16 +268,17 @@ __global__ __launch_bounds__(512, 2) void wino_wgrad_kernel(WinoWgradArgs a) {
         const Chunk kn1 = chunk_at(min((C) + 1, clast)), kn2 = chunk_at(min((C) + 2, clast));             \
         const float* ab = Ml + (PAR) * MSZ + aoff;                                                        \
         const float* bb = Vl + (PAR) * MSZ + boff;                                                        \
-        f32x4 a_cur = *reinterpret_cast<const f32x4*>(ab);                                                \
-        f32x4 b_cur = *reinterpret_cast<const f32x4*>(bb);                                                \
         _Pragma("unroll") for (int k = 0; k < 8; ++k) {                                                   \
-            f32x4 a_nxt = a_cur, b_nxt = b_cur;                                                           \
+            f32x4 a_nxt, b_nxt;                                                                           \
             __builtin_amdgcn_sched_barrier(0);                                                            \
             acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.x, b_cur.x, acc[k], 0, 0, 0);             \
             __builtin_amdgcn_sched_barrier(0);                                                            \
             if (k + 1 < 8) {                                                                              \
                 a_nxt = *reinterpret_cast<const f32x4*>(ab + (k + 1) * 64 * GT);                          \
                 b_nxt = *reinterpret_cast<const f32x4*>(bb + (k + 1) * 64 * GT);                          \
+            } else {                     /* behind the barrier: slice 0 of chunk C+1, from the other buffers */ \
+                a_nxt = *reinterpret_cast<const f32x4*>(Ml + ((PAR) ^ 1) * MSZ + aoff);                   \
+                b_nxt = *reinterpret_cast<const f32x4*>(Vl + ((PAR) ^ 1) * MSZ + boff);                   \
             }                                                                                             \
             if (k == 0) store_x(kn1);                                                                     \
             if (k == 1) load_x(kn2);                                                                      \
@@ -292,15 +293,20 @@ __global__ __launch_bounds__(512, 2) void wino_wgrad_kernel(WinoWgradArgs a) {
             __builtin_amdgcn_sched_barrier(0);                                                            \
             acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.z, b_cur.z, acc[k], 0, 0, 0);             \
             __builtin_amdgcn_sched_barrier(0);                                                            \
-            if (k == 5) xform_dy((PAR) ^ 1, (C) + 1 <= clast);                                                          \
+            if (k == 5) xform_dy((PAR) ^ 1, (C) + 1 <= clast);                                            \
             if (k == 6) load_dy(kn2);                                                                     \
             __builtin_amdgcn_sched_barrier(0);                                                            \
             acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.w, b_cur.w, acc[k], 0, 0, 0);             \
             __builtin_amdgcn_sched_barrier(0);                                                            \
+            /* the chunk's second barrier sits behind slice 6: the images of chunk C+1 are complete, every read  \
+               of this chunk's images is issued (slice 7's fragments are in registers), and slice 7 fetches the  \
+               first fragments of chunk C+1 -- no wave waits for LDS at a chunk boundary */                      \
+            if (k == 6) __syncthreads();                                                                  \
             a_cur = a_nxt; b_cur = b_nxt;                                                                 \
         }                                                                                                 \
-        __syncthreads();                                                                                  \
     }
+    f32x4 a_cur = *reinterpret_cast<const f32x4*>(Ml + aoff);
+    f32x4 b_cur = *reinterpret_cast<const f32x4*>(Vl + boff);
     {
         int c = c_begin;
         for (; c + 1 < c_end; c += 2) {
