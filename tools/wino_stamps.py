@@ -23,8 +23,11 @@ for Cin, Cout, H in [(64, 64, 64), (128, 64, 64), (128, 128, 32), (256, 128, 32)
     y = torch.empty(S, Cout, H, H, device=dev)
     nws = lib.vf_wino_conv_ws_floats(S, Cin, Cout, H, H)
     ws = torch.empty(max(nws, 1), device=dev)
+    ops_on = os.environ.get("VF_STAMP_OPERANDS", "0") == "1"     # 1: with bias + per-view bias
+    bias = torch.randn(Cout, device=dev); vb = torch.randn(S, Cout, device=dev)
     def fn():
-        _lib.call("vf_wino_conv_fwd", x.data_ptr(), uf.data_ptr(), None, None, None, y.data_ptr(),
+        _lib.call("vf_wino_conv_fwd", x.data_ptr(), uf.data_ptr(), bias.data_ptr() if ops_on else None,
+                  vb.data_ptr() if ops_on else None, None, y.data_ptr(),
                   ws.data_ptr(), nws, S, Cin, Cout, H, H, 0, st)
     for _ in range(3): fn()
     torch.cuda.synchronize()
