@@ -11,6 +11,11 @@
 
 namespace {
 
+__device__ __forceinline__ float4 ld_nt(const float4* p) {          // streaming (non-temporal) 16-byte load
+    const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+    return make_float4(t.x, t.y, t.z, t.w);
+}
+
 // "cat" inputs: the normalised tensor is the channel concatenation [x1 (C1 channels) | x2 (C - C1)] of two
 // contiguous NCHW tensors (the decoder's skip connections, reference unet.py:134) that is never materialised.
 // float4 index i4 of group (s, g) -> its address in whichever tensor holds that channel.
@@ -247,8 +252,10 @@ __global__ __launch_bounds__(NT) void gn_bwd_fused_kernel(const float* __restric
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int idc = min((int)threadIdx.x + i * NT, n4 - 1);
-            xv[i] = x4[idc];
-            dv[i] = d4[idc];
+            // (last use of both tensors in the backward pass: non-temporal loads leave the cache to dx, which the next
+            // kernel reads -- gn_bwd 2.80 -> 2.73 ms per step)
+            xv[i] = ld_nt(x4 + idc);
+            dv[i] = ld_nt(d4 + idc);
         }
     }
 #pragma unroll
