@@ -56,24 +56,26 @@ def _cpu_model():
 
 def cpu_baseline(hw, n_views, threads_all=None):
     """The CPU oracle (oracle/: PyTorch-CPU fp32 restatement of the reference, pinned to it by tests/golden; kind
-    "port") on the host cores, on BOUNDED samples of the bench workload (same network, image size and N; fewer
-    samples per iteration so that the leg takes ~1 minute):
-      train, all cores : B=2 x N views, 1 warm-up + 2 timed iterations (fwd + bwd + Adam)
-      train, 1 thread  : B=1 x N views, 1 warm-up + 1 timed iteration
-      sampler, all cores: B=1 x N views, 10 reverse steps of the T=1000 schedule (extrapolated linearly to T=1000)
+    "port") on the host cores, on BOUNDED samples of BASELINE.json's configurations, ~1 minute in all:
+      calibration      : B=2 x N views, one iteration per thread count (PyTorch-CPU eager does not scale to all cores)
+      C2 = `value`     : the bench workload itself, B=16 x N=6 (S=96), 1 warm-up + 2 timed iterations (fwd+bwd+Adam)
+      C4               : B=8 x N=6 (S=48), 1 warm-up + 2 timed iterations
+      C1 (in full)     : small UNet, B=2 N=2, one training iteration + the 10-step reverse chain
+      one thread       : B=1 x N views, 1 warm-up + 1 timed iteration
+      sampler (C5)     : B=1 x N views, 10 reverse steps of the T=1000 schedule (extrapolated linearly to T=1000)
     """
     from oracle import unet_ref, view_fusion_ref as vfr
     from view_fusion_amd import UNet
     hp = train.SMALL_UNET
     threads_all = threads_all or torch.get_num_threads()
 
-    def train_leg(B, iters, threads):
+    def train_leg(B, iters, threads, N=n_views):
         torch.set_num_threads(threads)
         torch.manual_seed(0)
         sd = {k: v.clone().requires_grad_(True) for k, v in UNet(**hp).state_dict().items()}
         opt = torch.optim.Adam(list(sd.values()), lr=1e-4)
         sched = vfr.schedule_buffers(vfr.beta_schedule(**train.BETA_SCHEDULE["train"]))
-        b = train.synthetic_batch(B, n_views, hw, "cpu", seed=0)
+        b = train.synthetic_batch(B, N, hw, "cpu", seed=0)
         fn = lambda x, a, l: unet_ref.unet_forward(sd, hp, x, a, l)
         g = torch.Generator().manual_seed(1)
 
@@ -90,24 +92,26 @@ def cpu_baseline(hw, n_views, threads_all=None):
         for _ in range(iters):
             one()
         dt = (time.perf_counter() - t0) / iters
-        return B * n_views / dt, dt
+        return B * N / dt, dt
 
-    def sampler_leg_cpu(steps, threads):
+    def sampler_leg_cpu(steps, threads, B=1, N=n_views, T=1000):
         torch.set_num_threads(threads)
         torch.manual_seed(0)
         sd = {k: v.clone() for k, v in UNet(**hp).state_dict().items()}
-        sched = vfr.schedule_buffers(vfr.beta_schedule(**train.BETA_SCHEDULE["test"]))
-        b = train.synthetic_batch(1, n_views, hw, "cpu", seed=0)
+        kw = dict(train.BETA_SCHEDULE["test"])
+        kw["num_timesteps"] = T
+        sched = vfr.schedule_buffers(vfr.beta_schedule(**kw))
+        b = train.synthetic_batch(B, N, hw, "cpu", seed=0)
         fn = lambda x, a, l: unet_ref.unet_forward(sd, hp, x, a, l)
         g = torch.Generator().manual_seed(2)
-        y = torch.randn(1, 3, hw, hw, generator=g)
+        y = torch.randn(B, 3, hw, hw, generator=g)
         with torch.no_grad():
             for i in range(steps + 1):
                 if i == 1:
                     t0 = time.perf_counter()      # step 0 is the warm-up
-                t = torch.full((1,), 999 - i, dtype=torch.long)
+                t = torch.full((B,), max(T - 1 - i, 0), dtype=torch.long)
                 y, _, _ = vfr.p_sample(fn, sched, y, b["y_cond"], b["view_count"], b["angle"], t,
-                                       torch.randn(1, 3, hw, hw, generator=g))
+                                       torch.randn(B, 3, hw, hw, generator=g))
         return (time.perf_counter() - t0) / steps
 
     # PyTorch-CPU eager does not scale to every core of a large host on batches this small (on the 2 x 64-core box
@@ -116,17 +120,26 @@ def cpu_baseline(hw, n_views, threads_all=None):
     for th in sorted({t for t in (8, 16, 32, 64, threads_all) if t <= threads_all}):
         calib[th] = train_leg(2, 1, th)[0]
     best = max(calib, key=calib.get)
-    v_all, dt_all = train_leg(2, 2, best)
     threads_max, threads_all = threads_all, best
+    v_c2, dt_c2 = train_leg(16, 2, best)
+    v_c4, dt_c4 = train_leg(8, 2, best)
+    v_c1, dt_c1 = train_leg(2, 1, best, N=2)
+    c1_chain = sampler_leg_cpu(10, best, B=2, N=2, T=10) * 10
     v_one, dt_one = train_leg(1, 1, 1)
     s_step = sampler_leg_cpu(10, threads_all)
     torch.set_num_threads(threads_max)
-    return dict(value=v_all, unit="view denoise-steps/s", cores=threads_all, kind="port",
+    return dict(value=v_c2, unit="view denoise-steps/s", cores=threads_all, kind="port",
                 cpu_model=_cpu_model(), logical_cpus=os.cpu_count(), torch=torch.__version__,
                 thread_calibration={str(k): v for k, v in calib.items()},
-                sample=f"oracle training iteration (fwd+bwd+Adam) on the bench network / image size / N={n_views}, "
-                       f"B=2 ({2 * n_views} views), 2 timed iterations after 1 warm-up, {dt_all:.2f} s/iteration, "
+                sample=f"C2, the bench workload itself: oracle training iteration (fwd+bwd+Adam), small UNet {hw}x{hw}, "
+                       f"B=16 N={n_views} ({16 * n_views} views), 2 timed iterations after 1 warm-up, {dt_c2:.2f} s/iteration, "
                        f"{threads_all} threads (the fastest of the calibrated counts; the host offers {threads_max})",
+                c4=dict(value=v_c4, cores=threads_all,
+                        sample=f"C4: B=8 N={n_views} ({8 * n_views} views), 2 timed iterations after 1 warm-up, "
+                               f"{dt_c4:.2f} s/iteration"),
+                c1=dict(train_value=v_c1, train_s_per_iteration=dt_c1, chain_s=c1_chain, cores=threads_all,
+                        sample="C1 in full: small UNet, B=2 N=2 64x64: one training iteration (after 1 warm-up) + the "
+                               "10-step reverse chain (T=10 schedule, 10 p_sample calls after 1 warm-up call)"),
                 one_thread=dict(value=v_one, cores=1, sample=f"B=1 ({n_views} views), 1 timed iteration after 1 warm-up, "
                                                              f"{dt_one:.2f} s/iteration"),
                 sampler=dict(value=1.0 / (s_step * 1000), unit="sampled views/s at T=1000", cores=threads_all,
@@ -137,14 +150,15 @@ def cpu_baseline(hw, n_views, threads_all=None):
 
 def pmc_traffic():
     """HBM bytes per launch per kernel from the committed rocprofv3 PMC passes of this same bench command
-    (profiles/r02_bench_pmc_traffic_kib_per_launch.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs;
-    FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 correction).  PMC counters cannot be read from inside the
-    process, so this is the recorded, not a live, figure; None when no table is committed."""
-    for name in ("r02_bench_pmc_traffic_kib_per_launch.json", "r01_bench_pmc_traffic_kib_per_launch.json"):
-        path = os.path.join(ROOT, "profiles", name)
+    (profiles/rNN_bench_pmc_traffic_kib_per_launch.json, newest round first: FETCH_SIZE and WRITE_SIZE collected in
+    separate --pmc runs; FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 correction).  PMC counters cannot be read
+    from inside the process, so this is the recorded, not a live, figure; None when no table is committed."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_pmc_traffic_kib_per_launch.json")), reverse=True):
         try:
             tab = json.load(open(path))
-            return {k: (2 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0 for k, d in tab.items()}, "profiles/" + name
+            return ({k: (2 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0 for k, d in tab.items()},
+                    "profiles/" + os.path.basename(path))
         except (OSError, KeyError, ValueError):
             continue
     return {}, None
@@ -209,15 +223,18 @@ def roofline(trainer, batch, S, ms_step, steps=2):
             row.update(algorithmic_gbs=nb / s / 1e9, frac_of_hbm_peak=nb / s / 1e9 / PEAK_HBM_GBS,
                        algorithmic_mb_per_launch=nb / n / 1e6)
         table[fam] = row
-    f, s, n, _ = agg["wino_conv"]
-    executed = f / WINO_REDUCTION["wino_conv"]
+    # headline family: the Winograd forward/dgrad kernel when any launch took it, else the MFMA-bound family with the
+    # largest time (small S: every 3x3 layer runs the direct kernel)
+    head = "wino_conv" if "wino_conv" in agg else max((k for k in agg if agg[k][0] > 0), key=lambda k: agg[k][1])
+    f, s, n, nb_head = agg[head]
+    executed = f / WINO_REDUCTION.get(head, 1.0)
     # floor of the whole step: every conv at the fp32 MFMA peak, the stride-1 3x3 layers at Winograd's multiply count
     # (forward + dgrad: nested F(2,3)xF(4,3); weight gradient: F(2x2,3x3))
     step_tflop_direct = GFLOP_PER_VIEW_TRAIN * S / 1e3
     g3 = GFLOP_3X3_S1_PER_VIEW_FWD * S / 1e3
     step_tflop_wino = step_tflop_direct - 2 * g3 * (1 - 1 / WINO_REDUCTION["wino_conv"]) - g3 * (1 - 1 / WINO_REDUCTION["wino_wgrad"])
     floor_ms = step_tflop_wino / PEAK_FP32_MATRIX_TFLOPS * 1e3
-    out = dict(bound="mfma", kernel=FAMILIES["wino_conv"][0], achieved=executed / s / 1e12, peak=PEAK_FP32_MATRIX_TFLOPS,
+    out = dict(bound="mfma", kernel=FAMILIES.get(head, (head,))[0], achieved=executed / s / 1e12, peak=PEAK_FP32_MATRIX_TFLOPS,
                unit="TFLOP/s", frac=executed / s / 1e12 / PEAK_FP32_MATRIX_TFLOPS,
                note="achieved = multiplies the matrix cores EXECUTE: algorithmic direct-convolution FLOPs "
                     "(2*S*Cout*Cin*9*H*W per launch) / 3 / HIP-event time of the vf_wino_conv_fwd launches "
@@ -225,6 +242,16 @@ def roofline(trainer, batch, S, ms_step, steps=2):
                direct_equivalent_tflops=f / s / 1e12, launches_per_step=n // steps, avg_launch_us=s / n * 1e6,
                algorithmic_gflop_per_launch=f / n / 1e9, executed_gflop_per_launch=executed / n / 1e9,
                traffic=traffic.get("wino_conv_kernel"), traffic_unit="HBM bytes per launch", traffic_source=source,
+               algorithmic_bytes_per_launch=nb_head / n if nb_head else None,
+               traffic_ratio=(traffic["wino_conv_kernel"] / (nb_head / n)
+                              if nb_head and traffic.get("wino_conv_kernel") and head == "wino_conv" else None),
+               traffic_note="algorithmic bytes = input + output activations (+ residual) + the layer's weights, once "
+                            "each; the PMC figure on top of that is: the 2-row halo re-read of every 2-row tile strip "
+                            "(input rows fetched 2x on 64^2/32^2 maps when the halo misses L2), one more input read "
+                            "per additional 64-channel co tile (Cout/64 workgroup columns stream the same x), the "
+                            "transformed weight image U (24/9 = 2.67x the 3x3 weights, streamed by every workgroup: "
+                            "L2 absorbs most, the rest is HBM/MALL fetch), and the K-split partial tiles of the tail "
+                            "round (written raw and re-read by wino_fixup_kernel)",
                step_floor_ms=dict(direct_fp32_mfma=step_tflop_direct / PEAK_FP32_MATRIX_TFLOPS * 1e3,
                                   winograd_adjusted=floor_ms,
                                   hbm=HBM_MB_PER_VIEW_TRAIN * S / 1e3 / PEAK_HBM_GBS * 1e3),
@@ -233,17 +260,44 @@ def roofline(trainer, batch, S, ms_step, steps=2):
     return out
 
 
+GFLOP_PER_VIEW_FWD = 20.994            # one stacked view through the small UNet, forward
+PARAM_BYTES = 33.9e6 * 4               # the weights every reverse step streams at least once
+
+
 def sampler_leg():
     """Second half of BASELINE's metric: sampled views/s of the reverse-diffusion loop (config C5:
     T=1000 test schedule, N conditioning views).  A bounded number of reverse steps is timed and
-    extrapolated linearly to T=1000 (the loop is strictly sequential with constant step cost)."""
+    extrapolated linearly to T=1000 (the loop is strictly sequential with constant step cost).
+
+    Roofline per configuration (one reverse step = one UNet forward over S = B*N stacked views + the fused tail):
+      mfma : 20.994 GFLOP x S / ms_per_step / 157.3 TF (direct-convolution FLOPs; where the Winograd kernel runs -- the
+             B=16 configuration -- the step executes fewer multiplies and `frac_of_winograd_floor` prices that)
+      hbm  : (weights once + 141.7 MB ideal-fusion activation traffic per view) / ms_per_step / 8 TB/s
+    At B=1 both fractions are small by construction: the step is a chain of ~260 short dependent kernels (graph replay),
+    i.e. latency-bound; `launches_per_step` and `us_per_launch` say how short."""
     from view_fusion_amd import sampling_bench
     model = train.build_model(device="cuda:0", phase="test")
     out = {"unit": "completed target views/s at T=1000", "schedule": "linear T=1000 1e-4..0.09"}
     for B, N, steps in ((1, 1, 100), (1, 6, 100), (1, 12, 100), (16, 6, 20)):
         r = sampling_bench.time_sampler(B, N, steps=steps, model=model, use_graph=None)
-        out[f"B{B}_N{N}"] = dict(sampled_views_per_sec=r["sampled_views_per_sec"], ms_per_step=r["ms_per_step"],
-                                 view_unet_evals_per_sec=r["view_unet_evals_per_sec"], steps_timed=steps)
+        S, ms = B * N, r["ms_per_step"]
+        gflop = GFLOP_PER_VIEW_FWD * S
+        nbytes = PARAM_BYTES + 141.7e6 * S
+        mfma_floor_ms = gflop / PEAK_FP32_MATRIX_TFLOPS
+        row = dict(sampled_views_per_sec=r["sampled_views_per_sec"], ms_per_step=ms,
+                   view_unet_evals_per_sec=r["view_unet_evals_per_sec"], steps_timed=steps, graph_replay=bool(S <= 16),
+                   roofline=dict(gflop_per_step=gflop, achieved_tflops=gflop / ms, mfma_floor_ms=mfma_floor_ms,
+                                 frac_of_fp32_mfma_peak=mfma_floor_ms / ms,
+                                 mbytes_per_step=nbytes / 1e6, hbm_floor_ms=nbytes / PEAK_HBM_GBS / 1e6,
+                                 frac_of_hbm_peak=nbytes / PEAK_HBM_GBS / 1e6 / ms,
+                                 weight_stream_floor_ms=PARAM_BYTES / PEAK_HBM_GBS / 1e6))
+        if S >= 48:      # the stride-1 3x3 layers run the nested Winograd kernel (1/3 of the direct multiplies)
+            wino_gflop = gflop - GFLOP_3X3_S1_PER_VIEW_FWD * S * (1 - 1 / WINO_REDUCTION["wino_conv"])
+            row["roofline"]["frac_of_winograd_floor"] = wino_gflop / PEAK_FP32_MATRIX_TFLOPS / ms
+        n_launch = getattr(sampling_bench, "LAST_LAUNCHES_PER_STEP", None)
+        if n_launch:
+            row["roofline"].update(abi_launcher_calls_per_step=n_launch, us_per_launcher_call=ms * 1e3 / n_launch)
+        out[f"B{B}_N{N}"] = row
     return out
 
 
@@ -304,12 +358,19 @@ def main():
             "iters_per_sec": args.steps / dt, "loss": loss_val,
             "achieved_tflops_total": 62.98e9 * S * world * args.steps / dt / 1e12,
         }
+        # the extra legs must never cost the headline line: a failure is reported inside the JSON instead
+        def leg(key, fn, *a):
+            try:
+                res[key] = fn(*a)
+            except Exception as e:          # noqa: BLE001
+                res[key] = {"error": f"{type(e).__name__}: {e}"}
+
         if world == 1 and not args.no_roofline:
-            res["roofline"] = roofline(trainer, batch, S, ms)
+            leg("roofline", roofline, trainer, batch, S, ms)
         if world == 1 and not args.no_sampler:
-            res["sampler"] = sampler_leg()
+            leg("sampler", sampler_leg)
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(64, args.views)
+            leg("cpu_baseline", cpu_baseline, 64, args.views)
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

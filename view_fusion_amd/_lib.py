@@ -11,8 +11,16 @@ import os
 import torch  # noqa: F401  (loads libamdhip64 first)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# VF_HIP_LIB: tuning aid -- load another build of the same C ABI (A/B timing of kernel variants in one process tree)
-LIB_PATH = os.environ.get("VF_HIP_LIB") or os.path.join(_HERE, "lib", "libvf_hip.so")
+LIB_PATH = os.path.join(_HERE, "lib", "libvf_hip.so")
+# Kernel-tuning aid, OFF in production: with VF_DEBUG_AB=1 *and* VF_HIP_LIB=<path> another build of the same C ABI is
+# loaded instead (A/B timing of kernel variants in one process tree; such builds live under build/ab/, never in lib/).
+# The override is announced on stderr and load() checks every symbol of the table below against it.
+_OVERRIDE = os.environ.get("VF_HIP_LIB") if os.environ.get("VF_DEBUG_AB") == "1" else None
+if _OVERRIDE:
+    LIB_PATH = _OVERRIDE
+elif os.environ.get("VF_HIP_LIB"):
+    import warnings
+    warnings.warn("VF_HIP_LIB is ignored unless VF_DEBUG_AB=1 (kernel-tuning aid)", stacklevel=2)
 
 _P, _I, _L, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
 
@@ -70,6 +78,7 @@ SIGNATURES = {
 _RESTYPE = {"vf_conv_wgrad_ws_floats": _L, "vf_time_affine_ws_floats": _L, "vf_wino_conv_ws_floats": _L, "vf_wino_wgrad_ws_floats": _L, "vf_conv_fwd_ws_floats": _L}
 
 _lib = None
+N_CALLS = 0          # C-ABI launcher invocations so far (bench.py: launches per sampler step)
 
 
 class VFHipError(RuntimeError):
@@ -85,6 +94,12 @@ def load():
                 f"{LIB_PATH} not found: build it with `python -m view_fusion_amd.build` "
                 "(there is no CPU / eager fallback for the ViewFusion hot path)")
         lib = ctypes.CDLL(LIB_PATH)
+        if _OVERRIDE:
+            import sys
+            print(f"[view_fusion_amd] VF_DEBUG_AB: loading {LIB_PATH} instead of lib/libvf_hip.so", file=sys.stderr)
+        missing = [name for name in SIGNATURES if not hasattr(lib, name)]
+        if missing:
+            raise VFHipError(f"{LIB_PATH} does not export {missing}: stale build? run `python -m view_fusion_amd.build`")
         for name, args in SIGNATURES.items():
             fn = getattr(lib, name)
             fn.argtypes = args
@@ -95,6 +110,8 @@ def load():
 
 def call(name, *args):
     """Invoke an int-returning launcher; non-zero hipError_t -> exception."""
+    global N_CALLS
+    N_CALLS += 1
     rc = getattr(load(), name)(*args)
     if rc != 0:
         raise VFHipError(f"{name} failed with hipError_t {rc}")

@@ -8,11 +8,27 @@ MI355X engine (no dataset / wandb / image-grid plumbing):
   * eval reduction: PSNR + all_reduce(AVG) + barriers ...... utils/metrics.py:6-8, utils/dist.py:69-91,
     experiment.py:314-370
 """
+import contextlib
 import math
 import os
 
 import torch
 import torch.distributed as dist
+
+
+@contextlib.contextmanager
+def _eval_mode(model):
+    """The reference's eval / inference entry points call `self.model.eval()` first (experiment.py:316): Dropout (the
+    only mode-dependent layer of the UNet) must be off while sampling.  The previous mode is restored on exit, so a
+    Trainer that finds the model in training mode keeps skipping its (slow) Module.train() walk."""
+    was = model.training
+    if was:
+        model.eval()
+    try:
+        yield
+    finally:
+        if was:
+            model.train()
 
 
 # ---- sampler drivers ---------------------------------------------------------------------------
@@ -27,7 +43,9 @@ def extrapolate(model, cond, angle, max_views=6, view_count=None, generator=None
     B = cond.shape[0]
     if view_count is None:
         view_count = torch.randint(max_views + 1, 24, (B,), generator=generator)
-    _, ret, logit_arr, weight_arr, _ = model(y_cond=cond, view_count=view_count, angle=angle, generate=True, **inject)
+    with _eval_mode(model):
+        _, ret, logit_arr, weight_arr, _ = model(y_cond=cond, view_count=view_count, angle=angle, generate=True,
+                                                 **inject)
     return ret.clamp(0, 1), logit_arr, weight_arr, view_count
 
 
@@ -39,13 +57,15 @@ def autoregressive_rollout(model, first_view, steps=24, y_t=None, z_seq=None):
     cond = first_view[:, None].contiguous()
     B = cond.shape[0]
     out = []
-    for count in range(1, steps + 1):
-        view_count = torch.full((B,), count)
-        angle = torch.full((B, 1), 2 * math.pi / 24 * count, device=cond.device)
-        inject = dict(y_t=None if y_t is None else y_t[count - 1], z_seq=None if z_seq is None else z_seq[count - 1])
-        *_, sample = model(y_cond=cond, view_count=view_count, angle=angle, generate=True, **inject)
-        cond = torch.cat((cond, sample[:, None]), dim=1)
-        out.append(sample)
+    with _eval_mode(model):
+        for count in range(1, steps + 1):
+            view_count = torch.full((B,), count)
+            angle = torch.full((B, 1), 2 * math.pi / 24 * count, device=cond.device)
+            inject = dict(y_t=None if y_t is None else y_t[count - 1],
+                          z_seq=None if z_seq is None else z_seq[count - 1])
+            *_, sample = model(y_cond=cond, view_count=view_count, angle=angle, generate=True, **inject)
+            cond = torch.cat((cond, sample[:, None]), dim=1)
+            out.append(sample)
     return torch.stack(out, dim=1)
 
 
@@ -62,8 +82,9 @@ def orbit_frames(model, all_views, n=24, **inject):
     target = torch.repeat_interleave(all_views, n // 24, dim=0)
     cond_views = torch.stack([all_views[::4]] * target.shape[0], dim=0).contiguous()
     view_count = torch.full((target.shape[0],), cond_views.shape[1])
-    _, ret, logit_arr, weight_arr, _ = model(y_cond=cond_views, view_count=view_count, angle=angles, generate=True,
-                                             **inject)
+    with _eval_mode(model):
+        _, ret, logit_arr, weight_arr, _ = model(y_cond=cond_views, view_count=view_count, angle=angles, generate=True,
+                                                 **inject)
     return ret.clamp(0, 1), logit_arr, weight_arr, cond_views, angles
 
 
@@ -127,13 +148,14 @@ def evaluate(model, batches, max_views=6, generator=None, extra_metrics=None, **
     cond (B,>=max_views,3,H,W), angle (B,1) and optionally view_count.  extra_metrics: {name: fn(generated, target) ->
     (B,)} for third-party metrics (the reference's SSIM).  Returns the reduced dict of 0-d tensors."""
     gen, gt = [], []
-    for b in batches:
-        vc = b.get("view_count")
-        if vc is None:
-            vc = torch.randint(1, max_views + 1, (b["target"].shape[0],), generator=generator)
-        *_, samples = model(y_cond=b["cond"], view_count=vc, angle=b["angle"], generate=True, **inject)
-        gen.append(samples)
-        gt.append(b["target"])
+    with _eval_mode(model):                        # Experiment.eval: self.model.eval() (experiment.py:316)
+        for b in batches:
+            vc = b.get("view_count")
+            if vc is None:
+                vc = torch.randint(1, max_views + 1, (b["target"].shape[0],), generator=generator)
+            *_, samples = model(y_cond=b["cond"], view_count=vc, angle=b["angle"], generate=True, **inject)
+            gen.append(samples)
+            gt.append(b["target"])
     _barrier()
     metrics = {"psnr": compute_psnr}
     metrics.update(extra_metrics or {})

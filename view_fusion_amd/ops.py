@@ -64,15 +64,26 @@ def _launch(kind, flops, name, *args, tag=None, nbytes=0.0):
 # ---------------------------------------------------------------------------------------------
 # split-K / slab workspace: one buffer per (device, stream) -- launches on one stream are ordered, so consecutive
 # kernels may reuse it; two streams (two models driven concurrently) get separate buffers.  Grown on demand.
+# Bounded: at most _WS_MAX (device, stream) entries, least recently used evicted (generate() makes a side stream per
+# graph warm-up).  A buffer allocated WHILE a stream is capturing lives in that graph's private pool: it is handed to
+# the capture but never cached, so no later capture or eager launch can pick up memory owned by another graph.
 _ws = {}
+_WS_MAX = 4
 
 
 def _workspace(device, nfloats):
     key = (device, _raw_stream())
-    buf = _ws.get(key)
+    buf = _ws.pop(key, None)
     if buf is None or buf.numel() < nfloats:
-        buf = torch.empty(int(nfloats), device=device, dtype=torch.float32)
-        _ws[key] = buf
+        new = torch.empty(int(nfloats), device=device, dtype=torch.float32)
+        if torch.cuda.is_current_stream_capturing():
+            if buf is not None:
+                _ws[key] = buf
+            return new
+        buf = new
+    _ws[key] = buf                                   # (re-)inserted last = most recently used
+    while len(_ws) > _WS_MAX:
+        _ws.pop(next(iter(_ws)))
     return buf
 
 
@@ -422,13 +433,15 @@ class _Conv2dFn(torch.autograd.Function):
         H, W = (Hi // 2, Wi // 2) if m == 1 else ((Hi * 2, Wi * 2) if m == 2 else (Hi, Wi))
         y = torch.empty(S, Cout, H, W, device=x.device, dtype=torch.float32)
         flops = 2.0 * S * Cout * Cin * KS * KS * H * W
+        # algorithmic HBM bytes: input, output (+ residual) and the weights, each once
+        nb = 4.0 * (x.numel() + y.numel() + weight.numel() + (residual.numel() if residual is not None else 0))
         wino = use_winograd(S, Cin, Cout, H, W, KS, m)
         if wino:
             wf, wb = _packed_wino(layer, force=training)
             ws, nws = _wino_ws(x.device, S, Cin, Cout, H, W)
             _launch("conv_fwd", flops, "vf_wino_conv_fwd", _ptr(x), _ptr(wf), _ptr(bias), _ptr(view_bias),
                     _ptr(residual), _ptr(y), _ptr(ws), nws, S, Cin, Cout, H, W, m, _stream(),
-                    tag=(Cin, Cout, H, KS, m))
+                    tag=(Cin, Cout, H, KS, m), nbytes=nb)
         else:
             wf, wb = _packed(layer, force=training)
             ws, nws = _conv_ws(x.device, S, Cin, Cout, H, W, KS)
@@ -456,7 +469,8 @@ class _Conv2dFn(torch.autograd.Function):
             dfull = torch.empty(S, Cin, H, W, device=x.device, dtype=torch.float32)
             ws, nws = _wino_ws(x.device, S, Cout, Cin, H, W)
             _launch("conv_dgrad", ctx.flops, "vf_wino_conv_fwd", _ptr(dy), _ptr(ctx.wb), None, None, None,
-                    _ptr(dfull), _ptr(ws), nws, S, Cout, Cin, H, W, 0, st, tag=ctx.tag)
+                    _ptr(dfull), _ptr(ws), nws, S, Cout, Cin, H, W, 0, st, tag=ctx.tag,
+                    nbytes=4.0 * (dy.numel() + dfull.numel() + ctx.pw.numel()))
             if m == 2:                                 # upsample + conv: 2x2 sum-pool back to the source size
                 dx = torch.empty_like(x)
                 _lib.call("vf_sumpool2", _ptr(dfull), _ptr(dx), dx.numel(), Wi, st)
@@ -874,7 +888,7 @@ def view_offsets(view_count, device):
     """
     if torch.is_tensor(view_count) and view_count.is_cuda:
         for ent in _VC_CACHE:
-            if ent[0] is view_count and ent[1] == view_count._version:
+            if ent[0] is view_count and ent[1] == view_count._version and ent[2][0].device == device:
                 return ent[2]
         vc = view_count.detach().cpu().tolist()
     elif torch.is_tensor(view_count):

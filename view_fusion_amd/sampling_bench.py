@@ -4,7 +4,9 @@ import time
 
 import torch
 
-from . import train
+from . import _lib, train
+
+LAST_LAUNCHES_PER_STEP = None      # C-ABI launcher calls of one reverse step of the last timed configuration
 
 
 def time_sampler(batch, views, steps=None, use_graph=True, device="cuda:0", model=None):
@@ -28,7 +30,15 @@ def time_sampler(batch, views, steps=None, use_graph=True, device="cuda:0", mode
 
 
 def _run(model, b, batch, views, steps, full_T, use_graph):
+    global LAST_LAUNCHES_PER_STEP
     sample_num = min(8, steps - 1)
+    with torch.no_grad():                      # one eager reverse step, counted (also packs the weights)
+        y = torch.randn_like(b["y_0"])
+        t = torch.full((batch,), steps - 1, device=y.device, dtype=torch.long)
+        model.p_sample(y, b["y_cond"], b["view_count"], b["angle"], t)
+        c0 = _lib.N_CALLS
+        model.p_sample(y, b["y_cond"], b["view_count"], b["angle"], t)
+        LAST_LAUNCHES_PER_STEP = _lib.N_CALLS - c0
     model.generate(b["y_cond"], b["view_count"], b["angle"], sample_num=sample_num, use_graph=use_graph)  # warm-up
     torch.cuda.synchronize()
     t0 = time.perf_counter()

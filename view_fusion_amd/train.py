@@ -102,12 +102,21 @@ class Trainer:
         self.model = model
         self.arena = None
         if world > 1 and os.environ.get("VF_REDUCER", "arena") != "ddp":
-            self.arena = reducer.ACTIVE = reducer.GradArena(model, world)
+            try:
+                self.arena = reducer.ACTIVE = reducer.GradArena(model, world)
+            except Exception as e:       # first collective of the job (parameter broadcast) or hook set-up failed
+                reducer.ACTIVE = None
+                raise SystemExit(
+                    f"[view_fusion_amd] gradient-arena set-up failed at world={world}: {type(e).__name__}: {e}\n"
+                    "  -> relaunch (a fresh process group, not a re-exec) with VF_REDUCER=ddp to use torch's "
+                    "DistributedDataParallel for the gradient exchange; see tools/scale_run.md") from e
         elif world > 1:
             kw = dict(broadcast_buffers=False, gradient_as_bucket_view=True, bucket_cap_mb=bucket_cap_mb)
             if next(model.parameters()).is_cuda:
                 kw.update(device_ids=[local_rank], output_device=local_rank)
             self.model = DistributedDataParallel(model, **kw)
+        # modules whose behaviour depends on train/eval mode (see step()): the blocks that carry a Dropout
+        self._mode_modules = [m for m in model.modules() if getattr(m, "dropout", 0) and hasattr(m, "_drop")]
         self.sched = LrScheduler(peak_lr=1e-4, peak_it=lr_warmup, decay_it=decay_it, decay_rate=0.16)
         params = list(model.parameters())
         if params[0].is_cuda:       # one multi-tensor HIP launch per step
@@ -123,7 +132,10 @@ class Trainer:
         lr = self.sched.get_cur_lr(self.it)
         for gparam in self.opt.param_groups:
             gparam["lr"] = lr
-        if not self.model.training:        # Module.train() walks all ~1400 submodules (2 ms): only when the mode changes
+        # The reference calls model.train() every iteration (experiment.py:286); Module.train() walks all ~1400
+        # submodules (2 ms), so it runs only when some module that HAS a mode-dependent layer is not in training mode.
+        # The residual blocks' Dropout is the only such layer; the root flag alone would miss `vf.denoise_fn.eval()`.
+        if not self.model.training or any(not m.training for m in self._mode_modules):
             self.model.train()
         self.opt.zero_grad()
         loss = self.model(y_0=batch["y_0"], y_cond=batch["y_cond"], view_count=batch["view_count"],
