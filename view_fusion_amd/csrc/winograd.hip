@@ -464,7 +464,7 @@ int launch_wino_wgrad(WinoWgradArgs a, float* dw, float* db, float* db2, size_t 
 extern "C" {
 
 // workspace floats for vf_wino_wgrad at this shape (slabs of transformed partial gradients)
-long vf_wino_wgrad_ws_floats(int S, int Cin, int Cout, int H, int W) {
+long vf_wino22_wgrad_ws_floats(int S, int Cin, int Cout, int H, int W) {
     const long slab = 16L * rup(Cout, 64) * rup(Cin, 32);
     const int nco = rup(Cout, 64) / 64, nci = (rup(Cin, 32) + 63) / 64;
     long z = 256 / (nco * nci);
@@ -474,18 +474,14 @@ long vf_wino_wgrad_ws_floats(int S, int Cin, int Cout, int H, int W) {
     return (z + 1) * slab + 256L * rup(Cout, 64);
 }
 
-int vf_wino_wgrad_supported(int H, int W, int mode) {
-    return H == W && (W == 8 || W == 16 || W == 32 || W == 64) && (mode == 0 || mode == 2);
-}
 
 // dw[Cout][Cin][3][3] of a stride-1 3x3 conv (H = W = output size in {8, 16, 32, 64}; mode 2: x is stored at half
 // size and nearest-upsampled on read) via Winograd F(2x2,3x3)
 // db (or NULL): also the bias gradient sum_{s,p} dY[s][co][p] -- the kernel reads every dY tile anyway;
 // db2 (or NULL): a second [Cout] destination for the same sums (the residual 1x1 conv shares this dY)
-int vf_wino_wgrad(const float* x, const float* dy, float* dw, float* db, float* db2, float* ws, long ws_floats, int S,
+int vf_wino22_wgrad(const float* x, const float* dy, float* dw, float* db, float* db2, float* ws, long ws_floats, int S,
                   int Cin, int Cout, int H, int W, int mode, void* stream) {
     if (S <= 0) return 0;
-    if (!vf_wino_wgrad_supported(H, W, mode)) return (int)hipErrorInvalidValue;
     WinoWgradArgs a;
     a.x = x; a.dy = dy; a.ws = ws; a.S = S; a.Cin = Cin; a.Cout = Cout;
     a.CoutP = rup(Cout, 64); a.CinQ = rup(Cin, 32);
