@@ -85,7 +85,6 @@ __global__ __launch_bounds__(512, 2) void wino44_wgrad_kernel(W44Args a) {
     constexpr int XCS = NR * GXW;                           // 144 (= 4 mod 16 units of 16 bytes: conflict-free) / 200 (8x8 maps: 2-way)
     constexpr int XSZ = CI44 * XCS;
     static_assert((2 * MSZ + 2 * VSZ + 2 * XSZ) * 4 <= 160 * 1024, "LDS budget");
-    static_assert(NX4 <= 3 * 256 && NHS <= 2 * 256, "staging duty per thread");
 
     __shared__ __attribute__((aligned(16))) float lds[2 * MSZ + 2 * VSZ + 2 * XSZ];
     float* const Ml = lds;                                  // dM[2][slice][co][tile]
@@ -113,48 +112,47 @@ __global__ __launch_bounds__(512, 2) void wino44_wgrad_kernel(W44Args a) {
 #define VF_LANES(M) __builtin_amdgcn_inverse_ballot_w64(M)
 #define VF_G1 __attribute__((address_space(1)))
 
-    // ---- dM role (tid < 256): (co, tile) = (tid >> 2, tid & 3)
+    // ---- dM role (tid < 256): (co, tile) = (tid >> 2, tid & 3).  Channels beyond Cout / Cin are CLAMPED, not masked:
+    // they load valid (duplicate) data whose products land in rows / columns of dU that nobody reads.
     const int tch = (tid & 255) >> 2, tt = tid & 3;
     const int ttr = tt / TPR, ttc = tt % TPR;
     const int tslot = (((tt >> 1) ^ ((tch >> 4) & 1)) << 1) | (tt & 1);          // swizzled tile slot
-    const bool dyok = is_dm && co0 + tch < a.Cout;
-    unsigned dyoffb = 4u * (unsigned)(tch * (H * W) + 4 * ttr * W + 4 * ttc);
-    const mask_t m_dy = __builtin_amdgcn_ballot_w64(dyok);
-    // raw x staging duty of the same threads: float4 e = tid + 256 i -> (ci, row, q); halo scalar e -> (ci, row, side)
+    unsigned dyoffb = 4u * (unsigned)((min(co0 + tch, a.Cout - 1) - co0) * (H * W) + 4 * ttr * W + 4 * ttc);
+    // raw x staging duty of the same waves.  A wave-slot (wave w, slot i) moves ONE strip row of 16 channels (TR = 1: 64
+    // lanes = 16 ci x 4 float4) or of all 32 channels (8x8 maps: 32 ci x 2 float4): c = 4 i + w -> (row, channel half).
+    // The row is wave-uniform, so "this row lies outside the image" is a scalar branch -- no lane masks, no mask
+    // arithmetic in the chunk loop.  Halo scalars: slot c = 4 i + w < NR holds row c: 64 lanes = 32 ci x {left, right}.
+    constexpr int NXS = TR == 1 ? 12 : 10;                 // row slots of a strip
+    int xrow[3];                                           // (uniform) strip row of slot i, or -1: no duty
     unsigned xoffb[3];
     int xsl[3];
-    mask_t m_x[3], m_xtop[3], m_xbot[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        const int e = (tid & 255) + 256 * i;
-        const int ci = e / (NR * QPR), row = (e / QPR) % NR, q = e % QPR;
-        const bool ok = is_dm && e < NX4 && ci0 + ci < a.Cin;
+        const int c = 4 * i + (wid & 3);
+        const int row = c % NR, chalf = c / NR;
+        const int ci = TR == 1 ? chalf * 16 + (lane >> 2) : (lane >> 1), q = TR == 1 ? (lane & 3) : (lane & 1);
+        const int cic = min(ci0 + ci, a.Cin - 1) - ci0;
+        xrow[i] = c < NXS ? row : -1;
         // source row gy = 4p - 1 + row (MODE 2: stored row (gy >> 1) = 2p - 1 + ((row + 1) >> 1)); the chunk-dependent
         // part, including the "- 1", lives in the uniform base
-        xoffb[i] = 4u * (unsigned)(MODE == 2 ? ci * (SH * SW) + ((row + 1) >> 1) * SW + 2 * q : ci * (H * W) + row * W + 4 * q);
+        xoffb[i] = 4u * (unsigned)(MODE == 2 ? cic * (SH * SW) + ((row + 1) >> 1) * SW + 2 * q : cic * (H * W) + row * W + 4 * q);
         xsl[i] = ci * XCS + row * GXW + 5 + 4 * q;
-        m_x[i] = __builtin_amdgcn_ballot_w64(ok);
-        m_xtop[i] = __builtin_amdgcn_ballot_w64(ok && row == 0);
-        m_xbot[i] = __builtin_amdgcn_ballot_w64(ok && row == NR - 1);
     }
+    int hrow[2];
     unsigned hoffb[2];
     int hsl[2];
-    mask_t m_h[2], m_htop[2], m_hbot[2], m_hleft[2], m_hright[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const int e = (tid & 255) + 256 * i;
-        const int hci = e / (NR * 2), hrow = (e >> 1) % NR, hside = e & 1;
-        const bool ok = HALO && is_dm && e < NHS && ci0 + hci < a.Cin;
+        const int c = 4 * i + (wid & 3);
+        const int hci = lane >> 1, hside = lane & 1;
+        const int cic = min(ci0 + hci, a.Cin - 1) - ci0;
+        hrow[i] = HALO && c < NR ? c : -1;
         // halo pixel gx = 4 q0 - 1 (left) or 4 q0 + PXW (right); the "4 q0 - 1" is in the base
-        hoffb[i] = 4u * (unsigned)(MODE == 2 ? hci * (SH * SW) + ((hrow + 1) >> 1) * SW + (hside ? PXW / 2 + 1 : 0)
-                                             : hci * (H * W) + hrow * W + (hside ? PXW + 1 : 0));
-        hsl[i] = hci * XCS + hrow * GXW + (hside ? 5 + PXW : 4);
-        m_h[i] = __builtin_amdgcn_ballot_w64(ok);
-        m_htop[i] = __builtin_amdgcn_ballot_w64(ok && hrow == 0);
-        m_hbot[i] = __builtin_amdgcn_ballot_w64(ok && hrow == NR - 1);
-        m_hleft[i] = __builtin_amdgcn_ballot_w64(ok && !hside);
-        m_hright[i] = __builtin_amdgcn_ballot_w64(ok && hside);
+        hoffb[i] = 4u * (unsigned)(MODE == 2 ? cic * (SH * SW) + ((c + 1) >> 1) * SW + (hside ? PXW / 2 + 1 : 0)
+                                             : cic * (H * W) + c * W + (hside ? PXW + 1 : 0));
+        hsl[i] = hci * XCS + c * GXW + (hside ? 5 + PXW : 4);
     }
+    constexpr mask_t EVEN_LANES = 0x5555555555555555ull, ODD_LANES = 0xAAAAAAAAAAAAAAAAull;   // left / right halo lanes
 
     // ---- V role (tid >= 256): 128 windows x 2 halves; wave (4 + 2 vhalf + j): windows (ci, tile) = (16 j + lane >> 2, lane & 3)
     const int vci = ((wid & 1) << 4) + (lane >> 2), vtt = lane & 3;
@@ -189,26 +187,23 @@ __global__ __launch_bounds__(512, 2) void wino44_wgrad_kernel(W44Args a) {
         return k;
     };
     // (the opaque copies keep base and offset apart until instruction selection: SGPR base + zero-extended VGPR offset)
+#define VF_ROW_OUT(K, ROW) (((K).top && (ROW) == 0) || ((K).bot && (ROW) == NR - 1))      /* scalar */
 #define VF_XLOAD1(K, I, R)                                                                                \
-    {                                                                                                     \
-        const mask_t edge_ = ((K).top ? m_xtop[I] : 0ull) | ((K).bot ? m_xbot[I] : 0ull);                 \
-        if (VF_LANES(m_x[I] & ~edge_)) {                                                                  \
-            const char* b_ = (K).xb;                                                                      \
-            unsigned& o_ = xoffb[I];                                                                      \
-            asm("" : "+s"(b_), "+v"(o_));                                                                 \
-            if (MODE == 2) {                                                                              \
-                const f32x2 h_ = *(const VF_G1 f32x2*)((const VF_G1 char*)b_ + o_);                       \
-                R = (f32x4){h_.x, h_.x, h_.y, h_.y};                                                      \
-            } else {                                                                                      \
-                R = *(const VF_G1 f32x4*)((const VF_G1 char*)b_ + o_);                                    \
-            }                                                                                             \
+    if (xrow[I] >= 0 && !VF_ROW_OUT(K, xrow[I])) {                                                        \
+        const char* b_ = (K).xb;                                                                          \
+        unsigned& o_ = xoffb[I];                                                                          \
+        asm("" : "+s"(b_), "+v"(o_));                                                                     \
+        if (MODE == 2) {                                                                                  \
+            const f32x2 h_ = *(const VF_G1 f32x2*)((const VF_G1 char*)b_ + o_);                           \
+            R = (f32x4){h_.x, h_.x, h_.y, h_.y};                                                          \
+        } else {                                                                                          \
+            R = *(const VF_G1 f32x4*)((const VF_G1 char*)b_ + o_);                                        \
         }                                                                                                 \
     }
+    // (a left / right halo pixel at the image border is never requested: it may lie outside the tensor)
 #define VF_HLOAD1(K, I, R)                                                                                \
-    if (HALO) {                                                                                           \
-        const mask_t edge_ = ((K).top ? m_htop[I] : 0ull) | ((K).bot ? m_hbot[I] : 0ull) |                \
-                             ((K).left ? m_hleft[I] : 0ull) | ((K).right ? m_hright[I] : 0ull);           \
-        if (VF_LANES(m_h[I] & ~edge_)) {                                                                  \
+    if (HALO && hrow[I] >= 0 && !VF_ROW_OUT(K, hrow[I])) {                                                \
+        if (VF_LANES((K).left ? ODD_LANES : ((K).right ? EVEN_LANES : ~0ull))) {                          \
             const char* b_ = (K).xb - 4;                                                                  \
             unsigned& o_ = hoffb[I];                                                                      \
             asm("" : "+s"(b_), "+v"(o_));                                                                 \
@@ -216,29 +211,40 @@ __global__ __launch_bounds__(512, 2) void wino44_wgrad_kernel(W44Args a) {
         }                                                                                                 \
     }
     auto load_x = [&](const Chunk& k) {
+#ifdef VF_ABL_NOGLOAD
+        return;
+#endif
+#ifndef VF_ABL_NOXLOAD
         VF_XLOAD1(k, 0, xr0);
         VF_XLOAD1(k, 1, xr1);
         VF_XLOAD1(k, 2, xr2);
+#endif
+#ifndef VF_ABL_NOHALO
         VF_HLOAD1(k, 0, xh0);
         VF_HLOAD1(k, 1, xh1);
+#endif
     };
     // strip pixels sit at odd dword offsets (idx 5 + 4q): four ds_write_b32 (as two ds_write2_b32) per float4 -- same LDS
     // cost as one ds_write_b128 (MI355X_MICROARCH.md, LDS table)
 #define VF_XSTORE1(K, BUF, I, R)                                                                          \
-    {                                                                                                     \
-        const mask_t edge_ = ((K).top ? m_xtop[I] : 0ull) | ((K).bot ? m_xbot[I] : 0ull);                 \
+    if (xrow[I] >= 0) {                                                                                   \
         float* d_ = Xl + (BUF) * XSZ + xsl[I];                                                            \
-        if (VF_LANES(edge_)) { asm volatile(""); d_[0] = 0.f; d_[1] = 0.f; d_[2] = 0.f; d_[3] = 0.f; }    \
-        if (VF_LANES(m_x[I] & ~edge_)) { d_[0] = R.x; d_[1] = R.y; d_[2] = R.z; d_[3] = R.w; }            \
+        if (VF_ROW_OUT(K, xrow[I])) { d_[0] = 0.f; d_[1] = 0.f; d_[2] = 0.f; d_[3] = 0.f; }               \
+        else { d_[0] = R.x; d_[1] = R.y; d_[2] = R.z; d_[3] = R.w; }                                      \
     }
 #define VF_HSTORE1(K, BUF, I, R)                                                                          \
-    if (HALO) {                                                                                           \
-        const mask_t edge_ = ((K).top ? m_htop[I] : 0ull) | ((K).bot ? m_hbot[I] : 0ull) |                \
-                             ((K).left ? m_hleft[I] : 0ull) | ((K).right ? m_hright[I] : 0ull);           \
-        if (VF_LANES(edge_)) { asm volatile(""); Xl[(BUF) * XSZ + hsl[I]] = 0.f; }                        \
-        if (VF_LANES(m_h[I] & ~edge_)) Xl[(BUF) * XSZ + hsl[I]] = R;                                      \
+    if (HALO && hrow[I] >= 0) {                                                                           \
+        float* d_ = Xl + (BUF) * XSZ + hsl[I];                                                            \
+        if (VF_ROW_OUT(K, hrow[I])) d_[0] = 0.f;                                                          \
+        else {                                                                                            \
+            d_[0] = R;                                                                                    \
+            if (VF_LANES((K).left ? EVEN_LANES : ((K).right ? ODD_LANES : 0ull))) d_[0] = 0.f;            \
+        }                                                                                                 \
     }
     auto store_x = [&](const Chunk& k, int buf) {      // k: the chunk the registers hold
+#ifdef VF_ABL_NOSTRIP
+        return;
+#endif
         VF_XSTORE1(k, buf, 0, xr0);
         VF_XSTORE1(k, buf, 1, xr1);
         VF_XSTORE1(k, buf, 2, xr2);
@@ -246,7 +252,10 @@ __global__ __launch_bounds__(512, 2) void wino44_wgrad_kernel(W44Args a) {
         VF_HSTORE1(k, buf, 1, xh1);
     };
     auto load_dy = [&](const Chunk& k) {
-        if (VF_LANES(m_dy)) {
+#ifdef VF_ABL_NOGLOAD
+        return;
+#endif
+        {
             const char* b = k.db;
             unsigned& o = dyoffb;
             asm("" : "+s"(b), "+v"(o));
@@ -283,6 +292,10 @@ __global__ __launch_bounds__(512, 2) void wino44_wgrad_kernel(W44Args a) {
         const f32x2 m12 = pk_lo_pm_hi(eo, eo);
         const f32x2 m34 = pk_lo_pm_2hi(pk_fmak<4>(vB[i], vA[i]));
         if (i == 1 && count) bias1 += m12.x;
+#ifdef VF_ABL_NOLDSW
+        asm volatile("" :: "v"(m12), "v"(m34));
+        return;
+#endif
         mo[(6 * i + 0) * (CO44 * GT44)] = vA[i].x;
         mo[(6 * i + 1) * (CO44 * GT44)] = m12.x;
         mo[(6 * i + 2) * (CO44 * GT44)] = m12.y;
@@ -340,6 +353,10 @@ __global__ __launch_bounds__(512, 2) void wino44_wgrad_kernel(W44Args a) {
         const f32x2 c12 = pk_lo_pm_hi(P2, Q);
         const f32x2 E = pk_sub(p45, p23), F = pk_sub(p23, p01);
         const f32x2 c34 = pk_xlo_pm_2yhi(E, F);
+#ifdef VF_ABL_NOLDSW
+        asm volatile("" :: "v"(c05), "v"(c12), "v"(c34));
+        return;
+#endif
         vo[0 * (CI44 * GT44)] = c05.x;
         vo[1 * (CI44 * GT44)] = c12.x;
         vo[2 * (CI44 * GT44)] = c12.y;
@@ -395,6 +412,18 @@ __global__ __launch_bounds__(512, 2) void wino44_wgrad_kernel(W44Args a) {
         AD = *reinterpret_cast<const f32x2*>(Ml + (PAR_) * MSZ + aoff + VF_SL(K_) * (CO44 * GT44));       \
         BD = *reinterpret_cast<const f32x2*>(Vl + (PAR_) * VSZ + boff + VF_SL(K_) * (CI44 * GT44));       \
     }
+    // timing ablations (diagnostic builds only; results are wrong): -DVF_ABL_NOSIDE drops the side work of the chunk
+    // loop, -DVF_ABL_NOBAR its barrier
+#ifdef VF_ABL_NOSIDE
+#define VF_ABL_SIDE(X)
+#else
+#define VF_ABL_SIDE(X) X
+#endif
+#ifdef VF_ABL_NOBAR
+#define VF_ABL_BARRIER()
+#else
+#define VF_ABL_BARRIER() __syncthreads()
+#endif
 #define VF_W44_CHUNK(C, PAR, FIRST, SIDE)                                                                 \
     {                                                                                                     \
         const Chunk kn2 = chunk_at(min((C) + 2, clast)), kn3 = chunk_at(min((C) + 3, clast));             \
@@ -404,10 +433,10 @@ __global__ __launch_bounds__(512, 2) void wino44_wgrad_kernel(W44Args a) {
             if (k < 6) { VF_FRAG(a1, b1, PAR, k + 1); }                                                   \
             else if (k == 6) { VF_FRAG(a1, b1, PAR, 7); VF_FRAG(a2, b2, PAR, 8); }                        \
             else if (k == 8) { VF_FRAG(a1, b1, (PAR) ^ 1, 0); }                                           \
-            SIDE(C, PAR, k, 0, kn2, kn3);                                                                 \
+            VF_ABL_SIDE(SIDE(C, PAR, k, 0, kn2, kn3));                                                    \
             VF_MF(k, a_cur.y, b_cur.y, false);                                                            \
-            SIDE(C, PAR, k, 1, kn2, kn3);                                                                 \
-            if (k == 6) __syncthreads();                                                                  \
+            VF_ABL_SIDE(SIDE(C, PAR, k, 1, kn2, kn3));                                                    \
+            if (k == 6) VF_ABL_BARRIER();                                                                 \
             if (k == 7) { a_cur = a2; b_cur = b2; } else { a_cur = a1; b_cur = b1; }                      \
         }                                                                                                 \
     }
