@@ -40,7 +40,7 @@ PEAK_HBM_GBS = 8000.0
 
 # Algorithmic constants of one stacked view through the small UNet (measured on the reference):
 GFLOP_PER_VIEW_TRAIN = 62.98           # 3 x 20.994 forward (conv3x3 19.19, conv1x1 1.45, attention 0.36)
-GFLOP_3X3_S1_PER_VIEW_FWD = 19.1905 - 0.19     # stride-1 3x3 layers: what the Winograd kernels run (2.25x fewer multiplies)
+GFLOP_3X3_S1_PER_VIEW_FWD = 19.1905 - 0.19     # stride-1 3x3 layers: what the Winograd kernels run
 HBM_MB_PER_VIEW_TRAIN = 3 * 141.7      # ideal-fusion traffic
 
 
@@ -169,7 +169,7 @@ FAMILIES = {
     "wino_conv": ("wino_conv_kernel<LOGW,MODE> (nested Winograd F(2,3)xF(4,3), + tail fixup): forward + dgrad of every "
                   "stride-1 3x3 layer", "mfma"),
     "direct_conv": ("conv_mfma_kernel<KS,LOGW,MODE,NPT>: forward + dgrad of the 1x1 / stride-2 layers", "mfma"),
-    "wino_wgrad": ("wino_wgrad_kernel (+ slab sum, finish): weight gradient of the stride-1 3x3 layers", "mfma"),
+    "wino_wgrad": ("wino44_wgrad_kernel (Winograd F(4x4,3x3), + slab-sum launch): weight gradient of the stride-1 3x3 layers", "mfma"),
     "direct_wgrad": ("conv1x1_wgrad_kernel / conv_wgrad_kernel (+ reduce): weight gradient of the 1x1 / stride-2 layers", "mfma"),
     "attn_fwd": ("attn_fwd_kh_kernel / attn_fwd_split_kernel", "mfma"),
     "attn_bwd": ("attention backward", "mfma"),
@@ -180,8 +180,9 @@ FAMILIES = {
 
 
 # direct-convolution multiplies per multiply the Winograd kernels execute: forward / dgrad run the nested
-# F(2,3) x F(4,3) (24 products per 2x4 outputs x 9 taps = 72 direct ones), the weight gradient F(2x2,3x3) (16 per 36)
-WINO_REDUCTION = {"wino_conv": 3.0, "wino_wgrad": 2.25}
+# F(2,3) x F(4,3) (24 products per 2x4 outputs x 9 taps = 72 direct ones), the weight gradient F(4x4,3x3) (36 products
+# per 4x4 outputs x 9 taps = 144 direct ones)
+WINO_REDUCTION = {"wino_conv": 3.0, "wino_wgrad": 4.0}
 
 
 def _family(kind, name):
@@ -229,7 +230,7 @@ def roofline(trainer, batch, S, ms_step, steps=2):
     f, s, n, nb_head = agg[head]
     executed = f / WINO_REDUCTION.get(head, 1.0)
     # floor of the whole step: every conv at the fp32 MFMA peak, the stride-1 3x3 layers at Winograd's multiply count
-    # (forward + dgrad: nested F(2,3)xF(4,3); weight gradient: F(2x2,3x3))
+    # (forward + dgrad: nested F(2,3)xF(4,3); weight gradient: F(4x4,3x3))
     step_tflop_direct = GFLOP_PER_VIEW_TRAIN * S / 1e3
     g3 = GFLOP_3X3_S1_PER_VIEW_FWD * S / 1e3
     step_tflop_wino = step_tflop_direct - 2 * g3 * (1 - 1 / WINO_REDUCTION["wino_conv"]) - g3 * (1 - 1 / WINO_REDUCTION["wino_wgrad"])

@@ -161,9 +161,13 @@ __global__ __launch_bounds__(512, 2) void wino44_wgrad_kernel(W44Args a) {
     const int wpo = vci * XCS + (4 * vtr + vhalf) * GXW + 4 * vtc + 4;           // window origin: first row this half reads
     const int vwo = vci * GT44 + vslot + (18 * vhalf) * (CI44 * GT44);           // V slot of this half's first slice
 
-    f32x4 xr0 = (f32x4){0.f, 0.f, 0.f, 0.f}, xr1 = xr0, xr2 = xr0;
-    float xh0 = 0.f, xh1 = 0.f;
-    f32x4 dy0 = xr0, dy1 = xr0, dy2 = xr0, dy3 = xr0;
+    // raw x rows and dY tiles in flight, one chunk deep (a second register set for either, i.e. two chunks of lead,
+    // was measured: no gain -- the loads are not late).  (Named registers + macros: arrays behind lambdas end up in
+    // scratch memory.)
+    const f32x4 z4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 xr0A = z4, xr1A = z4, xr2A = z4;
+    float xh0A = 0.f, xh1A = 0.f;
+    f32x4 dy0 = z4, dy1 = z4, dy2 = z4, dy3 = z4;
 
     struct Chunk {                                     // uniform: position of a chunk and its edge flags
         const char* xb;                                // base of the x loads (one row above / one pixel left of the strip)
@@ -210,20 +214,18 @@ __global__ __launch_bounds__(512, 2) void wino44_wgrad_kernel(W44Args a) {
             R = *(const VF_G1 float*)((const VF_G1 char*)b_ + o_);                                        \
         }                                                                                                 \
     }
-    auto load_x = [&](const Chunk& k) {
 #ifdef VF_ABL_NOGLOAD
-        return;
+#define VF_LOAD_X(K, SET)
+#else
+#define VF_LOAD_X(K, SET)                                                                                 \
+    {                                                                                                     \
+        VF_XLOAD1(K, 0, xr0##SET);                                                                        \
+        VF_XLOAD1(K, 1, xr1##SET);                                                                        \
+        VF_XLOAD1(K, 2, xr2##SET);                                                                        \
+        VF_HLOAD1(K, 0, xh0##SET);                                                                        \
+        VF_HLOAD1(K, 1, xh1##SET);                                                                        \
+    }
 #endif
-#ifndef VF_ABL_NOXLOAD
-        VF_XLOAD1(k, 0, xr0);
-        VF_XLOAD1(k, 1, xr1);
-        VF_XLOAD1(k, 2, xr2);
-#endif
-#ifndef VF_ABL_NOHALO
-        VF_HLOAD1(k, 0, xh0);
-        VF_HLOAD1(k, 1, xh1);
-#endif
-    };
     // strip pixels sit at odd dword offsets (idx 5 + 4q): four ds_write_b32 (as two ds_write2_b32) per float4 -- same LDS
     // cost as one ds_write_b128 (MI355X_MICROARCH.md, LDS table)
 #define VF_XSTORE1(K, BUF, I, R)                                                                          \
@@ -241,16 +243,18 @@ __global__ __launch_bounds__(512, 2) void wino44_wgrad_kernel(W44Args a) {
             if (VF_LANES((K).left ? EVEN_LANES : ((K).right ? ODD_LANES : 0ull))) d_[0] = 0.f;            \
         }                                                                                                 \
     }
-    auto store_x = [&](const Chunk& k, int buf) {      // k: the chunk the registers hold
 #ifdef VF_ABL_NOSTRIP
-        return;
+#define VF_STORE_X(K, BUF, SET)
+#else
+#define VF_STORE_X(K, BUF, SET)                       /* K: the chunk the registers hold */                  \
+    {                                                                                                     \
+        VF_XSTORE1(K, BUF, 0, xr0##SET);                                                                  \
+        VF_XSTORE1(K, BUF, 1, xr1##SET);                                                                  \
+        VF_XSTORE1(K, BUF, 2, xr2##SET);                                                                  \
+        VF_HSTORE1(K, BUF, 0, xh0##SET);                                                                  \
+        VF_HSTORE1(K, BUF, 1, xh1##SET);                                                                  \
+    }
 #endif
-        VF_XSTORE1(k, buf, 0, xr0);
-        VF_XSTORE1(k, buf, 1, xr1);
-        VF_XSTORE1(k, buf, 2, xr2);
-        VF_HSTORE1(k, buf, 0, xh0);
-        VF_HSTORE1(k, buf, 1, xh1);
-    };
     auto load_dy = [&](const Chunk& k) {
 #ifdef VF_ABL_NOGLOAD
         return;
@@ -271,42 +275,41 @@ __global__ __launch_bounds__(512, 2) void wino44_wgrad_kernel(W44Args a) {
     // vertical pass on the two column pairs (16 packed instructions), then per transformed row (c0,c1),(c2,c3):
     //   (e, o) = (c0,c1) + (c2,c3) -> [e + o, e - o];  (e', t) = (c0,c1) + 4 (c2,c3) -> [e' + 2t, e' - 2t]   (4 each)
     float bias1 = 0.f;                                 // sum of this thread's dY tiles = dM[1][1] (bias gradient rides along)
-    f32x2 vA[6], vB[6];                                // transformed rows, column pairs (c0,c1) / (c2,c3)
-    auto dy_vertical = [&]() {                         // consumes the dY registers (free for the next chunk's loads after it)
-        {
-            const f32x2 e = pk_add(dy0.xy, dy2.xy), o = pk_add(dy1.xy, dy3.xy);
-            const f32x2 e4 = pk_fmak<4>(dy2.xy, dy0.xy), t4 = pk_fmak<4>(dy3.xy, dy1.xy);
-            vA[0] = dy0.xy; vA[1] = pk_add(e, o); vA[2] = pk_sub(e, o);
-            vA[3] = pk_fmak<2>(t4, e4); vA[4] = pk_nmul2_add(t4, e4); vA[5] = dy3.xy;
-        }
-        {
-            const f32x2 e = pk_add(dy0.zw, dy2.zw), o = pk_add(dy1.zw, dy3.zw);
-            const f32x2 e4 = pk_fmak<4>(dy2.zw, dy0.zw), t4 = pk_fmak<4>(dy3.zw, dy1.zw);
-            vB[0] = dy0.zw; vB[1] = pk_add(e, o); vB[2] = pk_sub(e, o);
-            vB[3] = pk_fmak<2>(t4, e4); vB[4] = pk_nmul2_add(t4, e4); vB[5] = dy3.zw;
-        }
-    };
-    auto dy_row = [&](int buf, int i, bool count) {    // transformed row i: 4 packed instructions + 6 LDS values
+    // Row groups {0,1,2}, {3,4}, {5} are evaluated straight from the dY registers (the vertical combinations are
+    // recomputed per group instead of kept: 16 live registers less), each row then takes 4 packed instructions + 6 LDS
+    // values.
+    auto dy_out = [&](int buf, int i, f32x2 pa, f32x2 pb, bool count) {      // transformed row i: (c0,c1) = pa, (c2,c3) = pb
         float* mo = Ml + buf * MSZ + tch * GT44 + tslot;
-        const f32x2 eo = pk_add(vA[i], vB[i]);
+        const f32x2 eo = pk_add(pa, pb);
         const f32x2 m12 = pk_lo_pm_hi(eo, eo);
-        const f32x2 m34 = pk_lo_pm_2hi(pk_fmak<4>(vB[i], vA[i]));
+        const f32x2 m34 = pk_lo_pm_2hi(pk_fmak<4>(pb, pa));
         if (i == 1 && count) bias1 += m12.x;
 #ifdef VF_ABL_NOLDSW
         asm volatile("" :: "v"(m12), "v"(m34));
         return;
 #endif
-        mo[(6 * i + 0) * (CO44 * GT44)] = vA[i].x;
+        mo[(6 * i + 0) * (CO44 * GT44)] = pa.x;
         mo[(6 * i + 1) * (CO44 * GT44)] = m12.x;
         mo[(6 * i + 2) * (CO44 * GT44)] = m12.y;
         mo[(6 * i + 3) * (CO44 * GT44)] = m34.x;
         mo[(6 * i + 4) * (CO44 * GT44)] = m34.y;
-        mo[(6 * i + 5) * (CO44 * GT44)] = vB[i].y;
+        mo[(6 * i + 5) * (CO44 * GT44)] = pb.y;
     };
-    auto xform_dy = [&](int buf, bool count) {
-        dy_vertical();
-#pragma unroll
-        for (int i = 0; i < 6; ++i) dy_row(buf, i, count);
+    auto dy_group = [&](int buf, int grp, bool count) {
+        if (grp == 0) {                                // rows 0, 1, 2:  r0,  (r0 + r2) +- (r1 + r3)
+            const f32x2 eA = pk_add(dy0.xy, dy2.xy), oA = pk_add(dy1.xy, dy3.xy);
+            const f32x2 eB = pk_add(dy0.zw, dy2.zw), oB = pk_add(dy1.zw, dy3.zw);
+            dy_out(buf, 0, dy0.xy, dy0.zw, false);
+            dy_out(buf, 1, pk_add(eA, oA), pk_add(eB, oB), count);
+            dy_out(buf, 2, pk_sub(eA, oA), pk_sub(eB, oB), false);
+        } else if (grp == 1) {                         // rows 3, 4:  (r0 + 4 r2) +- 2 (r1 + 4 r3)
+            const f32x2 eA = pk_fmak<4>(dy2.xy, dy0.xy), tA = pk_fmak<4>(dy3.xy, dy1.xy);
+            const f32x2 eB = pk_fmak<4>(dy2.zw, dy0.zw), tB = pk_fmak<4>(dy3.zw, dy1.zw);
+            dy_out(buf, 3, pk_fmak<2>(tA, eA), pk_fmak<2>(tB, eB), false);
+            dy_out(buf, 4, pk_nmul2_add(tA, eA), pk_nmul2_add(tB, eB), false);
+        } else {                                       // row 5:  r3
+            dy_out(buf, 5, dy3.xy, dy3.zw, false);
+        }
     };
 
     // ---- V = B4^T d B4,  B4^T = [[4,0,-5,0,1,0],[0,-4,-4,1,1,0],[0,4,-4,-1,1,0],[0,-2,-1,2,1,0],[0,2,-1,-2,1,0],[0,4,0,-5,0,1]]
@@ -371,15 +374,17 @@ __global__ __launch_bounds__(512, 2) void wino44_wgrad_kernel(W44Args a) {
     for (int e = tid; e < 2 * XSZ; e += 512) Xl[e] = 0.f;      // channels beyond Cin / unused halo columns stay zero
     if (n > 0) {
         const Chunk k0 = chunk_at(c_begin), k1 = chunk_at(min(c_begin + 1, clast)), k2 = chunk_at(min(c_begin + 2, clast));
-        if (is_dm) { load_x(k0); load_dy(k0); }
+        if (is_dm) { VF_LOAD_X(k0, A); load_dy(k0); }
         __syncthreads();                               // zero fill done
-        if (is_dm) { store_x(k0, 0); load_x(k1); }
+        if (is_dm) { VF_STORE_X(k0, 0, A); VF_LOAD_X(k1, A); }
         __syncthreads();
         if (is_dm) {
-            xform_dy(0, true);
+            dy_group(0, 0, true);
+            dy_group(0, 1, false);
+            dy_group(0, 2, false);
             load_dy(k1);
-            store_x(k1, 1);
-            load_x(k2);
+            VF_STORE_X(k1, 1, A);
+            VF_LOAD_X(k2, A);
         } else {
 #pragma unroll
             for (int j = 0; j < 5; ++j) win_read(0, j);
@@ -424,38 +429,32 @@ __global__ __launch_bounds__(512, 2) void wino44_wgrad_kernel(W44Args a) {
 #else
 #define VF_ABL_BARRIER() __syncthreads()
 #endif
-#define VF_W44_CHUNK(C, PAR, FIRST, SIDE)                                                                 \
+#define VF_W44_CHUNK(C, PAR, FIRST, SIDE, SP)                                                             \
     {                                                                                                     \
-        const Chunk kn2 = chunk_at(min((C) + 2, clast)), kn3 = chunk_at(min((C) + 3, clast));             \
-        f32x2 a1, b1, a2, b2;                                                                             \
+        const Chunk kn2 = chunk_at(min((C) + 2, clast)), kn4 = chunk_at(min((C) + 3, clast));             \
+        f32x2 a2, b2;                 /* fragments run TWO slices ahead of their MFMAs: slice k fetches slice k+2 */ \
         _Pragma("unroll") for (int k = 0; k < 9; ++k) {                                                   \
             VF_MF(k, a_cur.x, b_cur.x, FIRST);                                                            \
-            if (k < 6) { VF_FRAG(a1, b1, PAR, k + 1); }                                                   \
-            else if (k == 6) { VF_FRAG(a1, b1, PAR, 7); VF_FRAG(a2, b2, PAR, 8); }                        \
-            else if (k == 8) { VF_FRAG(a1, b1, (PAR) ^ 1, 0); }                                           \
-            VF_ABL_SIDE(SIDE(C, PAR, k, 0, kn2, kn3));                                                    \
+            if (k < 7) { VF_FRAG(a2, b2, PAR, k + 2); }                                                   \
+            else { VF_FRAG(a2, b2, (PAR) ^ 1, k - 7); }   /* behind the barrier: chunk C+1, slices 0 and 1 */ \
+            VF_ABL_SIDE(SIDE(C, PAR, k, 0, kn2, kn4, SP));                                                  \
             VF_MF(k, a_cur.y, b_cur.y, false);                                                            \
-            VF_ABL_SIDE(SIDE(C, PAR, k, 1, kn2, kn3));                                                    \
+            VF_ABL_SIDE(SIDE(C, PAR, k, 1, kn2, kn4, SP));                                                  \
             if (k == 6) VF_ABL_BARRIER();                                                                 \
-            if (k == 7) { a_cur = a2; b_cur = b2; } else { a_cur = a1; b_cur = b1; }                      \
+            a_cur = a_nx; b_cur = b_nx; a_nx = a2; b_nx = b2;                                             \
         }                                                                                                 \
     }
     // dM waves: raw rows of chunk C+2 -> strip[PAR] in slice 0, transform of dY(C+1) spread over slices 1-4; every
     // global load goes out as soon as its registers are free (x: chunk C+3, dY: chunk C+2)
-#define VF_SIDE_DM(C, PAR, K, J, KN2, KN3)                                                                \
+#define VF_SIDE_DM(C, PAR, K, J, KN2, KN4, SP)                                                            \
     {                                                                                                     \
-        if ((K) == 0 && (J) == 0) store_x(KN2, PAR);                                                      \
-        if ((K) == 0 && (J) == 1) load_x(KN3);             /* registers just freed: a whole chunk of lead */ \
-        if ((K) == 1 && (J) == 0) dy_vertical();                                                          \
-        if ((K) == 1 && (J) == 1) load_dy(KN2);                                                           \
-        if ((K) == 2 && (J) == 0) dy_row((PAR) ^ 1, 0, false);                                            \
-        if ((K) == 2 && (J) == 1) dy_row((PAR) ^ 1, 1, (C) + 1 <= clast);                                 \
-        if ((K) == 3 && (J) == 0) dy_row((PAR) ^ 1, 2, false);                                            \
-        if ((K) == 3 && (J) == 1) dy_row((PAR) ^ 1, 3, false);                                            \
-        if ((K) == 4 && (J) == 0) dy_row((PAR) ^ 1, 4, false);                                            \
-        if ((K) == 4 && (J) == 1) dy_row((PAR) ^ 1, 5, false);                                            \
+        if ((K) == 0 && (J) == 0) VF_STORE_X(KN2, PAR, SP);                                               \
+        if ((K) == 0 && (J) == 1) VF_LOAD_X(KN4, SP);      /* chunk C+3, into the registers just freed */ \
+        if ((K) == 1 && (J) == 0) dy_group((PAR) ^ 1, 0, (C) + 1 <= clast);                               \
+        if ((K) == 2 && (J) == 0) dy_group((PAR) ^ 1, 1, false);                                          \
+        if ((K) == 3 && (J) == 0) { dy_group((PAR) ^ 1, 2, false); load_dy(KN2); }                        \
     }
-#define VF_SIDE_V(C, PAR, K, J, KN2, KN3)                                                                 \
+#define VF_SIDE_V(C, PAR, K, J, KN2, KN4, SP)                                                                  \
     {                                                                                                     \
         if ((K) == 0 && (J) == 1) { win_read((PAR) ^ 1, 0); win_read((PAR) ^ 1, 1); win_read((PAR) ^ 1, 2); } \
         if ((K) == 1 && (J) == 0) { win_read((PAR) ^ 1, 3); win_read((PAR) ^ 1, 4); }                     \
@@ -464,27 +463,28 @@ __global__ __launch_bounds__(512, 2) void wino44_wgrad_kernel(W44Args a) {
         if ((K) == 4 && (J) == 0) win_col_write((PAR) ^ 1, 1);                                            \
         if ((K) == 5 && (J) == 0) win_col_write((PAR) ^ 1, 2);                                            \
     }
-    f32x2 a_cur, b_cur;
+    f32x2 a_cur, b_cur, a_nx, b_nx;
     VF_FRAG(a_cur, b_cur, 0, 0);
+    VF_FRAG(a_nx, b_nx, 0, 1);
     if (n <= 0) {
 #pragma unroll
         for (int k = 0; k < 9; ++k) acc[k] = (f32x16){0};
     } else if (is_dm) {
-        VF_W44_CHUNK(c_begin, 0, true, VF_SIDE_DM);
+        VF_W44_CHUNK(c_begin, 0, true, VF_SIDE_DM, A);
         int c = c_begin + 1;
         for (; c + 1 < c_end; c += 2) {
-            VF_W44_CHUNK(c, 1, false, VF_SIDE_DM);
-            VF_W44_CHUNK(c + 1, 0, false, VF_SIDE_DM);
+            VF_W44_CHUNK(c, 1, false, VF_SIDE_DM, A);
+            VF_W44_CHUNK(c + 1, 0, false, VF_SIDE_DM, A);
         }
-        if (c < c_end) VF_W44_CHUNK(c, 1, false, VF_SIDE_DM);
+        if (c < c_end) VF_W44_CHUNK(c, 1, false, VF_SIDE_DM, A);
     } else {
-        VF_W44_CHUNK(c_begin, 0, true, VF_SIDE_V);
+        VF_W44_CHUNK(c_begin, 0, true, VF_SIDE_V, A);
         int c = c_begin + 1;
         for (; c + 1 < c_end; c += 2) {
-            VF_W44_CHUNK(c, 1, false, VF_SIDE_V);
-            VF_W44_CHUNK(c + 1, 0, false, VF_SIDE_V);
+            VF_W44_CHUNK(c, 1, false, VF_SIDE_V, A);
+            VF_W44_CHUNK(c + 1, 0, false, VF_SIDE_V, A);
         }
-        if (c < c_end) VF_W44_CHUNK(c, 1, false, VF_SIDE_V);
+        if (c < c_end) VF_W44_CHUNK(c, 1, false, VF_SIDE_V, A);
     }
 #undef VF_W44_CHUNK
 #undef VF_SIDE_DM
@@ -492,6 +492,8 @@ __global__ __launch_bounds__(512, 2) void wino44_wgrad_kernel(W44Args a) {
 #undef VF_FRAG
 #undef VF_MF
 #undef VF_XLOAD1
+#undef VF_LOAD_X
+#undef VF_STORE_X
 #undef VF_HLOAD1
 #undef VF_XSTORE1
 #undef VF_HSTORE1
