@@ -845,20 +845,26 @@ __global__ void conv_splitk_reduce_kernel(const float4* __restrict__ ws, const f
                                           float4* __restrict__ y, int ksplit, size_t n4, int HW4, int Cout) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n4) return;
-    float4 v = ws[i];
-    for (int k = 1; k < ksplit; ++k) {
-        const float4 t = ws[(size_t)k * n4 + i];
-        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
-    }
+    // every operand is requested before the first add (ksplit <= 16: two batches of eight independent loads on
+    // clamped indices; a plain accumulate loop pays one memory round trip per partial -- this kernel runs ~100 times
+    // per reverse step of the sampler).  Fixed summation order.
     const size_t sc = i / HW4;                 // s*Cout + co
     float b = 0.f;
     if (bias) b += bias[sc % Cout];
     if (vbias) b += vbias[sc];
-    if (res) {
-        const float4 r = res[i];
-        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (res) r = res[i];
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k0 = 0; k0 < ksplit; k0 += 8) {
+        float4 t[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = ws[(size_t)min(k0 + j, ksplit - 1) * n4 + i];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (k0 + j < ksplit) { v.x += t[j].x; v.y += t[j].y; v.z += t[j].z; v.w += t[j].w; }
+        }
     }
-    y[i] = make_float4(v.x + b, v.y + b, v.z + b, v.w + b);
+    y[i] = make_float4(v.x + r.x + b, v.y + r.y + b, v.z + r.z + b, v.w + r.w + b);
 }
 
 // Split-K factor: only when the natural grid cannot fill the chip (small S: the sampler).  Measured over the

@@ -583,8 +583,8 @@ __global__ __launch_bounds__(512, 2) void wino44_wgrad_kernel(W44Args a) {
 }
 
 // Slab sum: dW[co][ci][tap] = sum over the K slices' partial dW (fixed order, no float atomics).  One workgroup = one
-// output channel x 64 input channels; thread (ci, g) sums taps {0,1,2} / {3,4} / {5,6} / {7,8} over the slabs in 4
-// interleaved chains; the 9 x 64 sums are written out as one contiguous 2304-byte run of dW through LDS.
+// output channel x 64 input channels; thread (ci, g) sums all nine taps of every fourth slab, the four partial sums
+// meet in LDS, and the 9 x 64 results are written out as one contiguous 2304-byte run of dW.
 // Trailing workgroups: db[co] = sum over the slices' dY sums.
 __global__ __launch_bounds__(256) void wino44_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
                                                             int Cout, int Cin, int CoutP, int CinQ, int nslab,
@@ -613,40 +613,48 @@ __global__ __launch_bounds__(256) void wino44_reduce_kernel(const float* __restr
         }
         return;
     }
+    __shared__ float part[3][9][64];
     __shared__ float dwl[64 * 9];
     const int cx = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int ncb = (Cin + 63) / 64;
     const int co = blockIdx.x / ncb, cb = (blockIdx.x % ncb) * 64, ci = cb + cx;
     const size_t kst = (size_t)CoutP * CinQ, sst = 9 * kst;
-    const int t0 = g == 0 ? 0 : 2 * g + 1, nt = g == 0 ? 3 : 2;      // taps of this thread
-    float s3[3] = {0.f, 0.f, 0.f};
-    if (ci < CinQ) {
-        const float* p = ws + (size_t)t0 * kst + (size_t)co * CinQ + ci;
-        float c0[3] = {0.f, 0.f, 0.f}, c1[3] = {0.f, 0.f, 0.f}, c2[3] = {0.f, 0.f, 0.f}, c3[3] = {0.f, 0.f, 0.f};
-        int z = 0;
-        for (; z + 3 < nslab; z += 4) {
-            float v0[3], v1[3], v2[3], v3[3];
+    // thread (ci, g): all nine taps of the slabs z = g, g + 4, ...; two slabs (18 independent loads) in flight
+    float s9[9];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const size_t ko = (size_t)min(k, nt - 1) * kst;
-                v0[k] = p[(size_t)z * sst + ko];
-                v1[k] = p[(size_t)(z + 1) * sst + ko];
-                v2[k] = p[(size_t)(z + 2) * sst + ko];
-                v3[k] = p[(size_t)(z + 3) * sst + ko];
+    for (int k = 0; k < 9; ++k) s9[k] = 0.f;
+    if (ci < CinQ) {
+        const float* p = ws + (size_t)co * CinQ + ci;
+        float c0[9], c1[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) c0[k] = c1[k] = 0.f;
+        int z = g;
+        for (; z + 4 < nslab; z += 8) {
+            float v0[9], v1[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                v0[k] = p[(size_t)z * sst + k * kst];
+                v1[k] = p[(size_t)(z + 4) * sst + k * kst];
             }
 #pragma unroll
-            for (int k = 0; k < 3; ++k) { c0[k] += v0[k]; c1[k] += v1[k]; c2[k] += v2[k]; c3[k] += v3[k]; }
+            for (int k = 0; k < 9; ++k) { c0[k] += v0[k]; c1[k] += v1[k]; }
         }
-        for (; z < nslab; ++z) {
+        if (z < nslab) {
 #pragma unroll
-            for (int k = 0; k < 3; ++k) c0[k] += p[(size_t)z * sst + (size_t)min(k, nt - 1) * kst];
+            for (int k = 0; k < 9; ++k) c0[k] += p[(size_t)z * sst + k * kst];
         }
 #pragma unroll
-        for (int k = 0; k < 3; ++k) s3[k] = (c0[k] + c1[k]) + (c2[k] + c3[k]);
+        for (int k = 0; k < 9; ++k) s9[k] = c0[k] + c1[k];
     }
+    if (g > 0) {
 #pragma unroll
-    for (int k = 0; k < 3; ++k)
-        if (k < nt) dwl[cx * 9 + t0 + k] = s3[k];
+        for (int k = 0; k < 9; ++k) part[g - 1][k][cx] = s9[k];
+    }
+    __syncthreads();
+    if (g == 0) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) dwl[cx * 9 + k] = (s9[k] + part[0][k][cx]) + (part[1][k][cx] + part[2][k][cx]);
+    }
     __syncthreads();
     const int nvalid = min(64, Cin - cb) * 9;
     float* o = dw + ((size_t)co * Cin + cb) * 9;
