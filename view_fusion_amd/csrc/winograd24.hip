@@ -651,26 +651,37 @@ __global__ __launch_bounds__(256) void wino_fixup_kernel(WinoArgs a, int ntail) 
     const int s = G::g_view(wg) + G::t_img(tl), r0 = G::g_row(wg);
     const int co = cot * WTCO + col;
     if (s >= a.S || co >= a.Cout) return;
-    float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
-    for (int p = 0; p < a.tail_split; ++p) {
-        const float* w8 = a.ws + ((((size_t)j * a.tail_split + p) * WTCO + col) * WTT + tl) * 8;
-        const float4 t0 = *reinterpret_cast<const float4*>(w8), t1 = *reinterpret_cast<const float4*>(w8 + 4);
-        v0.x += t0.x; v0.y += t0.y; v0.z += t0.z; v0.w += t0.w;
-        v1.x += t1.x; v1.y += t1.y; v1.z += t1.z; v1.w += t1.w;
+    // every operand is requested before the first add (tail_split <= 8 partials on clamped indices, then bias and
+    // residual): a plain accumulate loop pays one memory round trip per partial.  Fixed summation order.
+    const int orow = r0 + 2 * G::t_row(tl), ocol = 4 * G::t_col(tl);
+    const size_t o = ((size_t)s * a.Cout + co) * G::HW + (size_t)orow * G::W + ocol;
+    float4 t0[8], t1[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        const float* w8 = a.ws + ((((size_t)j * a.tail_split + min(p, a.tail_split - 1)) * WTCO + col) * WTT + tl) * 8;
+        t0[p] = *reinterpret_cast<const float4*>(w8);
+        t1[p] = *reinterpret_cast<const float4*>(w8 + 4);
     }
     float b = 0.f;
     if (a.bias) b += a.bias[co];
     if (a.vbias) b += a.vbias[(size_t)s * a.Cout + co];
-    const int orow = r0 + 2 * G::t_row(tl), ocol = 4 * G::t_col(tl);
-    const size_t o = ((size_t)s * a.Cout + co) * G::HW + (size_t)orow * G::W + ocol;
+    float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0;
+    if (a.res) {
+        q0 = *reinterpret_cast<const float4*>(a.res + o);
+        q1 = *reinterpret_cast<const float4*>(a.res + o + G::W);
+    }
+    float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        if (p < a.tail_split) {
+            v0.x += t0[p].x; v0.y += t0[p].y; v0.z += t0[p].z; v0.w += t0[p].w;
+            v1.x += t1[p].x; v1.y += t1[p].y; v1.z += t1[p].z; v1.w += t1[p].w;
+        }
+    }
     v0.x += b; v0.y += b; v0.z += b; v0.w += b;
     v1.x += b; v1.y += b; v1.z += b; v1.w += b;
-    if (a.res) {
-        const float4 q0 = *reinterpret_cast<const float4*>(a.res + o);
-        const float4 q1 = *reinterpret_cast<const float4*>(a.res + o + G::W);
-        v0.x += q0.x; v0.y += q0.y; v0.z += q0.z; v0.w += q0.w;
-        v1.x += q1.x; v1.y += q1.y; v1.z += q1.z; v1.w += q1.w;
-    }
+    v0.x += q0.x; v0.y += q0.y; v0.z += q0.z; v0.w += q0.w;
+    v1.x += q1.x; v1.y += q1.y; v1.z += q1.z; v1.w += q1.w;
     *reinterpret_cast<float4*>(a.y + o) = v0;
     *reinterpret_cast<float4*>(a.y + o + G::W) = v1;
 }

@@ -62,6 +62,15 @@ __device__ __forceinline__ f32x2 pk_xlo_pm_2yhi(f32x2 e, f32x2 f) {      // [e.x
     return d;
 }
 
+#ifdef VF_STAMPS44
+// diagnostic build only: shader-clock sums per role (0 = dM waves, 1 = V waves): [role][0] chunk start -> barrier
+// arrival, [1] inside the barrier, [2] barrier -> chunk end, [3] chunks, [4] prologue, [5] epilogue, [6] waves
+__device__ unsigned long long g_stamps44[2][16];     // [8..13]: epilogue phases
+#define VF_ST44(V) const unsigned long long V = __builtin_amdgcn_s_memtime()
+#else
+#define VF_ST44(V)
+#endif
+
 template <int LOGW, int MODE>
 __global__ __launch_bounds__(512, 2) void wino44_wgrad_kernel(W44Args a) {
     constexpr int W = 1 << LOGW, H = W;
@@ -93,6 +102,11 @@ __global__ __launch_bounds__(512, 2) void wino44_wgrad_kernel(W44Args a) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform (SGPR): roles branch on it
+#ifdef VF_STAMPS44
+    unsigned long long st_a = 0, st_b = 0, st_c = 0, st_n = 0;
+    VF_ST44(t_k0);
+    const unsigned long long rt_k0 = __builtin_amdgcn_s_memrealtime();
+#endif
     const int cw = wid & 1, sg = wid >> 1;
     const int li = lane & 31, lh = lane >> 5;
     const bool is_dm = wid < 4;                             // wave-uniform role
@@ -429,10 +443,19 @@ __global__ __launch_bounds__(512, 2) void wino44_wgrad_kernel(W44Args a) {
 #else
 #define VF_ABL_BARRIER() __syncthreads()
 #endif
+#ifdef VF_STAMPS44
+#define VF_ST44_ACC1() { st_a += t_c1 - t_c0; st_b += t_c2 - t_c1; t_mid = t_c2; }
+#define VF_ST44_ACC2() { const unsigned long long t_c3 = __builtin_amdgcn_s_memtime(); st_c += t_c3 - t_mid; st_n += 1; }
+    unsigned long long t_mid = 0;
+#else
+#define VF_ST44_ACC1()
+#define VF_ST44_ACC2()
+#endif
 #define VF_W44_CHUNK(C, PAR, FIRST, SIDE, SP)                                                             \
     {                                                                                                     \
         const Chunk kn2 = chunk_at(min((C) + 2, clast)), kn4 = chunk_at(min((C) + 3, clast));             \
         f32x2 a2, b2;                 /* fragments run TWO slices ahead of their MFMAs: slice k fetches slice k+2 */ \
+        VF_ST44(t_c0);                                                                                    \
         _Pragma("unroll") for (int k = 0; k < 9; ++k) {                                                   \
             VF_MF(k, a_cur.x, b_cur.x, FIRST);                                                            \
             if (k < 7) { VF_FRAG(a2, b2, PAR, k + 2); }                                                   \
@@ -440,9 +463,10 @@ __global__ __launch_bounds__(512, 2) void wino44_wgrad_kernel(W44Args a) {
             VF_ABL_SIDE(SIDE(C, PAR, k, 0, kn2, kn4, SP));                                                  \
             VF_MF(k, a_cur.y, b_cur.y, false);                                                            \
             VF_ABL_SIDE(SIDE(C, PAR, k, 1, kn2, kn4, SP));                                                  \
-            if (k == 6) VF_ABL_BARRIER();                                                                 \
+            if (k == 6) { VF_ST44(t_c1); VF_ABL_BARRIER(); VF_ST44(t_c2); VF_ST44_ACC1(); }              \
             a_cur = a_nx; b_cur = b_nx; a_nx = a2; b_nx = b2;                                             \
         }                                                                                                 \
+        VF_ST44_ACC2();                                                                                   \
     }
     // dM waves: raw rows of chunk C+2 -> strip[PAR] in slice 0, transform of dY(C+1) spread over slices 1-4; every
     // global load goes out as soon as its registers are free (x: chunk C+3, dY: chunk C+2)
@@ -463,6 +487,9 @@ __global__ __launch_bounds__(512, 2) void wino44_wgrad_kernel(W44Args a) {
         if ((K) == 4 && (J) == 0) win_col_write((PAR) ^ 1, 1);                                            \
         if ((K) == 5 && (J) == 0) win_col_write((PAR) ^ 1, 2);                                            \
     }
+#ifdef VF_STAMPS44
+    VF_ST44(t_k1);
+#endif
     f32x2 a_cur, b_cur, a_nx, b_nx;
     VF_FRAG(a_cur, b_cur, 0, 0);
     VF_FRAG(a_nx, b_nx, 0, 1);
@@ -501,6 +528,9 @@ __global__ __launch_bounds__(512, 2) void wino44_wgrad_kernel(W44Args a) {
 #undef VF_LANES
 
 #undef VF_SL
+#ifdef VF_STAMPS44
+    VF_ST44(t_k2);
+#endif
     const int slab = bz;
     if (a.bsum && by == 0 && is_dm) {          // bias gradient partial: the 4 tile lanes of a channel, fixed order
         float b = bias1;
@@ -544,7 +574,9 @@ __global__ __launch_bounds__(512, 2) void wino44_wgrad_kernel(W44Args a) {
     }
     // cross-wave sum through LDS (the loop's images are dead: every wave is past the last chunk's barrier)
     float* const xch = lds;                        // [slot][k 9][r 16][lane 64]
+    VF_ST44(t_e1);
     __syncthreads();
+    VF_ST44(t_e2);
     if (ih == 1) {
         float* o = xch + (size_t)(2 * jh + cw) * (9 * 16 * 64) + lane;
 #pragma unroll
@@ -553,6 +585,7 @@ __global__ __launch_bounds__(512, 2) void wino44_wgrad_kernel(W44Args a) {
             for (int r = 0; r < 16; ++r) o[(k * 16 + r) * 64] = acc[k][r];
     }
     __syncthreads();
+    VF_ST44(t_e3);
     if (ih == 0) {
         const float* o = xch + (size_t)(2 * jh + cw) * (9 * 16 * 64) + lane;
 #pragma unroll
@@ -560,6 +593,7 @@ __global__ __launch_bounds__(512, 2) void wino44_wgrad_kernel(W44Args a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[k][r] += o[(k * 16 + r) * 64];
     }
+    VF_ST44(t_e4);
     __syncthreads();
     if (ih == 0 && jh == 1) {
         float* o = xch + (size_t)cw * (9 * 16 * 64) + lane;
@@ -569,6 +603,7 @@ __global__ __launch_bounds__(512, 2) void wino44_wgrad_kernel(W44Args a) {
             for (int r = 0; r < 16; ++r) o[(k * 16 + r) * 64] = acc[k][r];
     }
     __syncthreads();
+    VF_ST44(t_e5);
     if (sg == 0) {
         const float* o = xch + (size_t)cw * (9 * 16 * 64) + lane;
         // slab [tap 9][CoutP][CinQ]: one 64-bit base per lane, 32-bit offsets inside the slab
@@ -578,8 +613,26 @@ __global__ __launch_bounds__(512, 2) void wino44_wgrad_kernel(W44Args a) {
         for (int k = 0; k < 9; ++k)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                sb[(size_t)k * kst + ((r & 3) + 8 * (r >> 2)) * a.CinQ] = acc[k][r] + o[(k * 16 + r) * 64];
+            {
+                const float v_ = acc[k][r] + o[(k * 16 + r) * 64];
+#ifdef VF_ABL_NOSTORE
+                asm volatile("" :: "v"(v_));
+#else
+                sb[(size_t)k * kst + ((r & 3) + 8 * (r >> 2)) * a.CinQ] = v_;
+#endif
+            }
     }
+#ifdef VF_STAMPS44
+    if (lane == 0) {
+        const unsigned long long t_k3 = __builtin_amdgcn_s_memtime();
+        unsigned long long* g = g_stamps44[is_dm ? 0 : 1];
+        atomicAdd(&g[0], st_a); atomicAdd(&g[1], st_b); atomicAdd(&g[2], st_c); atomicAdd(&g[3], st_n);
+        atomicAdd(&g[4], t_k1 - t_k0); atomicAdd(&g[5], t_k3 - t_k2); atomicAdd(&g[6], 1ull);
+        atomicAdd(&g[14], t_k3 - t_k0); atomicAdd(&g[15], __builtin_amdgcn_s_memrealtime() - rt_k0);   // shader clocks / 100 MHz ticks
+        atomicAdd(&g[8], t_e1 - t_k2); atomicAdd(&g[9], t_e2 - t_e1); atomicAdd(&g[10], t_e3 - t_e2);
+        atomicAdd(&g[11], t_e4 - t_e3); atomicAdd(&g[12], t_e5 - t_e4); atomicAdd(&g[13], t_k3 - t_e5);
+    }
+#endif
 }
 
 // Slab sum: dW[co][ci][tap] = sum over the K slices' partial dW (fixed order, no float atomics).  One workgroup = one
@@ -741,3 +794,10 @@ int vf_wino_wgrad(const float* x, const float* dy, float* dw, float* db, float* 
 }
 
 }  // extern "C"
+
+#ifdef VF_STAMPS44
+extern "C" void vf_debug_stamps44(unsigned long long* out16, int reset) {
+    if (out16) (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_stamps44), 256);
+    if (reset) { unsigned long long z[32] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps44), z, 256); }
+}
+#endif
