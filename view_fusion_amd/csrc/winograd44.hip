@@ -106,7 +106,6 @@ __global__ __launch_bounds__(512, 2) void wino44_wgrad_kernel(W44Args a) {
     unsigned long long st_a = 0, st_b = 0, st_c = 0, st_n = 0;
     VF_ST44(t_k0);
     const unsigned long long rt_k0 = __builtin_amdgcn_s_memrealtime();
-    const unsigned long long rt_k0 = __builtin_amdgcn_s_memrealtime();
 #endif
     const int cw = wid & 1, sg = wid >> 1;
     const int li = lane & 31, lh = lane >> 5;
@@ -631,10 +630,7 @@ __global__ __launch_bounds__(512, 2) void wino44_wgrad_kernel(W44Args a) {
         atomicAdd(&g[4], t_k1 - t_k0); atomicAdd(&g[5], t_k3 - t_k2); atomicAdd(&g[6], 1ull);
         atomicAdd(&g[8], t_e1 - t_k2); atomicAdd(&g[9], t_e2 - t_e1); atomicAdd(&g[10], t_e3 - t_e2);
         atomicAdd(&g[11], t_e4 - t_e3); atomicAdd(&g[12], t_e5 - t_e4); atomicAdd(&g[13], t_k3 - t_e5);
-        atomicAdd(&g[14], t_k3 - t_k0); atomicAdd(&g[15], __builtin_amdgcn_s_memrealtime() - rt_k0);
         atomicAdd(&g[14], t_k3 - t_k0); atomicAdd(&g[15], __builtin_amdgcn_s_memrealtime() - rt_k0);   // shader clocks / 100 MHz ticks
-        atomicAdd(&g[8], t_e1 - t_k2); atomicAdd(&g[9], t_e2 - t_e1); atomicAdd(&g[10], t_e3 - t_e2);
-        atomicAdd(&g[11], t_e4 - t_e3); atomicAdd(&g[12], t_e5 - t_e4); atomicAdd(&g[13], t_k3 - t_e5);
     }
 #endif
 }
