@@ -71,6 +71,17 @@ int vf_conv1x1_cat_dgrad(const float* dy, const float* w_packed_bwd, float* dx1,
                          int Cout, int H, int W, void* stream);
 int vf_conv1x1_cat_wgrad(const float* x1, const float* x2, int C1, const float* dy, float* dw_oihw, float* ws,
                          long ws_floats, int S, int Cin, int Cout, int H, int W, void* stream);
+/* EXPERIMENT (hosts select it with VF_BF16X3=1; default off): the same 1x1 convolutions with fp32-accurate products on
+ * the bf16 matrix path -- every operand split into three bf16 pieces, six MFMAs per K=16 block, fp32 accumulation
+ * (csrc/conv1x1_bf16x3.hip).  pack: w_oihw [Cout][Cin] -> split + packed forward operand (and the transposed dgrad
+ * operand if w3_bwd != NULL); sizes in 32-bit words from vf_conv1x1_bf16x3_pack_dwords(M, K) with (M, K) = (Cout, Cin) /
+ * (Cin, Cout).  conv: x may be the concatenation [x | x2] (x2 != NULL: C1in channels in x), y may be split into
+ * [y | y2] (y2 != NULL: C1out channels in y); HW a power of two >= 64. */
+long vf_conv1x1_bf16x3_pack_dwords(int M, int K);
+int vf_conv1x1_bf16x3_pack(const float* w_oihw, void* w3_fwd, void* w3_bwd, int Cout, int Cin, void* stream);
+int vf_conv1x1_bf16x3(const float* x, const float* x2, int C1in, const void* w3, const float* bias,
+                      const float* view_bias, const float* residual, float* y, float* y2, int C1out, int S, int Cin,
+                      int Cout, int HW, void* stream);
 long vf_conv_wgrad_ws_floats(int S, int Cin, int Cout, int H, int W, int KS);
 int vf_conv_wgrad(const float* x, const float* dy, float* dw_oihw, float* ws, long ws_floats, int S, int Cin,
                   int Cout, int H, int W, int KS, int mode, void* stream);

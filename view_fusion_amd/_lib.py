@@ -44,6 +44,9 @@ SIGNATURES = {
     "vf_conv_fwd_ws_floats": [_I, _I, _I, _I, _I, _I],
     "vf_conv_wgrad_ws_floats": [_I, _I, _I, _I, _I, _I],
     "vf_conv_wgrad": [_P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _P],
+    "vf_conv1x1_bf16x3_pack_dwords": [_I, _I],
+    "vf_conv1x1_bf16x3_pack": [_P, _P, _P, _I, _I, _P],
+    "vf_conv1x1_bf16x3": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "vf_wino_supported": [_I, _I, _I],
     "vf_wino_pack_sizes": [_I, _I, ctypes.POINTER(_L), ctypes.POINTER(_L)],
     "vf_wino_pack_weights": [_P, _P, _P, _I, _I, _P],
@@ -75,7 +78,7 @@ SIGNATURES = {
     "vf_compose_mse_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "vf_p_sample_tail": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
 }
-_RESTYPE = {"vf_conv_wgrad_ws_floats": _L, "vf_time_affine_ws_floats": _L, "vf_wino_conv_ws_floats": _L, "vf_wino_wgrad_ws_floats": _L, "vf_conv_fwd_ws_floats": _L}
+_RESTYPE = {"vf_conv1x1_bf16x3_pack_dwords": _L, "vf_conv_wgrad_ws_floats": _L, "vf_time_affine_ws_floats": _L, "vf_wino_conv_ws_floats": _L, "vf_wino_wgrad_ws_floats": _L, "vf_conv_fwd_ws_floats": _L}
 
 _lib = None
 N_CALLS = 0          # C-ABI launcher invocations so far (bench.py: launches per sampler step)

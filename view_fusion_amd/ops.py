@@ -423,6 +423,38 @@ def pack_all(root, S=None):
         object.__setattr__(l, attr + "_fresh", True)
 
 
+# EXPERIMENT, default off: VF_BF16X3=1 routes the forward and dgrad passes of the 1x1 convolutions (maps >= 8x8) through
+# the bf16x3 split-product kernel (csrc/conv1x1_bf16x3.hip); weight gradients stay on the fp32 MFMA kernels.
+BF16X3 = os.environ.get("VF_BF16X3") == "1"
+
+
+def _packed_b3(layer, force):
+    """Split + packed operands (forward, dgrad) of a 1x1 layer for the bf16x3 kernel; same caching rules as _packed."""
+    w = layer.weight
+    cache = getattr(layer, "_vf_pack3", None)
+    key = (w._version, w.data_ptr(), w.device)
+    if not force and cache is not None and cache[0] == key:
+        return cache[1], cache[2]
+    Cout, Cin = w.shape[0], w.shape[1]
+    lib = _lib.load()
+    nf, nb = lib.vf_conv1x1_bf16x3_pack_dwords(Cout, Cin), lib.vf_conv1x1_bf16x3_pack_dwords(Cin, Cout)
+    if cache is not None and cache[1].numel() == nf and cache[1].device == w.device:
+        wf, wb = cache[1], cache[2]
+    else:
+        wf = torch.empty(nf, device=w.device, dtype=torch.int32)
+        wb = torch.empty(nb, device=w.device, dtype=torch.int32)
+    wd = w.detach()
+    _check(wd)
+    _lib.call("vf_conv1x1_bf16x3_pack", _ptr(wd), ctypes.c_void_p(wf.data_ptr()), ctypes.c_void_p(wb.data_ptr()), Cout, Cin,
+              _stream())
+    object.__setattr__(layer, "_vf_pack3", (None if force else key, wf, wb))
+    return wf, wb
+
+
+def _use_b3(KS, m, HW):
+    return BF16X3 and KS == 1 and m == 0 and HW >= 64 and (HW & (HW - 1)) == 0
+
+
 class _Conv2dFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, view_bias, residual, layer, mode, training, twin):
@@ -436,7 +468,13 @@ class _Conv2dFn(torch.autograd.Function):
         # algorithmic HBM bytes: input, output (+ residual) and the weights, each once
         nb = 4.0 * (x.numel() + y.numel() + weight.numel() + (residual.numel() if residual is not None else 0))
         wino = use_winograd(S, Cin, Cout, H, W, KS, m)
-        if wino:
+        ctx.b3 = _use_b3(KS, m, H * W)
+        if ctx.b3:
+            wf, wb = _packed_b3(layer, force=training)
+            _launch("conv_fwd", flops, "vf_conv1x1_bf16x3", _ptr(x), None, 0, ctypes.c_void_p(wf.data_ptr()), _ptr(bias),
+                    _ptr(view_bias), _ptr(residual), _ptr(y), None, 0, S, Cin, Cout, H * W, _stream(),
+                    tag=(Cin, Cout, H, KS, m))
+        elif wino:
             wf, wb = _packed_wino(layer, force=training)
             ws, nws = _wino_ws(x.device, S, Cin, Cout, H, W)
             _launch("conv_fwd", flops, "vf_wino_conv_fwd", _ptr(x), _ptr(wf), _ptr(bias), _ptr(view_bias),
@@ -476,6 +514,10 @@ class _Conv2dFn(torch.autograd.Function):
                 _lib.call("vf_sumpool2", _ptr(dfull), _ptr(dx), dx.numel(), Wi, st)
             else:
                 dx = dfull
+        elif ctx.needs_input_grad[0] and ctx.b3:
+            dx = torch.empty_like(x)
+            _launch("conv_dgrad", ctx.flops, "vf_conv1x1_bf16x3", _ptr(dy), None, 0, ctypes.c_void_p(ctx.wb.data_ptr()), None,
+                    None, None, _ptr(dx), None, 0, S, Cout, Cin, H * W, st, tag=ctx.tag)
         elif ctx.needs_input_grad[0]:
             if m == 0:
                 dx = torch.empty_like(x)
@@ -554,10 +596,17 @@ class _Conv1x1CatFn(torch.autograd.Function):
         S, C1, H, W = x1.shape
         Cout, Cin = weight.shape[0], weight.shape[1]
         y = torch.empty(S, Cout, H, W, device=x1.device, dtype=torch.float32)
-        wf, wb = _packed(layer, force=training)
-        ws, nws = _conv_ws(x1.device, S, Cin, Cout, H, W, 1)
-        _launch("conv_fwd", 2.0 * S * Cout * Cin * H * W, "vf_conv1x1_cat_fwd", _ptr(x1), _ptr(x2), C1, _ptr(wf),
-                _ptr(bias), _ptr(y), _ptr(ws), nws, S, Cin, Cout, H, W, _stream(), tag=(Cin, Cout, H, 1, 0))
+        ctx.b3 = _use_b3(1, 0, H * W)
+        if ctx.b3:
+            wf, wb = _packed_b3(layer, force=training)
+            _launch("conv_fwd", 2.0 * S * Cout * Cin * H * W, "vf_conv1x1_bf16x3", _ptr(x1), _ptr(x2), C1,
+                    ctypes.c_void_p(wf.data_ptr()), _ptr(bias), None, None, _ptr(y), None, 0, S, Cin, Cout, H * W, _stream(),
+                    tag=(Cin, Cout, H, 1, 0))
+        else:
+            wf, wb = _packed(layer, force=training)
+            ws, nws = _conv_ws(x1.device, S, Cin, Cout, H, W, 1)
+            _launch("conv_fwd", 2.0 * S * Cout * Cin * H * W, "vf_conv1x1_cat_fwd", _ptr(x1), _ptr(x2), C1, _ptr(wf),
+                    _ptr(bias), _ptr(y), _ptr(ws), nws, S, Cin, Cout, H, W, _stream(), tag=(Cin, Cout, H, 1, 0))
         ctx.save_for_backward(x1, x2)
         ctx.wb, ctx.dims, ctx.has_bias = wb, (Cin, Cout), bias is not None
         ctx.pw, ctx.pb = weight, bias
@@ -574,8 +623,12 @@ class _Conv1x1CatFn(torch.autograd.Function):
         dx1 = dx2 = dw = db = None
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
             dx1, dx2 = torch.empty_like(x1), torch.empty_like(x2)
-            _launch("conv_dgrad", flops, "vf_conv1x1_cat_dgrad", _ptr(dy), _ptr(ctx.wb), _ptr(dx1), _ptr(dx2), C1, S,
-                    Cin, Cout, H, W, st, tag=tag)
+            if ctx.b3:
+                _launch("conv_dgrad", flops, "vf_conv1x1_bf16x3", _ptr(dy), None, 0, ctypes.c_void_p(ctx.wb.data_ptr()), None,
+                        None, None, _ptr(dx1), _ptr(dx2), C1, S, Cout, Cin, H * W, st, tag=tag)
+            else:
+                _launch("conv_dgrad", flops, "vf_conv1x1_cat_dgrad", _ptr(dy), _ptr(ctx.wb), _ptr(dx1), _ptr(dx2), C1, S,
+                        Cin, Cout, H, W, st, tag=tag)
         if ctx.needs_input_grad[2]:
             ws = _workspace(x1.device, _lib.load().vf_conv_wgrad_ws_floats(S, Cin, Cout, H, W, 1))
             dw = _gout(ctx.pw, Cout, Cin, 1, 1, like=x1)
