@@ -350,7 +350,11 @@ def main():
             "metric": "denoise_steps_per_sec", "value": S * world * args.steps / dt,
             "unit": "view denoise-steps/s (UNet fwd+bwd per stacked view, incl. compose/MSE/Adam)",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            # VF_BF16X3=1 (experiment, default off): the 1x1 convolutions' forward / dgrad products run as bf16x3 split
+            # products on the bf16 matrix path -- such a line is NOT the fp32-MFMA headline and says so here
+            "dtype": "f32" if not ops.BF16X3 else "f32 (1x1 conv fwd+dgrad: bf16x3 split products on the bf16 MFMA path)",
+            "data": "synthetic",
             "config": {"workload": "small UNet 64x64 (33.9M params), B=%d/GPU N=%d (S=%d views/GPU), training "
                                    "iteration fwd+bwd+Adam, linear T=2000 schedule%s" % (args.batch, args.views, S,
                                                                                      ", ragged view_count" if args.ragged else ""),

@@ -133,3 +133,46 @@ def test_reduce_dict_identity_without_process_group():
     from view_fusion_amd import drivers
     d = {"psnr": torch.tensor(3.0)}
     assert drivers.reduce_dict(d) is d
+
+
+def test_drivers_run_in_eval_mode_and_restore_the_mode():
+    """Experiment.eval calls model.eval() first (experiment.py:316): the sampler drivers switch Dropout off for the call
+    and put the model back into the mode they found it in."""
+    import torch
+    from view_fusion_amd import drivers
+
+    class Probe(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.drop = torch.nn.Dropout(0.5)
+            self.seen = []
+
+        def forward(self, **kw):
+            self.seen.append(self.training)
+            b = kw["y_cond"].shape[0]
+            z = torch.zeros(b, 2, 3, 4, 4)
+            return z[:, 0], z, None, None, z[:, 0]
+
+    m = Probe().train()
+    cond = torch.zeros(2, 23, 3, 4, 4)
+    drivers.extrapolate(m, cond, torch.zeros(2, 1), view_count=torch.tensor([7, 8]))
+    assert m.seen == [False] and m.training
+    m.eval()
+    drivers.extrapolate(m, cond, torch.zeros(2, 1), view_count=torch.tensor([7, 8]))
+    assert m.seen == [False, False] and not m.training
+
+
+def test_trainer_restores_training_mode_of_submodules():
+    """Trainer.step re-enters training mode when only a SUBMODULE with a mode-dependent layer was put into eval mode
+    (the reference calls model.train() every iteration, experiment.py:286)."""
+    import torch
+    from view_fusion_amd import train
+    from view_fusion_amd.unet import _ResBlock
+
+    blk = _ResBlock(4, 4, 8, 2, dropout=0.1)
+    root = torch.nn.Sequential(blk)
+    tr = train.Trainer.__new__(train.Trainer)
+    tr._mode_modules = [m for m in root.modules() if getattr(m, "dropout", 0) and hasattr(m, "_drop")]
+    assert tr._mode_modules == [blk]
+    blk.eval()
+    assert root.training and any(not m.training for m in tr._mode_modules)
