@@ -61,6 +61,14 @@ int vf_conv_fwd(const float* x, const float* w_packed, const float* bias /*[Cout
                 const float* view_bias /*[S][Cout]|NULL*/, const float* residual /*like y|NULL*/, float* y,
                 float* ws /*|NULL*/, long ws_floats, int S, int Cin, int Cout, int H, int W, int KS, int mode,
                 void* stream);
+/* inference fusion: a_out = [Swish](GroupNorm(groups, eps)(conv output)), the GroupNorm evaluated inside the conv's
+ * split-K reduce launch where the conv runs split-K (small S: the sampler), by a GroupNorm launch behind it otherwise.
+ * y: a valid output buffer; it holds the conv output afterwards if store_y != 0 (or the unfused route ran).
+ * gn_stats: scratch, 2*S*groups floats. */
+int vf_conv_fwd_gn(const float* x, const float* w_packed, const float* bias, const float* view_bias, const float* residual,
+                   float* y, int store_y, const float* gn_gamma, const float* gn_beta, float* a_out, float* gn_stats,
+                   int groups, float eps, int silu, float* ws, long ws_floats, int S, int Cin, int Cout, int H, int W,
+                   int KS, int mode, void* stream);
 /* split-K workspace the call above wants at this shape (0 when the natural grid fills the chip) */
 long vf_conv_fwd_ws_floats(int S, int Cin, int Cout, int H, int W, int KS);
 /* 1x1 conv on the channel concatenation [x1 (C1 channels, multiple of 64) | x2] (residual conv of the decoder

@@ -474,9 +474,9 @@ def test_conv1x1_bf16x3_vs_fp64(dev, Cin, Cout, H, S, cat_in, cat_out):
     else:
         y1, y2 = torch.full((S, Cout, H, H), float("nan"), device=dev), None
     P = lambda t: t.data_ptr() if t is not None else None
-    _lib.call("vf_conv1x1_bf16x3", P(x1), P(x2), cat_in, w3.data_ptr(), P(bias.to(dev)) if use_epi else None,
-              P(vb.to(dev)) if use_epi else None, P(res.to(dev)) if use_epi else None, P(y1), P(y2), cat_out, S, Cin, Cout,
-              H * H, st)
+    bg, vg, rg = (bias.to(dev), vb.to(dev), res.to(dev)) if use_epi else (None, None, None)   # (kept alive across the call)
+    _lib.call("vf_conv1x1_bf16x3", P(x1), P(x2), cat_in, w3.data_ptr(), P(bg), P(vg), P(rg), P(y1), P(y2), cat_out, S, Cin,
+              Cout, H * H, st)
     torch.cuda.synchronize()
     y = torch.cat((y1, y2), dim=1) if cat_out else y1
     assert _rel_l2(y, ref) < 1e-6

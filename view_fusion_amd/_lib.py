@@ -42,6 +42,7 @@ SIGNATURES = {
     "vf_conv_pack_weights_multi": [_P, _I, _L, _P],
     "vf_conv_fwd": [_P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _P],
     "vf_conv_fwd_ws_floats": [_I, _I, _I, _I, _I, _I],
+    "vf_conv_fwd_gn": [_P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _F, _I, _P, _L, _I, _I, _I, _I, _I, _I, _I, _P],
     "vf_conv_wgrad_ws_floats": [_I, _I, _I, _I, _I, _I],
     "vf_conv_wgrad": [_P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _P],
     "vf_conv1x1_bf16x3_pack_dwords": [_I, _I],

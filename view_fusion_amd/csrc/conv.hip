@@ -72,6 +72,14 @@ struct ConvArgs {
     const float* x2;
     float* y2;
     int C1, C1o;
+    // inference fusion (vf_conv_fwd_gn): the GroupNorm(+Swish) that consumes this conv's output.  gn_out != null: the
+    // split-K reduce kernel also normalises (one launch instead of two); y is then written only if gn_store_y.
+    const float* gn_gamma = nullptr;
+    const float* gn_beta = nullptr;
+    float* gn_out = nullptr;
+    float* gn_stats = nullptr;      // [2][S * groups] scratch for the unfused fallback
+    int gn_groups = 0, gn_silu = 0, gn_store_y = 1;
+    float gn_eps = 1e-5f;
 };
 
 // Global -> register load of one float4 of the input patch (zero outside the image / tensor).
@@ -867,6 +875,114 @@ __global__ void conv_splitk_reduce_kernel(const float4* __restrict__ ws, const f
     y[i] = make_float4(v.x + r.x + b, v.y + r.y + b, v.z + r.z + b, v.w + r.w + b);
 }
 
+// Split-K reduce + epilogue + GroupNorm(+Swish) in ONE launch (sampler regime, vf_conv_fwd_gn): one workgroup per
+// (view, group) sums the K-split partials of its channels, adds bias / per-view bias / residual, optionally stores the
+// conv output, and -- the whole group being in its registers -- normalises it (two-pass mean / variance as
+// gn_fwd_kernel) into `a_out`.  Replaces conv_splitk_reduce_kernel + gn_fwd_kernel.
+template <int NV, int NT>
+__global__ __launch_bounds__(NT) void conv_splitk_reduce_gn_kernel(const float4* __restrict__ ws, const float* __restrict__ bias,
+                                                                    const float* __restrict__ vbias,
+                                                                    const float4* __restrict__ res, float4* __restrict__ y,
+                                                                    const float* __restrict__ gamma,
+                                                                    const float* __restrict__ beta, float4* __restrict__ a_out,
+                                                                    int ksplit, size_t n4_total, int hw4sh, int Cout, int cpg,
+                                                                    float eps, int silu) {
+    __shared__ float red[NT / 64];
+    constexpr int KB = NV >= 8 ? 1 : 8 / NV;                 // partials per batch: >= 8 independent loads in flight
+    const int G = Cout / cpg;
+    const int sg = blockIdx.x, s = sg / G, g = sg - s * G;
+    const int n4 = cpg << hw4sh;
+    const size_t base4 = ((size_t)s * Cout + (size_t)g * cpg) << hw4sh;
+    float4 v[NV];
+    size_t gi[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        gi[i] = base4 + min((int)threadIdx.x + i * NT, n4 - 1);
+    }
+    for (int k0 = 0; k0 < ksplit; k0 += KB) {
+        float4 t[KB][NV];
+#pragma unroll
+        for (int kk = 0; kk < KB; ++kk)
+#pragma unroll
+            for (int i = 0; i < NV; ++i) t[kk][i] = ws[(size_t)min(k0 + kk, ksplit - 1) * n4_total + gi[i]];
+#pragma unroll
+        for (int kk = 0; kk < KB; ++kk)
+            if (k0 + kk < ksplit) {
+#pragma unroll
+                for (int i = 0; i < NV; ++i) { v[i].x += t[kk][i].x; v[i].y += t[kk][i].y; v[i].z += t[kk][i].z; v[i].w += t[kk][i].w; }
+            }
+    }
+    float gam[NV], bet[NV];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int idx = min((int)threadIdx.x + i * NT, n4 - 1);
+        const int c = g * cpg + (idx >> hw4sh);
+        float b = 0.f;
+        if (bias) b += bias[c];
+        if (vbias) b += vbias[(size_t)s * Cout + c];
+        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (res) r = res[gi[i]];
+        v[i] = make_float4(v[i].x + r.x + b, v[i].y + r.y + b, v[i].z + r.z + b, v[i].w + r.w + b);
+        gam[i] = gamma[c];
+        bet[i] = beta[c];
+        const bool ok = (int)threadIdx.x + i * NT < n4;
+        if (y && ok) y[gi[i]] = v[i];
+        if (!ok) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    const float inv_n = 1.0f / (float)(n4 * 4);
+    const float mean = block_sum<NT>(sum, red) * inv_n;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+        const float q = (a * a + b * b) + (c * c + d * d);
+        sq += (int)threadIdx.x + i * NT < n4 ? q : 0.f;
+    }
+    const float var = block_sum<NT>(sq, red) * inv_n;
+    const float rstd = 1.0f / sqrtf(var + eps);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        if ((int)threadIdx.x + i * NT < n4) {
+            const float ga = gam[i] * rstd;
+            const float be = bet[i] - mean * ga;
+            float4 o = make_float4(v[i].x * ga + be, v[i].y * ga + be, v[i].z * ga + be, v[i].w * ga + be);
+            if (silu) { o.x = silu_f(o.x); o.y = silu_f(o.y); o.z = silu_f(o.z); o.w = silu_f(o.w); }
+            a_out[gi[i]] = o;
+        }
+    }
+}
+
+// launches the fused reduce + GroupNorm for a (view, group) of n4g float4; false if the group is too large
+inline bool launch_reduce_gn(const ConvArgs& a, int ks, size_t n4_total, int HW, hipStream_t st) {
+    const int cpg = a.Cout / a.gn_groups;
+    const long n4g = (long)cpg * HW / 4;
+    int hw4sh = 0;
+    while ((1 << hw4sh) < HW / 4) ++hw4sh;
+    const dim3 grid(a.S * a.gn_groups);
+    float4* y4 = a.gn_store_y ? (float4*)a.y : nullptr;
+#define VF_RGN(NV, NT)                                                                                          \
+    {                                                                                                           \
+        hipLaunchKernelGGL((conv_splitk_reduce_gn_kernel<NV, NT>), grid, dim3(NT), 0, st, (const float4*)a.ws, a.bias, \
+                           a.vbias, (const float4*)a.res, y4, a.gn_gamma, a.gn_beta, (float4*)a.gn_out, ks, n4_total, \
+                           hw4sh, a.Cout, cpg, a.gn_eps, a.gn_silu);                                            \
+        return true;                                                                                            \
+    }
+    if (n4g <= 256) VF_RGN(1, 256)
+    if (n4g <= 512) VF_RGN(2, 256)
+    if (n4g <= 1024) VF_RGN(4, 256)
+    if (n4g <= 2048) VF_RGN(8, 256)
+    if (n4g <= 4096) VF_RGN(8, 512)
+    if (n4g <= 8192) VF_RGN(8, 1024)
+#undef VF_RGN
+    return false;
+}
+
+extern "C" int vf_gn_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, int S,
+                         int C, int HW, int groups, float eps, int silu, void* stream);
+
 // Split-K factor: only when the natural grid cannot fill the chip (small S: the sampler).  Measured over the
 // sampler's layer shapes at S = 1 / 6 / 12 (tools/small_conv.py): the fastest split is the largest one that still
 // gives every workgroup a CU of its own in a single round (nblk * k <= 256) -- a second round, or more partial
@@ -897,12 +1013,18 @@ int launch_conv_npt(ConvArgs a, hipStream_t st, long ws_floats) {
     while (ks > 1 && (size_t)ks * out_floats > (size_t)ws_floats) --ks;
     a.ksplit = ks;
     hipLaunchKernelGGL((conv_mfma_kernel<KS, LOGW, MODE, NPT, NCO>), dim3(nblk * ks), dim3(256), 0, st, a);
+    bool gn_done = false;
     if (ks > 1) {
         const size_t n4 = out_floats / 4;
-        hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st,
-                           (const float4*)a.ws, a.bias, a.vbias, (const float4*)a.res, (float4*)a.y, ks, n4, HW / 4,
-                           a.Cout);
+        if (a.gn_out) gn_done = launch_reduce_gn(a, ks, n4, HW, st);
+        if (!gn_done)
+            hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st,
+                               (const float4*)a.ws, a.bias, a.vbias, (const float4*)a.res, (float4*)a.y, ks, n4, HW / 4,
+                               a.Cout);
     }
+    if (a.gn_out && !gn_done)         // the conv wrote y itself (no split-K here): plain GroupNorm launch behind it
+        return vf_gn_fwd(a.y, a.gn_gamma, a.gn_beta, a.gn_out, a.gn_stats, a.gn_stats + (size_t)a.S * a.gn_groups, a.S,
+                         a.Cout, HW, a.gn_groups, a.gn_eps, a.gn_silu, (void*)st);
     VF_RETURN_LAST_ERROR();
 }
 
@@ -1022,9 +1144,19 @@ int vf_conv_pack_weights_multi(const void* desc, int nlayers, long total_blocks,
 // nearest-upsampled on the fly; 4: x = dY [S][Cin][H][W] of a stride-2 conv, y = dX [S][Cout][2H][2W] (w_packed =
 // the dgrad pack, no epilogue operands).
 // ws / ws_floats: optional split-K workspace (see vf_conv_fwd_ws_floats); NULL disables split-K.
+struct GnFuse {
+    const float* gamma;
+    const float* beta;
+    float* out;
+    float* stats;
+    int groups, silu, store_y;
+    float eps;
+};
+
 static int conv_fwd_impl(const float* x, const float* x2, int C1, const float* w_packed, const float* bias,
                          const float* view_bias, const float* residual, float* y, float* y2, int C1o, float* ws,
-                         long ws_floats, int S, int Cin, int Cout, int H, int W, int KS, int mode, void* stream) {
+                         long ws_floats, int S, int Cin, int Cout, int H, int W, int KS, int mode, void* stream,
+                         const GnFuse* gn = nullptr) {
     if (S <= 0) return 0;
     const int lw = ilog2_exact(W);
     if (H != W || lw < 3 || lw > 7 || (KS != 1 && KS != 3)) return (int)hipErrorInvalidValue;
@@ -1041,6 +1173,11 @@ static int conv_fwd_impl(const float* x, const float* x2, int C1, const float* w
     a.CoutP = round_up(Cout, TCO);
     a.ksplit = 1;
     a.ws = ws;
+    if (gn) {
+        if (gn->groups <= 0 || Cout % gn->groups != 0 || y2 || mode == 4) return (int)hipErrorInvalidValue;
+        a.gn_gamma = gn->gamma; a.gn_beta = gn->beta; a.gn_out = gn->out; a.gn_stats = gn->stats;
+        a.gn_groups = gn->groups; a.gn_silu = gn->silu; a.gn_store_y = gn->store_y; a.gn_eps = gn->eps;
+    }
     hipStream_t st = (hipStream_t)stream;
 #define VF_CASE(KS_, LW_, M_) \
     if (KS == KS_ && lw == LW_ && mode == M_) return launch_conv<KS_, LW_, M_>(a, st, ws_floats);
@@ -1058,6 +1195,19 @@ int vf_conv_fwd(const float* x, const float* w_packed, const float* bias, const 
                 int W, int KS, int mode, void* stream) {
     return conv_fwd_impl(x, nullptr, Cin, w_packed, bias, view_bias, residual, y, nullptr, Cout, ws, ws_floats, S, Cin,
                          Cout, H, W, KS, mode, stream);
+}
+
+// Inference fusion: a = [Swish](GroupNorm(groups)(conv(x) + bias + view_bias + residual)) with the GroupNorm evaluated by
+// the conv's split-K reduce launch where the conv runs split-K (small S: the sampler), by a plain GroupNorm launch
+// otherwise.  y (always a valid [S][Cout][H][W] buffer) holds the conv output afterwards only if store_y != 0 or the
+// unfused route was taken; gn_stats = scratch of 2*S*groups floats.
+int vf_conv_fwd_gn(const float* x, const float* w_packed, const float* bias, const float* view_bias, const float* residual,
+                   float* y, int store_y, const float* gn_gamma, const float* gn_beta, float* a_out, float* gn_stats,
+                   int groups, float eps, int silu, float* ws, long ws_floats, int S, int Cin, int Cout, int H, int W,
+                   int KS, int mode, void* stream) {
+    GnFuse gn{gn_gamma, gn_beta, a_out, gn_stats, groups, silu, store_y, eps};
+    return conv_fwd_impl(x, nullptr, Cin, w_packed, bias, view_bias, residual, y, nullptr, Cout, ws, ws_floats, S, Cin,
+                         Cout, H, W, KS, mode, stream, &gn);
 }
 
 // 1x1 conv whose input is the never-materialised channel concatenation [x1 (C1 channels) | x2 (Cin - C1)]

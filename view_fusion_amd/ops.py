@@ -664,6 +664,33 @@ def conv2d(x, layer, view_bias=None, residual=None, mode="same", twin=None):
     return _Conv2dFn.apply(x, layer.weight, layer.bias, view_bias, residual, layer, mode, training, twin)
 
 
+def conv2d_gn(x, layer, gn, groups, silu, view_bias=None, residual=None, mode="same", want_y=False):
+    """Inference only (no autograd): (y | None, a) with y = conv2d(x, layer, view_bias, residual, mode) and
+    a = [Swish](GroupNorm(gn.weight, gn.bias, groups)(y)).  Where the conv runs split-K (small S: the sampler) the
+    GroupNorm is evaluated by the conv's reduce launch -- one kernel instead of two, and y is only written if `want_y`;
+    elsewhere (Winograd path, large grids) it is the two separate ops."""
+    S, Cin, Hi, Wi = x.shape
+    Cout, _, KS, _ = layer.weight.shape
+    m = _MODES[mode]
+    H, W = (Hi // 2, Wi // 2) if m == 1 else ((Hi * 2, Wi * 2) if m == 2 else (Hi, Wi))
+    lib = _lib.load()
+    fused = (not torch.is_grad_enabled() and not use_winograd(S, Cin, Cout, H, W, KS, m) and not _use_b3(KS, m, H * W)
+             and lib.vf_conv_fwd_ws_floats(S, Cin, Cout, H, W, KS) > 0)
+    if not fused:
+        y = conv2d(x, layer, view_bias=view_bias, residual=residual, mode=mode)
+        return y, group_norm(y, gn.weight, gn.bias, groups, silu)
+    _check(x, layer.bias, view_bias, residual, gn.weight, gn.bias)
+    y = torch.empty(S, Cout, H, W, device=x.device, dtype=torch.float32)
+    a = torch.empty_like(y)
+    stats = torch.empty(2 * S * groups, device=x.device, dtype=torch.float32)
+    wf, _ = _packed(layer, force=False)
+    ws, nws = _conv_ws(x.device, S, Cin, Cout, H, W, KS)
+    _lib.call("vf_conv_fwd_gn", _ptr(x), _ptr(wf), _ptr(layer.bias), _ptr(view_bias), _ptr(residual), _ptr(y), int(want_y),
+              _ptr(gn.weight), _ptr(gn.bias), _ptr(a), _ptr(stats), groups, 1e-5, int(silu), _ptr(ws), nws, S, Cin, Cout,
+              H, W, KS, m, _stream())
+    return (y if want_y else None), a
+
+
 # ---------------------------------------------------------------------------------------------
 def _bgemm(A, B, C, bias, batch, M, N, K, sA, sB, sC, alpha=1.0, beta=0.0, offA=0, offB=0, offC=0):
     _lib.call("vf_bgemm", _ptr(A, offA), _ptr(B, offB), _ptr(C, offC), _ptr(bias), batch, M, N, K, sA[0], sA[1],

@@ -52,6 +52,28 @@ class _ResBlock(nn.Module):
         from . import ops
         return ops.dropout(a, self.dropout, next(draws) if draws is not None else None)
 
+    def _forward_inference(self, x, e, skip, a_in, next_gn):
+        """No-grad path (the sampler): the same arithmetic, with every GroupNorm that FOLLOWS a conv evaluated by that
+        conv's split-K reduce launch where it has one (ops.conv2d_gn).  a_in: GroupNorm1(x) if the producer of x already
+        computed it; next_gn = (GroupNorm holder, silu) of the consumer of this block's output, or None.
+        -> (y, next_a | None)."""
+        from . import ops
+        b1, b2 = self.block1["block"], self.block2["block"]
+        if skip is not None:
+            C1, C = x.shape[1], x.shape[1] + skip.shape[1]
+            if not (isinstance(self.res_conv, nn.Conv2d) and ops.cat_fusable(C1, C, x.shape[2] * x.shape[3], self.groups)):
+                x, skip = ops.concat_channels(x, skip), None
+        if skip is not None:
+            a, x1, x2 = ops.group_norm_cat_skip(x, skip, b1["0"].weight, b1["0"].bias, self.groups, silu=True)
+            res = ops.conv1x1_cat(x1, x2, self.res_conv)
+        else:
+            a = a_in if a_in is not None else ops.group_norm(x, b1["0"].weight, b1["0"].bias, self.groups, silu=True)
+            res = x if isinstance(self.res_conv, nn.Identity) else ops.conv2d(x, self.res_conv)
+        _, a2 = ops.conv2d_gn(a, b1["3"], b2["0"], self.groups, True, view_bias=e)
+        if next_gn is None:
+            return ops.conv2d(a2, b2["3"], residual=res), None
+        return ops.conv2d_gn(a2, b2["3"], next_gn[0], self.groups, next_gn[1], residual=res, want_y=True)
+
     def forward(self, x, e, skip=None, tap=False, draws=None):
         """tap=True (encoder blocks): also return a handle on the INPUT x for the decoder's skip connection, whose
         gradient is then added inside this block's GroupNorm backward instead of by an autograd add.
@@ -89,9 +111,13 @@ class _SelfAttention(nn.Module):
         self.out = nn.Conv2d(ch, ch, 1)
         self.groups = groups
 
-    def forward(self, x):
+    def forward(self, x, n=None):
+        """n: GroupNorm(x) when the producer of x has already evaluated it (inference fusion)."""
         from . import ops
-        n, xs = ops.group_norm_skip(x, self.norm.weight, self.norm.bias, self.groups, silu=False)
+        if n is None:
+            n, xs = ops.group_norm_skip(x, self.norm.weight, self.norm.bias, self.groups, silu=False)
+        else:
+            xs = x
         qkv = ops.conv2d(n, self.qkv)                                               # (S,3C,H,W)
         o = ops.attention(qkv)                                                      # (S,C,H,W)
         return ops.conv2d(o, self.out, residual=xs)
@@ -104,6 +130,13 @@ class _ResAttnBlock(nn.Module):
         self.res_block = _ResBlock(cin, cout, emb_dim, groups, dropout)
         if with_attn:
             self.attn = _SelfAttention(cout, groups)
+
+    def forward_inference(self, x, e, skip=None, a_in=None, next_gn=None):
+        """No-grad path: -> (y, GroupNorm_next(y) | None); see _ResBlock._forward_inference."""
+        if self.with_attn:
+            y, n = self.res_block._forward_inference(x, e, skip, a_in, (self.attn.norm, False))
+            return self.attn(y, n), None
+        return self.res_block._forward_inference(x, e, skip, a_in, next_gn)
 
     def forward(self, x, e, skip=None, tap=False, draws=None):
         xt = None
@@ -218,6 +251,42 @@ class UNet(nn.Module):
             object.__setattr__(self, "_vf_affine", lst)
         return lst
 
+    def _has_dropout(self):
+        return any(isinstance(m, _ResBlock) and m.dropout > 0 for m in self.modules())
+
+    def _forward_inference(self, x, es):
+        """The no-grad forward (sampler): same dataflow as below without the autograd handles; a residual block whose
+        output goes straight into another residual block's first GroupNorm (or into the final one) lets its last conv
+        evaluate that GroupNorm too."""
+        from . import ops
+
+        def gn1_of(layer):            # first GroupNorm of a residual block that consumes its input un-concatenated
+            return (layer.res_block.block1["block"]["0"], True) if isinstance(layer, _ResAttnBlock) else None
+
+        feats, a_next = [], None
+        downs = list(self.downs)
+        for i, layer in enumerate(downs):
+            if isinstance(layer, _ResAttnBlock):
+                nxt = downs[i + 1] if i + 1 < len(downs) else self.mid[0]
+                x, a_next = layer.forward_inference(x, next(es), a_in=a_next, next_gn=gn1_of(nxt))
+            elif isinstance(layer, _Resample):
+                x, a_next = layer(x), None
+            else:
+                x, a_next = ops.conv2d(x, layer), None
+            feats.append(x)
+        x, a_next = self.mid[0].forward_inference(x, next(es), a_in=a_next, next_gn=None)   # (attention block)
+        x, a_next = self.mid[1].forward_inference(x, next(es), a_in=None, next_gn=None)
+        ups = list(self.ups)
+        fc = self.final_conv["block"]
+        for i, layer in enumerate(ups):
+            if isinstance(layer, _ResAttnBlock):
+                last = i + 1 == len(ups)
+                x, a_next = layer.forward_inference(x, next(es), skip=feats.pop(), next_gn=(fc["0"], True) if last else None)
+            else:
+                x, a_next = layer(x), None
+        a = a_next if a_next is not None else ops.group_norm(x, fc["0"].weight, fc["0"].bias, self.norm_groups, silu=True)
+        return ops.conv2d(a, fc["3"])
+
     def forward(self, x, angle, time, dropout_u=None):
         """x (S,Cin,H,W), angle (S,1), time = noise level (S,1)  ->  (S,Cout,H,W).
         dropout_u (extra, default None = torch's device RNG): the uniform draws of the residual blocks' Dropout
@@ -232,6 +301,9 @@ class UNet(nn.Module):
         emb = ops.linear(ops.swish(emb), mlp["2"].weight, mlp["2"].bias)            # (S,inner)
         # FeatureWiseAffine of every residual block (unet.py:160-177) in one grouped launch
         es = iter(ops.time_affine_all(emb, self._affine_layers()))
+
+        if not torch.is_grad_enabled() and not (self.training and self._has_dropout()):
+            return self._forward_inference(x, es)       # (Dropout active: the general path below applies it)
 
         # feats[i] feeds the next encoder layer AND the decoder: where that next layer is a residual block, the
         # decoder takes the block's handle on its input instead (see _ResBlock.forward, tap)
