@@ -44,6 +44,9 @@ int vf_rowsum(const float* x, float* out /*[rows]*/, int rows, int len, void* st
 int vf_bias_grad(const float* dy, float* db, float* dvb, int S, int C, int HW, void* stream);
 int vf_colsum(const float* part /*[batch][S][C]*/, float* out /*[batch][C]*/, int batch, int S, int C,
               void* stream);
+/* many column sums in one launch: desc = device int64 [n][6] rows {part, out, S, C, batch, first 64-column block};
+ * total_blocks = sum over the rows of ceil(C/64) * batch.  Same arithmetic as vf_colsum per row. */
+int vf_colsum_multi(const void* desc, int n, long total_blocks, void* stream);
 
 /* ---- convolution : nn.Conv2d 3x3 / 1x1, nn.Upsample+conv, stride-2 conv,
  *      unet.py:42,189,198,214,238,255,256 (+ FeatureWiseAffine add :160-177, residual add :245,277) ---- */

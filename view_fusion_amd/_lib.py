@@ -37,6 +37,7 @@ SIGNATURES = {
     "vf_rowsum": [_P, _P, _I, _I, _P],
     "vf_bias_grad": [_P, _P, _P, _I, _I, _I, _P],
     "vf_colsum": [_P, _P, _I, _I, _I, _P],
+    "vf_colsum_multi": [_P, _I, _L, _P],
     "vf_conv_pack_sizes": [_I, _I, _I, ctypes.POINTER(_L), ctypes.POINTER(_L)],
     "vf_conv_pack_weights": [_P, _P, _P, _I, _I, _I, _P],
     "vf_conv_pack_weights_multi": [_P, _I, _L, _P],

@@ -475,6 +475,47 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ p
     if (ry == 0 && c < C) out[(size_t)blockIdx.y * C + c] = (red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]);
 }
 
+// Many column sums in ONE launch (the GroupNorm weight / bias gradients of a whole backward pass): entry e of the
+// device table = {part [batch][S][C], out [batch][C], S, C, batch, first 64-column block}; the block grid covers all
+// entries' (64-column block, batch row) pairs.  Same arithmetic and summation order as colsum_kernel.
+struct ColsumDesc {
+    const float* part;
+    float* out;
+    long long S, C, batch, first_block;
+};
+__global__ __launch_bounds__(256) void colsum_multi_kernel(const ColsumDesc* __restrict__ desc, int n) {
+    __shared__ float red[4][64];
+    const long long vb = blockIdx.x;
+    int lo = 0, hi = n;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (desc[mid].first_block <= vb) lo = mid; else hi = mid;
+    }
+    const ColsumDesc d = desc[lo];
+    const int S = (int)d.S, C = (int)d.C;
+    const int nbx = (C + 63) / 64;
+    const int rel = (int)(vb - d.first_block);
+    const int bx = rel % nbx, by = rel / nbx;
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int c = bx * 64 + cx;
+    const float* p = d.part + (size_t)by * S * C;
+    float a = 0.f;
+    if (c < C) {
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int s = ry; s < S; s += 32) {
+            float t[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t[j] = p[(size_t)min(s + 4 * j, S - 1) * C + c];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += s + 4 * j < S ? t[j] : 0.f;
+        }
+        a = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    }
+    red[ry][cx] = a;
+    __syncthreads();
+    if (ry == 0 && c < C) d.out[(size_t)by * C + c] = (red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]);
+}
+
 template <int NV, int NT>
 int launch_gn_fwd(const float* x, const float* x2, int C1, const float* gamma, const float* beta, float* y, float* mean,
                   float* rstd, int S, int C, int HW, int cpg, float eps, int silu, hipStream_t st) {
@@ -599,6 +640,14 @@ int vf_bias_grad(const float* dy, float* db, float* dvb, int S, int C, int HW, v
     if (S <= 0 || C <= 0) return 0;
     if (HW & 3) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(bias_grad_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, dy, db, dvb, S, C, HW);
+    VF_RETURN_LAST_ERROR();
+}
+
+// desc: device int64 [n][6] rows {part, out, S, C, batch, first_block}; total_blocks = sum of ceil(C/64) * batch
+int vf_colsum_multi(const void* desc, int n, long total_blocks, void* stream) {
+    if (n <= 0 || total_blocks <= 0) return 0;
+    hipLaunchKernelGGL(colsum_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const ColsumDesc*)desc, n);
     VF_RETURN_LAST_ERROR();
 }
 

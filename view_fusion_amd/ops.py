@@ -132,6 +132,57 @@ def _gout(p, *shape, like):
     return t if t is not None else torch.empty(*shape, device=like.device, dtype=torch.float32)
 
 
+# GroupNorm weight / bias gradients = column sums over the views of the per-(view, channel) partials the backward kernel
+# emits: ~70 launches of 5 us per backward pass.  Single-process training defers them: every GroupNorm backward only
+# registers its (partials, destination) pair, and ONE multi-tensor launch at the end of the backward pass (an autograd
+# engine callback) fills all destinations.  Deferral needs the destination to be adopted by AccumulateGrad without being
+# READ, so it is taken only when both parameters' .grad is None (zero_grad(set_to_none=True), what Trainer.step does);
+# with the data-parallel gradient arena active the sums stay immediate (a segment's all-reduce is launched as soon as
+# its last gradient is registered).  COLSUM_DEFER = False restores the immediate launches.
+COLSUM_DEFER = True
+_PENDING_COLSUMS = []
+
+
+_CS_TABLE = {}          # device -> [rows (Python), pinned staging tensor, device table, copy-done event]
+
+
+def _flush_colsums():
+    global _PENDING_COLSUMS
+    pend, _PENDING_COLSUMS = _PENDING_COLSUMS, []
+    if not pend:
+        return
+    rows, first = [], 0
+    for parts, dgb, batch, S, C in pend:
+        rows.append([parts.data_ptr(), dgb.data_ptr(), S, C, batch, first])
+        first += ((C + 63) // 64) * batch
+    dev = pend[0][0].device
+    ent = _CS_TABLE.get(dev)
+    if ent is None or ent[1].shape[0] < len(rows):
+        n = max(128, len(rows))
+        ent = [None, torch.empty(n, 6, dtype=torch.int64).pin_memory(), torch.empty(n, 6, dtype=torch.int64, device=dev),
+               torch.cuda.Event()]
+        _CS_TABLE[dev] = ent
+    if ent[0] != rows:          # the caching allocator hands every step the same addresses: usually nothing to upload
+        ent[3].synchronize()    # (the previous upload has long finished; never overwrite a staging buffer in flight)
+        ent[1][:len(rows)].copy_(torch.tensor(rows, dtype=torch.int64))
+        ent[2][:len(rows)].copy_(ent[1][:len(rows)], non_blocking=True)
+        ent[3].record()
+        ent[0] = rows
+    _lib.call("vf_colsum_multi", ctypes.c_void_p(ent[2].data_ptr()), len(rows), first, _stream())
+    _flush_colsums.keep = pend          # the partials / destinations stay referenced until the next flush
+
+
+def _colsum(parts, dgb, batch, S, C, params):
+    """dgb[b][c] = sum_s parts[b][s][c], now or (see above) at the end of the running backward pass."""
+    if (COLSUM_DEFER and reducer.ACTIVE is None and all(p is not None and p.grad is None for p in params)
+            and torch._C._current_graph_task_id() != -1):
+        if not _PENDING_COLSUMS:
+            torch.autograd.Variable._execution_engine.queue_callback(_flush_colsums)
+        _PENDING_COLSUMS.append((parts, dgb, batch, S, C))
+        return
+    _lib.call("vf_colsum", _ptr(parts), _ptr(dgb), batch, S, C, _stream())
+
+
 def _gn_backward(ctx, dy, addend, addend2=None):
     x, gamma, beta, mean, rstd = ctx.saved_tensors
     dy = _c(dy)
@@ -152,7 +203,7 @@ def _gn_backward(ctx, dy, addend, addend2=None):
     dgb = reducer.ACTIVE.slot_pair(*ctx.gb) if reducer.ACTIVE is not None else None
     if dgb is None:
         dgb = torch.empty(2, C, device=x.device, dtype=torch.float32)
-    _lib.call("vf_colsum", _ptr(parts), _ptr(dgb), 2, S, C, _stream())
+    _colsum(parts, dgb, 2, S, C, ctx.gb)
     return dx, dgb[0], dgb[1]
 
 
@@ -226,7 +277,7 @@ class _GroupNormCatSkipFn(torch.autograd.Function):
         dgb = reducer.ACTIVE.slot_pair(*ctx.gb) if reducer.ACTIVE is not None else None
         if dgb is None:
             dgb = torch.empty(2, C, device=x1.device, dtype=torch.float32)
-        _lib.call("vf_colsum", _ptr(parts), _ptr(dgb), 2, S, C, _stream())
+        _colsum(parts, dgb, 2, S, C, ctx.gb)
         return dx1, dx2, dgb[0], dgb[1], None, None
 
 
