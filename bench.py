@@ -120,7 +120,14 @@ def cpu_baseline(hw, n_views, threads_all=None):
     for th in sorted({t for t in (8, 16, 32, 64, threads_all) if t <= threads_all}):
         calib[th] = train_leg(2, 1, th)[0]
     best = max(calib, key=calib.get)
-    threads_max, threads_all = threads_all, best
+    threads_max = threads_all
+    # the bench workload itself is eight times larger than the calibration sample: let it also try two and four times the
+    # calibrated thread count (one iteration each) before the timed pair
+    c2_calib = {}
+    for th in sorted({t for t in (best, 2 * best, 4 * best) if t <= threads_max}):
+        c2_calib[th] = train_leg(16, 1, th)[0]
+    best = max(c2_calib, key=c2_calib.get)
+    threads_all = best
     v_c2, dt_c2 = train_leg(16, 2, best)
     v_c4, dt_c4 = train_leg(8, 2, best)
     v_c1, dt_c1 = train_leg(2, 1, best, N=2)
@@ -131,6 +138,7 @@ def cpu_baseline(hw, n_views, threads_all=None):
     return dict(value=v_c2, unit="view denoise-steps/s", cores=threads_all, kind="port",
                 cpu_model=_cpu_model(), logical_cpus=os.cpu_count(), torch=torch.__version__,
                 thread_calibration={str(k): v for k, v in calib.items()},
+                thread_calibration_b16={str(k): v for k, v in c2_calib.items()},
                 sample=f"C2, the bench workload itself: oracle training iteration (fwd+bwd+Adam), small UNet {hw}x{hw}, "
                        f"B=16 N={n_views} ({16 * n_views} views), 2 timed iterations after 1 warm-up, {dt_c2:.2f} s/iteration, "
                        f"{threads_all} threads (the fastest of the calibrated counts; the host offers {threads_max})",
