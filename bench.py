@@ -69,7 +69,7 @@ def cpu_baseline(hw, n_views, threads_all=None):
     hp = train.SMALL_UNET
     threads_all = threads_all or torch.get_num_threads()
 
-    def train_leg(B, iters, threads, N=n_views):
+    def train_leg(B, iters, threads, N=n_views, warm=True):
         torch.set_num_threads(threads)
         torch.manual_seed(0)
         sd = {k: v.clone().requires_grad_(True) for k, v in UNet(**hp).state_dict().items()}
@@ -87,7 +87,8 @@ def cpu_baseline(hw, n_views, threads_all=None):
             loss.backward()
             opt.step()
 
-        one()                                     # warm-up (oneDNN primitive creation)
+        if warm:
+            one()                                 # warm-up (oneDNN primitive creation)
         t0 = time.perf_counter()
         for _ in range(iters):
             one()
@@ -125,7 +126,7 @@ def cpu_baseline(hw, n_views, threads_all=None):
     # calibrated thread count (one iteration each) before the timed pair
     c2_calib = {}
     for th in sorted({t for t in (best, 2 * best, 4 * best) if t <= threads_max}):
-        c2_calib[th] = train_leg(16, 1, th)[0]
+        c2_calib[th] = train_leg(16, 1, th, warm=False)[0]      # (12 s per iteration: the warm-up share is negligible)
     best = max(c2_calib, key=c2_calib.get)
     threads_all = best
     v_c2, dt_c2 = train_leg(16, 2, best)
