@@ -3,7 +3,7 @@
 //     dW (3x3) = G4^T [ sum_tiles (A4 dY A4^T) (.) (B4^T d B4) ] G4       dY = 4x4 output-gradient tile, d = 6x6 window
 //
 // 36 products per 16 pixels and (co, ci) pair = 2.25 multiplies per pixel instead of 9 (direct) or 4 (the F(2x2,3x3)
-// kernel this replaces, winograd.hip).  fp32 throughout.  Error of the resulting dW against an fp64 correlation
+// kernel of rounds 1-2, experiments/winograd_f22_wgrad.hip.txt).  fp32 throughout.  Error of the resulting dW against an fp64 correlation
 // (random data, K = 1536 ... 24576 tiles): rel-L2 7e-6 (direct fp32 accumulation: 3e-6, F(2x2): 2e-6) -- the sum over
 // tiles runs in the transformed domain, the 4-point constants (4, 8, 1/6, 1/24) enter once per axis; the tolerance
 // of the gradient tests is 1e-4.  (The forward / dgrad kernel keeps the milder nested F(2,3)xF(4,3): an activation
@@ -27,7 +27,6 @@
 // of the 36-slice dU.  wino44_reduce_kernel sums the slabs in a fixed order (no float atomics) and writes dW (one
 // follow-up launch instead of the F(2x2) kernel's two).
 #include "common.h"
-#include <stdlib.h>
 
 namespace {
 inline int rup44(int v, int m) { return (v + m - 1) / m * m; }
@@ -228,9 +227,6 @@ __global__ __launch_bounds__(512, 2) void wino44_wgrad_kernel(W44Args a) {
             R = *(const VF_G1 float*)((const VF_G1 char*)b_ + o_);                                        \
         }                                                                                                 \
     }
-#ifdef VF_ABL_NOGLOAD
-#define VF_LOAD_X(K, SET)
-#else
 #define VF_LOAD_X(K, SET)                                                                                 \
     {                                                                                                     \
         VF_XLOAD1(K, 0, xr0##SET);                                                                        \
@@ -239,7 +235,6 @@ __global__ __launch_bounds__(512, 2) void wino44_wgrad_kernel(W44Args a) {
         VF_HLOAD1(K, 0, xh0##SET);                                                                        \
         VF_HLOAD1(K, 1, xh1##SET);                                                                        \
     }
-#endif
     // strip pixels sit at odd dword offsets (idx 5 + 4q): four ds_write_b32 (as two ds_write2_b32) per float4 -- same LDS
     // cost as one ds_write_b128 (MI355X_MICROARCH.md, LDS table)
 #define VF_XSTORE1(K, BUF, I, R)                                                                          \
@@ -257,9 +252,6 @@ __global__ __launch_bounds__(512, 2) void wino44_wgrad_kernel(W44Args a) {
             if (VF_LANES((K).left ? EVEN_LANES : ((K).right ? ODD_LANES : 0ull))) d_[0] = 0.f;            \
         }                                                                                                 \
     }
-#ifdef VF_ABL_NOSTRIP
-#define VF_STORE_X(K, BUF, SET)
-#else
 #define VF_STORE_X(K, BUF, SET)                       /* K: the chunk the registers hold */                  \
     {                                                                                                     \
         VF_XSTORE1(K, BUF, 0, xr0##SET);                                                                  \
@@ -268,11 +260,7 @@ __global__ __launch_bounds__(512, 2) void wino44_wgrad_kernel(W44Args a) {
         VF_HSTORE1(K, BUF, 0, xh0##SET);                                                                  \
         VF_HSTORE1(K, BUF, 1, xh1##SET);                                                                  \
     }
-#endif
     auto load_dy = [&](const Chunk& k) {
-#ifdef VF_ABL_NOGLOAD
-        return;
-#endif
         {
             const char* b = k.db;
             unsigned& o = dyoffb;
@@ -298,10 +286,6 @@ __global__ __launch_bounds__(512, 2) void wino44_wgrad_kernel(W44Args a) {
         const f32x2 m12 = pk_lo_pm_hi(eo, eo);
         const f32x2 m34 = pk_lo_pm_2hi(pk_fmak<4>(pb, pa));
         if (i == 1 && count) bias1 += m12.x;
-#ifdef VF_ABL_NOLDSW
-        asm volatile("" :: "v"(m12), "v"(m34));
-        return;
-#endif
         mo[(6 * i + 0) * (CO44 * GT44)] = pa.x;
         mo[(6 * i + 1) * (CO44 * GT44)] = m12.x;
         mo[(6 * i + 2) * (CO44 * GT44)] = m12.y;
@@ -370,10 +354,6 @@ __global__ __launch_bounds__(512, 2) void wino44_wgrad_kernel(W44Args a) {
         const f32x2 c12 = pk_lo_pm_hi(P2, Q);
         const f32x2 E = pk_sub(p45, p23), F = pk_sub(p23, p01);
         const f32x2 c34 = pk_xlo_pm_2yhi(E, F);
-#ifdef VF_ABL_NOLDSW
-        asm volatile("" :: "v"(c05), "v"(c12), "v"(c34));
-        return;
-#endif
         vo[0 * (CI44 * GT44)] = c05.x;
         vo[1 * (CI44 * GT44)] = c12.x;
         vo[2 * (CI44 * GT44)] = c12.y;
@@ -431,18 +411,6 @@ __global__ __launch_bounds__(512, 2) void wino44_wgrad_kernel(W44Args a) {
         AD = *reinterpret_cast<const f32x2*>(Ml + (PAR_) * MSZ + aoff + VF_SL(K_) * (CO44 * GT44));       \
         BD = *reinterpret_cast<const f32x2*>(Vl + (PAR_) * VSZ + boff + VF_SL(K_) * (CI44 * GT44));       \
     }
-    // timing ablations (diagnostic builds only; results are wrong): -DVF_ABL_NOSIDE drops the side work of the chunk
-    // loop, -DVF_ABL_NOBAR its barrier
-#ifdef VF_ABL_NOSIDE
-#define VF_ABL_SIDE(X)
-#else
-#define VF_ABL_SIDE(X) X
-#endif
-#ifdef VF_ABL_NOBAR
-#define VF_ABL_BARRIER()
-#else
-#define VF_ABL_BARRIER() __syncthreads()
-#endif
 #ifdef VF_STAMPS44
 #define VF_ST44_ACC1() { st_a += t_c1 - t_c0; st_b += t_c2 - t_c1; t_mid = t_c2; }
 #define VF_ST44_ACC2() { const unsigned long long t_c3 = __builtin_amdgcn_s_memtime(); st_c += t_c3 - t_mid; st_n += 1; }
@@ -460,10 +428,10 @@ __global__ __launch_bounds__(512, 2) void wino44_wgrad_kernel(W44Args a) {
             VF_MF(k, a_cur.x, b_cur.x, FIRST);                                                            \
             if (k < 7) { VF_FRAG(a2, b2, PAR, k + 2); }                                                   \
             else { VF_FRAG(a2, b2, (PAR) ^ 1, k - 7); }   /* behind the barrier: chunk C+1, slices 0 and 1 */ \
-            VF_ABL_SIDE(SIDE(C, PAR, k, 0, kn2, kn4, SP));                                                  \
+            SIDE(C, PAR, k, 0, kn2, kn4, SP);                                                               \
             VF_MF(k, a_cur.y, b_cur.y, false);                                                            \
-            VF_ABL_SIDE(SIDE(C, PAR, k, 1, kn2, kn4, SP));                                                  \
-            if (k == 6) { VF_ST44(t_c1); VF_ABL_BARRIER(); VF_ST44(t_c2); VF_ST44_ACC1(); }              \
+            SIDE(C, PAR, k, 1, kn2, kn4, SP);                                                               \
+            if (k == 6) { VF_ST44(t_c1); __syncthreads(); VF_ST44(t_c2); VF_ST44_ACC1(); }              \
             a_cur = a_nx; b_cur = b_nx; a_nx = a2; b_nx = b2;                                             \
         }                                                                                                 \
         VF_ST44_ACC2();                                                                                   \
@@ -613,14 +581,7 @@ __global__ __launch_bounds__(512, 2) void wino44_wgrad_kernel(W44Args a) {
         for (int k = 0; k < 9; ++k)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-            {
-                const float v_ = acc[k][r] + o[(k * 16 + r) * 64];
-#ifdef VF_ABL_NOSTORE
-                asm volatile("" :: "v"(v_));
-#else
-                sb[(size_t)k * kst + ((r & 3) + 8 * (r >> 2)) * a.CinQ] = v_;
-#endif
-            }
+                sb[(size_t)k * kst + ((r & 3) + 8 * (r >> 2)) * a.CinQ] = acc[k][r] + o[(k * 16 + r) * 64];
     }
 #ifdef VF_STAMPS44
     if (lane == 0) {
@@ -739,24 +700,9 @@ int launch_wino44_wgrad(W44Args a, float* dw, float* db, float* db2, size_t ws_f
 }  // namespace
 
 extern "C" {
-// the F(2x2,3x3) kernel this one replaces (winograd.hip), kept for A/B timing: VF_WGRAD_F22=1 selects it
-long vf_wino22_wgrad_ws_floats(int S, int Cin, int Cout, int H, int W);
-int vf_wino22_wgrad(const float* x, const float* dy, float* dw, float* db, float* db2, float* ws, long ws_floats, int S,
-                    int Cin, int Cout, int H, int W, int mode, void* stream);
-}
-
-namespace {
-bool use_f22() {
-    static const bool v = [] { const char* e = getenv("VF_WGRAD_F22"); return e && e[0] == '1'; }();
-    return v;
-}
-}  // namespace
-
-extern "C" {
 
 // workspace floats for vf_wino_wgrad at this shape (slabs of transformed partial gradients + per-slice dY sums)
 long vf_wino_wgrad_ws_floats(int S, int Cin, int Cout, int H, int W) {
-    if (use_f22()) return vf_wino22_wgrad_ws_floats(S, Cin, Cout, H, W);
     const long slab = 9L * rup44(Cout, CO44) * rup44(Cin, CI44);
     const int nco = rup44(Cout, CO44) / CO44, nci = rup44(Cin, CI44) / CI44;
     long z = 256 / (nco * nci);
@@ -778,7 +724,6 @@ int vf_wino_wgrad(const float* x, const float* dy, float* dw, float* db, float* 
                   int Cin, int Cout, int H, int W, int mode, void* stream) {
     if (S <= 0) return 0;
     if (!vf_wino_wgrad_supported(H, W, mode)) return (int)hipErrorInvalidValue;
-    if (use_f22()) return vf_wino22_wgrad(x, dy, dw, db, db2, ws, ws_floats, S, Cin, Cout, H, W, mode, stream);
     W44Args a;
     a.x = x; a.dy = dy; a.ws = ws; a.S = S; a.Cin = Cin; a.Cout = Cout;
     a.CoutP = rup44(Cout, CO44); a.CinQ = rup44(Cin, CI44);
