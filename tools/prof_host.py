@@ -17,6 +17,14 @@ t1 = time.perf_counter()
 torch.cuda.synchronize()
 t2 = time.perf_counter()
 print(f"host enqueue time per step {1e3 * (t1 - t0) / 5:.2f} ms; wall incl. drain {1e3 * (t2 - t0) / 5:.2f} ms")
+single = []
+for _ in range(5):                      # one step at a time from an EMPTY queue: no back-pressure from the launch queue
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    tr.step(batch)
+    single.append(time.perf_counter() - t0)
+torch.cuda.synchronize()
+print("host enqueue time of single steps from an empty queue, ms:", " ".join(f"{1e3 * t:.2f}" for t in single))
 pr = cProfile.Profile()
 pr.enable()
 for _ in range(3):
