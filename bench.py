@@ -322,6 +322,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-sampler", action="store_true")
+    ap.add_argument("--graph", type=int, default=int(os.environ.get("VF_STEP_GRAPH", "0")),
+                    help="1: replay the iteration as one HIP graph (single process, fixed view_count); 0: eager launches")
     args = ap.parse_args()
 
     rank, local_rank, world = train.init_distributed()
@@ -330,7 +332,7 @@ def main():
     torch.cuda.set_device(dev)
 
     model = train.build_model(device=str(dev), seed=0)
-    trainer = train.Trainer(model, world=world, local_rank=local_rank)
+    trainer = train.Trainer(model, world=world, local_rank=local_rank, graph=bool(args.graph))
     batch = train.synthetic_batch(args.batch, args.views, 64, dev, seed=rank, ragged=args.ragged)
     S = int(batch["view_count"].sum())
 
@@ -339,7 +341,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    # a graph is captured on the (GRAPH_AFTER+1)-th iteration of a geometry: keep the capture out of the timed region
+    for _ in range(max(args.warmup, train.Trainer.GRAPH_AFTER + 1) if trainer.use_graph else args.warmup):
         trainer.step(batch)
     barrier()
     t0 = time.perf_counter()
@@ -368,7 +371,8 @@ def main():
                                    "iteration fwd+bwd+Adam, linear T=2000 schedule%s" % (args.batch, args.views, S,
                                                                                      ", ragged view_count" if args.ragged else ""),
                        "global_batch": args.batch * world, "views": args.views,
-                       "parallelism": "dp%d" % world},
+                       "parallelism": "dp%d" % world,
+                       "launch": "HIP-graph replay of the whole iteration" if trainer.graph_steps else "eager launches"},
             "iters_per_sec": args.steps / dt, "loss": loss_val,
             "achieved_tflops_total": 62.98e9 * S * world * args.steps / dt / 1e12,
         }

@@ -185,6 +185,12 @@ int vf_psnr(const float* generated, const float* target, float* out /*[B]*/, int
  * desc = device int64 [ntensors][6] rows {p, g, exp_avg, exp_avg_sq, numel, first_block}, block = 1024 elems */
 int vf_adam_multi(const void* desc, int ntensors, long total_blocks, float lr, float beta1, float beta2, float eps,
                   float bias_correction1, float bias_correction2, void* stream);
+/* the same update with {lr, 1-beta1^t, 1-beta2^t} read from device memory (float[3]) at run time: the form a HIP-graph
+ * capture of the training step uses */
+int vf_adam_multi_dev(const void* desc, int ntensors, long total_blocks, const float* scalars, float beta1, float beta2,
+                      float eps, void* stream);
+/* scalars[0..2] = {lr, bc1, bc2}, enqueued on `stream` (values carried as launch arguments) */
+int vf_adam_set_scalars(float* scalars, float lr, float bc1, float bc2, void* stream);
 
 #ifdef __cplusplus
 }

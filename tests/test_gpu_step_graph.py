@@ -1,0 +1,121 @@
+"""The whole training iteration replayed as one HIP graph (train.Trainer(graph=True)) against the same iteration
+enqueued launch by launch: the same kernels on the same data, so parameters, optimizer state and losses are compared
+BIT FOR BIT, with the random draws injected (t, u, noise are graph inputs) and with torch's device RNG."""
+import copy
+
+import pytest
+import torch
+
+from conftest import SMALL, TINY
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _pair(hp, seed=3):
+    from view_fusion_amd import train
+    a = train.build_model(unet_params=hp, device=DEV, seed=seed)
+    b = copy.deepcopy(a)
+    return a, b
+
+
+def _batches(n, B, N, hw, ragged=False):
+    from view_fusion_amd import train
+    return [train.synthetic_batch(B, N, hw, device=DEV, seed=100 + i, ragged=ragged) for i in range(n)]
+
+
+def _draws(i, B, hw, T=2000):
+    g = torch.Generator().manual_seed(900 + i)
+    return dict(t=torch.randint(1, T, (B,), generator=g).to(DEV), u=torch.rand(B, 1, generator=g).to(DEV),
+                noise=torch.randn(B, 3, hw, hw, generator=g).to(DEV))
+
+
+def _same(ma, mb):
+    for (k, p), q in zip(ma.named_parameters(), mb.parameters()):
+        assert torch.equal(p, q), k
+
+
+@pytest.mark.parametrize("hp,B,N,hw", [(TINY, 2, 3, 16), (SMALL, 4, 2, 64)])
+def test_graph_step_matches_eager_bitwise_with_injected_draws(hp, B, N, hw):
+    from view_fusion_amd import train
+    ma, mb = _pair(hp)
+    ta, tb = train.Trainer(ma, graph=False, lr_warmup=4), train.Trainer(mb, graph=True, lr_warmup=4)
+    batches = _batches(6, B, N, hw)
+    vc = batches[0]["view_count"]
+    for i, bt in enumerate(batches):
+        bt["view_count"] = vc                        # one geometry
+        la, lb = ta.step(bt, **_draws(i, B, hw)), tb.step(bt, **_draws(i, B, hw))
+        assert torch.equal(la, lb), i
+        _same(ma, mb)
+    assert ta.graph_steps == 0 and tb.graph_steps == 6 - train.Trainer.GRAPH_AFTER
+    # .grad shows the last iteration's gradients, the optimizer state continues where the eager one is
+    for p, q in zip(ma.parameters(), mb.parameters()):
+        assert torch.equal(p.grad, q.grad)
+    sa, sb = ta.opt.state_dict()["state"], tb.opt.state_dict()["state"]
+    for k in sa:
+        assert float(sa[k]["step"]) == float(sb[k]["step"]) == 6
+        assert torch.equal(sa[k]["exp_avg"], sb[k]["exp_avg"]) and torch.equal(sa[k]["exp_avg_sq"], sb[k]["exp_avg_sq"])
+    # an eager iteration after the replays (a kernel log forces it) continues from the same state
+    bt = batches[0]
+    la, lb = ta.step(bt, **_draws(9, B, hw)), tb.step(bt, **_draws(9, B, hw), y_t=None)   # y_t: not a graph input
+    assert torch.equal(la, lb)
+    _same(ma, mb)
+
+
+def test_graph_step_with_device_rng_matches_eager():
+    """No injection: the captured draws (randint, rand, randn) advance torch's Philox offset per replay exactly as
+    the eager launches do, so two runs from the same seed stay identical."""
+    from view_fusion_amd import train
+    ma, mb = _pair(TINY)
+    ta, tb = train.Trainer(ma, graph=False), train.Trainer(mb, graph=True)
+    bt = _batches(1, 2, 3, 16)[0]
+    la, lb = [], []
+    torch.manual_seed(11)
+    for _ in range(5):
+        la.append(ta.step(bt))
+    torch.manual_seed(11)
+    for _ in range(5):
+        lb.append(tb.step(bt))
+    assert tb.graph_steps == 3
+    assert len({float(x) for x in lb}) == 5           # every replay drew new (t, u, noise)
+    assert all(torch.equal(x, y) for x, y in zip(la, lb))
+    _same(ma, mb)
+
+
+def test_graph_step_two_geometries_and_ragged_fallback():
+    from view_fusion_amd import train
+    ma, mb = _pair(TINY)
+    ta, tb = train.Trainer(ma, graph=False), train.Trainer(mb, graph=True)
+    b1, b2 = _batches(2, 2, 3, 16)
+    b2["view_count"] = torch.tensor([1, 2])
+    order = [b1, b1, b2, b2, b1, b2, b1, b2, b2, b1]
+    for i, bt in enumerate(order):
+        la, lb = ta.step(bt, **_draws(i, 2, 16)), tb.step(bt, **_draws(i, 2, 16))
+        assert torch.equal(la, lb), i
+        for p, q in zip(ma.parameters(), mb.parameters()):
+            assert torch.equal(p, q) and torch.equal(p.grad, q.grad)
+    assert tb.graph_steps == 6 and len(tb._graphs) == 2
+    # a device-resident view_count is never read back per step: eager
+    b3 = dict(b1, view_count=b1["view_count"].to(DEV))
+    n = tb.graph_steps
+    assert torch.equal(ta.step(b3, **_draws(20, 2, 16)), tb.step(b3, **_draws(20, 2, 16)))
+    assert tb.graph_steps == n
+    _same(ma, mb)
+
+
+def test_sampling_after_graph_steps_sees_updated_weights():
+    """The packed-weight caches of the inference path are keyed on the parameters' version counters, which every
+    replay bumps: a sampler call after replays must not reuse packs made before them."""
+    from view_fusion_amd import train
+    ma, mb = _pair(TINY)
+    ta, tb = train.Trainer(ma, graph=False, lr_warmup=2), train.Trainer(mb, graph=True, lr_warmup=2)
+    bt = _batches(1, 2, 3, 16)[0]
+    y_t = torch.randn(2, 3, 16, 16, device=DEV)
+    t = torch.tensor([7, 3], device=DEV)
+    z = torch.randn(2, 3, 16, 16, device=DEV)
+    for i in range(5):
+        ta.step(bt, **_draws(i, 2, 16)), tb.step(bt, **_draws(i, 2, 16))
+        ya = ma.p_sample(y_t, bt["y_cond"], bt["view_count"], bt["angle"], t, z=z)[0]
+        yb = mb.p_sample(y_t, bt["y_cond"], bt["view_count"], bt["angle"], t, z=z)[0]
+        assert torch.equal(ya, yb), i
+    assert tb.graph_steps == 3

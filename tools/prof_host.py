@@ -4,7 +4,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from view_fusion_amd import train
 dev = "cuda:0"
 model = train.build_model(device=dev, phase="train")
-tr = train.Trainer(model)
+GRAPH = os.environ.get("VF_STEP_GRAPH") == "1"
+tr = train.Trainer(model, graph=GRAPH)
+print("whole-step HIP graph:", "on" if GRAPH else "off")
 batch = train.synthetic_batch(16, 6, 64, device=dev, seed=0)
 for _ in range(3):
     tr.step(batch)

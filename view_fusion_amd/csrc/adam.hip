@@ -17,8 +17,12 @@ struct AdamDesc {
 
 constexpr int ADAM_PER_BLOCK = 1024;   // 256 threads x 4 elements
 
+// scal (or null): device float[3] {lr, bc1, bc2} read at run time instead of the launch arguments -- a HIP-graph replay
+// of the training step takes the step-dependent scalars from memory the host refreshes before every replay
 __global__ __launch_bounds__(256) void adam_multi_kernel(const AdamDesc* __restrict__ desc, int ntensors, float lr,
-                                                         float b1, float b2, float eps, float bc1, float bc2) {
+                                                         float b1, float b2, float eps, float bc1, float bc2,
+                                                         const float* __restrict__ scal) {
+    if (scal) { lr = scal[0]; bc1 = scal[1]; bc2 = scal[2]; }
     int lo = 0, hi = ntensors;
     while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
@@ -61,7 +65,30 @@ int vf_adam_multi(const void* desc, int ntensors, long total_blocks, float lr, f
                   float bc1, float bc2, void* stream) {
     if (ntensors <= 0 || total_blocks <= 0) return 0;
     hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream,
-                       (const AdamDesc*)desc, ntensors, lr, beta1, beta2, eps, bc1, bc2);
+                       (const AdamDesc*)desc, ntensors, lr, beta1, beta2, eps, bc1, bc2, (const float*)nullptr);
+    VF_RETURN_LAST_ERROR();
+}
+
+__global__ void adam_set_scalars_kernel(float* dst, float a, float b, float c) {
+    dst[0] = a; dst[1] = b; dst[2] = c;
+}
+
+// dst[0..2] = {lr, bc1, bc2}: the values travel as launch arguments (copied at enqueue time), so the host may run any
+// number of replays ahead of the GPU without a staging buffer to guard
+int vf_adam_set_scalars(float* dst, float lr, float bc1, float bc2, void* stream) {
+    if (!dst) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(adam_set_scalars_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, dst, lr, bc1, bc2);
+    VF_RETURN_LAST_ERROR();
+}
+
+// the same update with {lr, 1-beta1^t, 1-beta2^t} read from device memory (scalars: float[3]) when the kernel runs: the
+// form a captured training step uses (the host rewrites the three floats before every graph replay)
+int vf_adam_multi_dev(const void* desc, int ntensors, long total_blocks, const float* scalars, float beta1, float beta2,
+                      float eps, void* stream) {
+    if (ntensors <= 0 || total_blocks <= 0) return 0;
+    if (!scalars) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const AdamDesc*)desc, ntensors, 0.f, beta1, beta2, eps, 1.f, 1.f, scalars);
     VF_RETURN_LAST_ERROR();
 }
 

@@ -147,10 +147,34 @@ _CS_TABLE = {}          # device -> {"rows": last uploaded table, "ring": [[pinn
 _CS_RING = 4            # staging buffers in rotation: an upload never waits for a copy younger than four backward passes
 
 
+_CAPTURE_FIXUPS = []    # [(device table, host rows, keep-alive)] of launches recorded into a stream capture, see below
+
+
+def end_capture():
+    """A captured training step (train.Trainer) launches its table-driven kernels on device tables whose CONTENTS are
+    only needed when the graph is replayed: they are uploaded here, after the capture has ended, with ordinary copies
+    -- no host-to-device copy node (and no pinned staging buffer to keep stable) inside the graph.  Returns what the
+    graph's owner must keep referenced for as long as it replays the graph."""
+    fix = list(_CAPTURE_FIXUPS)
+    del _CAPTURE_FIXUPS[:]
+    for tab, rows, _ in fix:
+        tab.copy_(rows)
+    return fix
+
+
 def _flush_colsums():
     global _PENDING_COLSUMS
     pend, _PENDING_COLSUMS = _PENDING_COLSUMS, []
     if not pend:
+        return
+    if torch.cuda.is_current_stream_capturing():
+        rows, first = [], 0
+        for parts, dgb, batch, S, C in pend:
+            rows.append([parts.data_ptr(), dgb.data_ptr(), S, C, batch, first])
+            first += ((C + 63) // 64) * batch
+        tab = torch.empty(len(rows), 6, dtype=torch.int64, device=pend[0][0].device)
+        _lib.call("vf_colsum_multi", ctypes.c_void_p(tab.data_ptr()), len(rows), first, _stream())
+        _CAPTURE_FIXUPS.append((tab, torch.tensor(rows, dtype=torch.int64), pend))
         return
     key = tuple(v for e in pend for v in (e[0].data_ptr(), e[1].data_ptr(), e[3], e[4]))
     dev = pend[0][0].device

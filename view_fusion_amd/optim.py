@@ -73,6 +73,51 @@ class FusedAdam(torch.optim.Optimizer):
         super().load_state_dict(sd)
         self._plans = {}
 
+    # -- HIP-graph capture of a whole training step (train.Trainer) ------------------------------------------------
+    # A captured step cannot carry step-dependent launch arguments, so the update reads {lr, 1-b1^t, 1-b2^t} from three
+    # device floats that `graph_tick` refreshes (as launch arguments of a one-thread kernel) before every replay.
+    def graph_begin(self):
+        """Handle for capturing `step_captured`, or None when the update is not ONE launch over ALL parameters (more
+        than one group or bucket, a parameter without state yet): the caller then stays on the eager path."""
+        if len(self.param_groups) != 1:
+            return None
+        plan = self._plans.get(0)
+        if plan is None or len(plan["buckets"]) != 1:
+            return None
+        b = plan["buckets"][0]
+        if len(b["params"]) != len(self.param_groups[0]["params"]):
+            return None
+        rows = b["host"][0].clone()
+        return dict(bucket=b, rows=rows, dev=torch.empty(rows.shape, dtype=torch.int64, device=b["params"][0].device))
+
+    @torch.no_grad()
+    def step_captured(self, h, scalars):
+        """Inside the capture, after backward(): the one multi-tensor launch.  The descriptor table's contents (the
+        gradient addresses this capture allocated) are uploaded by `graph_end` once the capture has ended."""
+        b, group = h["bucket"], self.param_groups[0]
+        b1, b2 = group["betas"]
+        _lib.call("vf_adam_multi_dev", ctypes.c_void_p(h["dev"].data_ptr()), len(b["params"]), b["blocks"],
+                  ctypes.c_void_p(scalars.data_ptr()), float(b1), float(b2), float(group["eps"]),
+                  ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+
+    def graph_end(self, h):
+        grads = [p.grad for p in h["bucket"]["params"]]
+        if any(g is None or not g.is_contiguous() for g in grads):
+            raise _lib.VFHipError("captured training step: a parameter received no (or a strided) gradient")
+        h["rows"][:, 1] = torch.tensor([g.data_ptr() for g in grads], dtype=torch.int64)
+        h["dev"].copy_(h["rows"])
+        h["grads"] = grads                             # the graph writes these allocations on every replay
+        return h
+
+    def graph_tick(self, h, scalars):
+        """Before a replay: advance the step count and hand the replay its learning rate and bias corrections."""
+        b, group = h["bucket"], self.param_groups[0]
+        b["t"] += 1
+        b1, b2 = group["betas"]
+        _lib.call("vf_adam_set_scalars", ctypes.c_void_p(scalars.data_ptr()), float(group["lr"]), 1.0 - b1 ** b["t"],
+                  1.0 - b2 ** b["t"], ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        torch.autograd.graph.increment_version(b["params"])
+
     # -- the step ------------------------------------------------------------------------------------------------
     @torch.no_grad()
     def step(self, closure=None):

@@ -96,8 +96,30 @@ def build_model(unet_params=None, beta_schedule=None, device="cuda", phase="trai
     return vf
 
 
+class _StepGraph:
+    """One captured training iteration (forward, backward, Adam) for one batch geometry."""
+    __slots__ = ("graph", "inputs", "view_count", "loss", "adam", "keep", "seen")
+
+    def __init__(self):
+        self.graph, self.seen = None, 0
+
+
 class Trainer:
-    def __init__(self, model, world=1, local_rank=0, lr_warmup=2500, decay_it=4000000, bucket_cap_mb=32):
+    """The reference's iteration (experiment.py:265-293) around `model`.
+
+    graph (default: the VF_STEP_GRAPH environment variable, off unless "1"): single-process GPU runs replay the WHOLE
+    iteration -- weight packs, forward, backward, the multi-tensor Adam launch: ~1000 kernels -- as one HIP graph per
+    batch geometry (tensor shapes + the view_count values) instead of enqueueing it launch by launch.  A geometry is
+    captured after it has run eagerly `GRAPH_AFTER` times (descriptor tables, packed-weight buffers and optimizer
+    state then exist and are only re-used), at most `GRAPH_MAX` geometries are kept, everything else -- ragged runs
+    that never repeat a view_count vector, injected draws (**extra), a kernel log, world > 1 -- runs eagerly.  The
+    captured step is the same launches on the same data: with the same random draws its parameters match the eager
+    step's bit for bit (tests/test_gpu_step_graph.py).  Learning rate and Adam bias corrections are read from device
+    memory refreshed before each replay; torch's device RNG advances per replay as it does per eager step."""
+    GRAPH_AFTER = 2
+    GRAPH_MAX = 4
+
+    def __init__(self, model, world=1, local_rank=0, lr_warmup=2500, decay_it=4000000, bucket_cap_mb=32, graph=None):
         self.module = model
         self.model = model
         self.arena = None
@@ -125,6 +147,75 @@ class Trainer:
         else:                       # CPU harness tests (gloo) only
             self.opt = torch.optim.Adam(params, lr=self.sched.get_cur_lr(0))
         self.it = -1
+        if graph is None:
+            graph = os.environ.get("VF_STEP_GRAPH") == "1"
+        self.use_graph = bool(graph) and world == 1 and params[0].is_cuda
+        self._graphs = {}           # geometry key -> _StepGraph
+        self._pool = None           # the graphs' shared private memory pool
+        self._scal = None           # device {lr, 1-b1^t, 1-b2^t}
+        self._last_graph = None
+        self.graph_steps = 0        # iterations that ran as a replay (diagnostics / tests)
+
+    # -- whole-step HIP graph ---------------------------------------------------------------------------------------
+    def _graph_key(self, batch, extra):
+        from . import ops
+        if not self.use_graph or ops.KERNEL_LOG is not None or self.arena is not None:
+            return None
+        if any(k not in ("t", "u", "noise") for k in extra):       # injected draws are graph inputs, nothing else is
+            return None
+        vc = batch["view_count"]
+        if torch.is_tensor(vc):
+            if vc.is_cuda:          # reading it back would be a device sync per step
+                return None
+            vc = vc.tolist()
+        ts = [("y_0", batch["y_0"]), ("y_cond", batch["y_cond"]), ("angle", batch["angle"])] + sorted(extra.items())
+        if not all(torch.is_tensor(t) and t.is_cuda for _, t in ts):
+            return None
+        return tuple((k, tuple(t.shape), t.dtype) for k, t in ts) + (tuple(int(v) for v in vc),)
+
+    def _capture(self, e, key, batch, extra):
+        from . import ops
+        dev = batch["y_0"].device
+        adam = self.opt.graph_begin()
+        if adam is None:
+            return False
+        if self._scal is None:
+            self._scal = torch.zeros(3, device=dev, dtype=torch.float32)
+        e.inputs = {k: {**batch, **extra}[k].detach().clone().contiguous() for k, _, _ in key[:-1]}
+        e.view_count = torch.tensor(key[-1], dtype=torch.int64, device=dev)
+        ops.view_offsets(e.view_count, dev)          # resolved (one read-back) and remembered BEFORE the capture
+        self.opt.zero_grad()                           # the capture allocates the gradients in the graph's pool
+        g = torch.cuda.CUDAGraph()
+        kw = {} if self._pool is None else dict(pool=self._pool)
+        try:
+            with torch.cuda.graph(g, capture_error_mode="relaxed", **kw):
+                loss = self.model(view_count=e.view_count, **e.inputs)
+                loss.backward()
+                self.opt.step_captured(adam, self._scal)
+        finally:
+            fix = ops.end_capture()
+        if self._pool is None:
+            self._pool = g.pool()
+        e.adam = self.opt.graph_end(adam)
+        e.loss, e.graph = loss.detach(), g
+        # buffers the captured launches address that are otherwise owned by replaceable caches: the packed weights
+        e.keep = (fix, getattr(self.module.denoise_fn, "_vf_pack_plan", None),
+                  [(getattr(m, "_vf_pack", None), getattr(m, "_vf_wpack", None)) for m in self.module.modules()
+                   if isinstance(m, torch.nn.Conv2d)])
+        return True
+
+    def _graph_step(self, e, batch, extra):
+        for k, dst in e.inputs.items():
+            src = extra[k] if k in extra else batch[k]
+            dst.copy_(src.reshape(dst.shape), non_blocking=True)
+        if self._last_graph is not e:                  # .grad shows the gradients of the graph that ran last
+            for p, gr in zip(e.adam["bucket"]["params"], e.adam["grads"]):
+                p.grad = gr
+            self._last_graph = e
+        self.opt.graph_tick(e.adam, self._scal)
+        e.graph.replay()
+        self.graph_steps += 1
+        return e.loss.clone()
 
     def step(self, batch, **extra):
         """One reference iteration; returns the (device) loss tensor, no host sync."""
@@ -137,6 +228,26 @@ class Trainer:
         # The residual blocks' Dropout is the only such layer; the root flag alone would miss `vf.denoise_fn.eval()`.
         if not self.model.training or any(not m.training for m in self._mode_modules):
             self.model.train()
+        key = self._graph_key(batch, extra)
+        if key is not None:
+            e = self._graphs.get(key)
+            if e is None and len(self._graphs) < self.GRAPH_MAX:
+                e = self._graphs[key] = _StepGraph()
+            if e is not None:
+                if e.graph is None and e.seen >= self.GRAPH_AFTER:
+                    try:
+                        if not self._capture(e, key, batch, extra):
+                            self.use_graph = False
+                    except Exception as err:           # leave the run on the eager path, loudly
+                        import sys
+                        print(f"[view_fusion_amd] training-step graph capture failed ({type(err).__name__}: {err}); "
+                              "continuing eagerly", file=sys.stderr)
+                        self.use_graph, e.graph = False, None
+                        self.opt.zero_grad()
+                if e.graph is not None:
+                    return self._graph_step(e, batch, extra)
+                e.seen += 1
+        self._last_graph = None
         self.opt.zero_grad()
         loss = self.model(y_0=batch["y_0"], y_cond=batch["y_cond"], view_count=batch["view_count"],
                           angle=batch["angle"], **extra)
