@@ -322,8 +322,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-sampler", action="store_true")
-    ap.add_argument("--graph", type=int, default=int(os.environ.get("VF_STEP_GRAPH", "0")),
-                    help="1: replay the iteration as one HIP graph (single process, fixed view_count); 0: eager launches")
+    ap.add_argument("--graph", type=int, default=int(os.environ.get("VF_STEP_GRAPH", "1")),
+                    help="1 (default): single-process runs replay the iteration as one HIP graph per batch geometry -- the "
+                         "same launches on the same data, host enqueue 0.4 instead of 13 ms per step; 0: eager launches. "
+                         "Multi-process runs (gradient arena + RCCL) always launch eagerly.")
     args = ap.parse_args()
 
     rank, local_rank, world = train.init_distributed()

@@ -103,6 +103,25 @@ def test_graph_step_two_geometries_and_ragged_fallback():
     _same(ma, mb)
 
 
+def test_graph_step_ragged_view_counts_share_one_graph_per_stacked_count():
+    """The reference draws view_count per sample and iteration: vectors with the same sum replay the same graph, with
+    the offsets table as an input."""
+    from view_fusion_amd import train
+    ma, mb = _pair(TINY)
+    ta, tb = train.Trainer(ma, graph=False), train.Trainer(mb, graph=True)
+    vcs = [[1, 2, 3], [3, 2, 1], [2, 2, 2], [3, 1, 2], [2, 3, 1], [2, 2, 2], [1, 1, 1], [1, 2, 3]]
+    for i, (bt, vc) in enumerate(zip(_batches(len(vcs), 3, 3, 16), vcs)):
+        bt["view_count"] = torch.tensor(vc)
+        la, lb = ta.step(bt, **_draws(i, 3, 16)), tb.step(bt, **_draws(i, 3, 16))
+        assert torch.equal(la, lb), i
+        for p, q in zip(ma.parameters(), mb.parameters()):
+            assert torch.equal(p, q) and torch.equal(p.grad, q.grad), i
+    assert tb.graph_steps == 5 and len(tb._graphs) == 2        # S = 6 (captured), S = 3 (seen once)
+    bad = dict(_batches(1, 3, 3, 16)[0], view_count=torch.tensor([1, 0, 3]))
+    with pytest.raises(ValueError):
+        tb.step(bad)
+
+
 def test_sampling_after_graph_steps_sees_updated_weights():
     """The packed-weight caches of the inference path are keyed on the parameters' version counters, which every
     replay bumps: a sampler call after replays must not reuse packs made before them."""

@@ -147,19 +147,44 @@ _CS_TABLE = {}          # device -> {"rows": last uploaded table, "ring": [[pinn
 _CS_RING = 4            # staging buffers in rotation: an upload never waits for a copy younger than four backward passes
 
 
-_CAPTURE_FIXUPS = []    # [(device table, host rows, keep-alive)] of launches recorded into a stream capture, see below
+# A captured training step (train.Trainer) launches its table-driven kernels on device tables whose CONTENTS are only
+# needed when the graph is replayed: they are uploaded after the capture has ended, with ordinary copies -- no host-to-
+# device copy node (and no pinned staging buffer to keep stable) inside the graph.  Such a table must NOT come from the
+# capturing graph's memory pool: the pool hands a block that an earlier tensor of the same capture has released to a
+# later one, so on every replay the earlier kernels would scribble over a table uploaded once.  begin_capture()
+# therefore allocates the table BEFORE the capture starts.
+_CAPTURE_TABLE = None   # [device table (rows x 6 int64), rows used, host rows, keep-alive] while a Trainer is capturing
+
+
+def begin_capture(device, max_rows):
+    global _CAPTURE_TABLE
+    _CAPTURE_TABLE = [torch.empty(max(1, max_rows), 6, dtype=torch.int64, device=device), 0, None, None]
+
+
+def prime_tables(net, S, device):
+    """The per-geometry descriptor tables of a UNet's training forward (weight packs, FeatureWiseAffine group) hold
+    ONE geometry at a time and are rebuilt -- with a host-to-device copy -- when S changes which layers take the Winograd
+    path: make them current for S now, so that a capture of the iteration that follows finds them and only launches.
+    Returns those tables and the packed-weight buffers: the captured launches address them, and the caches drop them
+    when another geometry comes along, so the graph's owner keeps them referenced."""
+    if not (isinstance(net, torch.nn.Module) and hasattr(net, "_affine_layers")):
+        return None
+    pack_all(net, S)
+    layers = net._affine_layers()
+    _ta_desc(layers, S, device)
+    return (getattr(net, "_vf_pack_plan", None), _TA_DESC.get(id(layers[0])),
+            [(getattr(m, "_vf_pack", None), getattr(m, "_vf_wpack", None)) for m in net.modules()
+             if isinstance(m, torch.nn.Conv2d)])
 
 
 def end_capture():
-    """A captured training step (train.Trainer) launches its table-driven kernels on device tables whose CONTENTS are
-    only needed when the graph is replayed: they are uploaded here, after the capture has ended, with ordinary copies
-    -- no host-to-device copy node (and no pinned staging buffer to keep stable) inside the graph.  Returns what the
-    graph's owner must keep referenced for as long as it replays the graph."""
-    fix = list(_CAPTURE_FIXUPS)
-    del _CAPTURE_FIXUPS[:]
-    for tab, rows, _ in fix:
-        tab.copy_(rows)
-    return fix
+    """Upload the tables of the capture that just ended; returns what the graph's owner must keep referenced for as
+    long as it replays the graph."""
+    global _CAPTURE_TABLE
+    ct, _CAPTURE_TABLE = _CAPTURE_TABLE, None
+    if ct is not None and ct[1]:
+        ct[0][:ct[1]].copy_(ct[2])
+    return ct
 
 
 def _flush_colsums():
@@ -168,13 +193,16 @@ def _flush_colsums():
     if not pend:
         return
     if torch.cuda.is_current_stream_capturing():
+        ct = _CAPTURE_TABLE
         rows, first = [], 0
         for parts, dgb, batch, S, C in pend:
             rows.append([parts.data_ptr(), dgb.data_ptr(), S, C, batch, first])
             first += ((C + 63) // 64) * batch
-        tab = torch.empty(len(rows), 6, dtype=torch.int64, device=pend[0][0].device)
-        _lib.call("vf_colsum_multi", ctypes.c_void_p(tab.data_ptr()), len(rows), first, _stream())
-        _CAPTURE_FIXUPS.append((tab, torch.tensor(rows, dtype=torch.int64), pend))
+        if ct is None or ct[1] or len(rows) > ct[0].shape[0]:
+            raise _lib.VFHipError("deferred GroupNorm parameter sums inside a stream capture need ops.begin_capture() "
+                                  "with room for every GroupNorm layer (one backward pass per capture)")
+        _lib.call("vf_colsum_multi", ctypes.c_void_p(ct[0].data_ptr()), len(rows), first, _stream())
+        ct[1], ct[2], ct[3] = len(rows), torch.tensor(rows, dtype=torch.int64), pend
         return
     key = tuple(v for e in pend for v in (e[0].data_ptr(), e[1].data_ptr(), e[3], e[4]))
     dev = pend[0][0].device
@@ -212,7 +240,8 @@ def _flush_colsums():
 def _colsum(parts, dgb, batch, S, C, params):
     """dgb[b][c] = sum_s parts[b][s][c], now or (see above) at the end of the running backward pass."""
     if (COLSUM_DEFER and reducer.ACTIVE is None and all(p is not None and p.grad is None for p in params)
-            and torch._C._current_graph_task_id() != -1):
+            and torch._C._current_graph_task_id() != -1
+            and (_CAPTURE_TABLE is not None or not torch.cuda.is_current_stream_capturing())):
         if not _PENDING_COLSUMS:
             torch.autograd.Variable._execution_engine.queue_callback(_flush_colsums)
         _PENDING_COLSUMS.append((parts, dgb, batch, S, C))

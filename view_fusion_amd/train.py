@@ -98,7 +98,7 @@ def build_model(unet_params=None, beta_schedule=None, device="cuda", phase="trai
 
 class _StepGraph:
     """One captured training iteration (forward, backward, Adam) for one batch geometry."""
-    __slots__ = ("graph", "inputs", "view_count", "loss", "adam", "keep", "seen")
+    __slots__ = ("graph", "inputs", "view_count", "off", "vc", "loss", "adam", "keep", "seen")
 
     def __init__(self):
         self.graph, self.seen = None, 0
@@ -109,15 +109,20 @@ class Trainer:
 
     graph (default: the VF_STEP_GRAPH environment variable, off unless "1"): single-process GPU runs replay the WHOLE
     iteration -- weight packs, forward, backward, the multi-tensor Adam launch: ~1000 kernels -- as one HIP graph per
-    batch geometry (tensor shapes + the view_count values) instead of enqueueing it launch by launch.  A geometry is
+    batch geometry instead of enqueueing it launch by launch.  The geometry is the tensor shapes plus the stacked-view
+    count S = sum(view_count): which sample owns which views is the offsets table the kernels read from device memory,
+    so it is a graph INPUT like the images, and a ragged run (experiment.py:277-279 draws view_count per sample and
+    iteration) needs one graph per S it meets (at most B*(N-1)+1), not one per view_count vector.  A geometry is
     captured after it has run eagerly `GRAPH_AFTER` times (descriptor tables, packed-weight buffers and optimizer
-    state then exist and are only re-used), at most `GRAPH_MAX` geometries are kept, everything else -- ragged runs
-    that never repeat a view_count vector, injected draws (**extra), a kernel log, world > 1 -- runs eagerly.  The
-    captured step is the same launches on the same data: with the same random draws its parameters match the eager
-    step's bit for bit (tests/test_gpu_step_graph.py).  Learning rate and Adam bias corrections are read from device
-    memory refreshed before each replay; torch's device RNG advances per replay as it does per eager step."""
+    state then exist and are only re-used); up to `GRAPH_MAX` graphs share one memory pool (each keeps its own
+    gradient tensors, 136 MB for the small UNet).  Eager as before: injected arguments other than the draws t / u /
+    noise (which are graph inputs), a device-resident view_count (reading it back would be a sync per step), a
+    kernel log, world > 1.  The captured step is the same launches on the same data: with the same random draws its
+    parameters match the eager step's bit for bit (tests/test_gpu_step_graph.py).  Learning rate and Adam bias
+    corrections are read from device memory refreshed before each replay; torch's device RNG advances per replay
+    exactly as it does per eager step."""
     GRAPH_AFTER = 2
-    GRAPH_MAX = 4
+    GRAPH_MAX = 96
 
     def __init__(self, model, world=1, local_rank=0, lr_warmup=2500, decay_it=4000000, bucket_cap_mb=32, graph=None):
         self.module = model
@@ -171,9 +176,14 @@ class Trainer:
         ts = [("y_0", batch["y_0"]), ("y_cond", batch["y_cond"]), ("angle", batch["angle"])] + sorted(extra.items())
         if not all(torch.is_tensor(t) and t.is_cuda for _, t in ts):
             return None
-        return tuple((k, tuple(t.shape), t.dtype) for k, t in ts) + (tuple(int(v) for v in vc),)
+        vc = tuple(int(v) for v in vc)
+        if len(vc) != batch["y_0"].shape[0] or min(vc) < 1 or max(vc) > batch["y_cond"].shape[1]:
+            return None                       # the eager path raises the reference's errors
+        # the launch geometry depends on the stacked-view count S only: WHICH sample owns which views is the offsets
+        # table the kernels read from device memory, a graph input like the images
+        return tuple((k, tuple(t.shape), t.dtype) for k, t in ts) + (sum(vc),), vc
 
-    def _capture(self, e, key, batch, extra):
+    def _capture(self, e, key, vc, batch, extra):
         from . import ops
         dev = batch["y_0"].device
         adam = self.opt.graph_begin()
@@ -182,29 +192,41 @@ class Trainer:
         if self._scal is None:
             self._scal = torch.zeros(3, device=dev, dtype=torch.float32)
         e.inputs = {k: {**batch, **extra}[k].detach().clone().contiguous() for k, _, _ in key[:-1]}
-        e.view_count = torch.tensor(key[-1], dtype=torch.int64, device=dev)
-        ops.view_offsets(e.view_count, dev)          # resolved (one read-back) and remembered BEFORE the capture
+        e.view_count = torch.tensor(vc, dtype=torch.int64, device=dev)
+        offs = ops.view_offsets(e.view_count, dev)   # resolved (one read-back) and remembered BEFORE the capture
+        e.off, e.vc = offs[0], vc                    # the offsets table: rewritten when a replay's view_count differs
+        tables = ops.prime_tables(getattr(self.module, "denoise_fn", None), key[-1], dev)
         self.opt.zero_grad()                           # the capture allocates the gradients in the graph's pool
         g = torch.cuda.CUDAGraph()
         kw = {} if self._pool is None else dict(pool=self._pool)
+        ops.begin_capture(dev, sum(1 for m in self.module.modules() if isinstance(m, torch.nn.GroupNorm)))
+        failed = None
         try:
             with torch.cuda.graph(g, capture_error_mode="relaxed", **kw):
-                loss = self.model(view_count=e.view_count, **e.inputs)
-                loss.backward()
-                self.opt.step_captured(adam, self._scal)
+                try:        # an exception must not unwind through the capture: let it end, then report
+                    loss = self.model(view_count=e.view_count, **e.inputs)
+                    loss.backward()
+                    self.opt.step_captured(adam, self._scal)
+                except Exception as err:      # noqa: BLE001
+                    failed = err
         finally:
             fix = ops.end_capture()
+        if failed is not None:
+            raise failed
         if self._pool is None:
             self._pool = g.pool()
         e.adam = self.opt.graph_end(adam)
         e.loss, e.graph = loss.detach(), g
-        # buffers the captured launches address that are otherwise owned by replaceable caches: the packed weights
-        e.keep = (fix, getattr(self.module.denoise_fn, "_vf_pack_plan", None),
-                  [(getattr(m, "_vf_pack", None), getattr(m, "_vf_wpack", None)) for m in self.module.modules()
-                   if isinstance(m, torch.nn.Conv2d)])
+        e.keep = (fix, tables, offs)       # what the captured launches address besides the graph's own pool
         return True
 
-    def _graph_step(self, e, batch, extra):
+    def _graph_step(self, e, vc, batch, extra):
+        if vc != e.vc:
+            off = [0]
+            for v in vc:
+                off.append(off[-1] + v)
+            e.off.copy_(torch.tensor(off, dtype=torch.int32).pin_memory(), non_blocking=True)
+            e.vc = vc
         for k, dst in e.inputs.items():
             src = extra[k] if k in extra else batch[k]
             dst.copy_(src.reshape(dst.shape), non_blocking=True)
@@ -228,7 +250,7 @@ class Trainer:
         # The residual blocks' Dropout is the only such layer; the root flag alone would miss `vf.denoise_fn.eval()`.
         if not self.model.training or any(not m.training for m in self._mode_modules):
             self.model.train()
-        key = self._graph_key(batch, extra)
+        key, vc = self._graph_key(batch, extra) or (None, None)
         if key is not None:
             e = self._graphs.get(key)
             if e is None and len(self._graphs) < self.GRAPH_MAX:
@@ -236,7 +258,7 @@ class Trainer:
             if e is not None:
                 if e.graph is None and e.seen >= self.GRAPH_AFTER:
                     try:
-                        if not self._capture(e, key, batch, extra):
+                        if not self._capture(e, key, vc, batch, extra):
                             self.use_graph = False
                     except Exception as err:           # leave the run on the eager path, loudly
                         import sys
@@ -245,7 +267,7 @@ class Trainer:
                         self.use_graph, e.graph = False, None
                         self.opt.zero_grad()
                 if e.graph is not None:
-                    return self._graph_step(e, batch, extra)
+                    return self._graph_step(e, vc, batch, extra)
                 e.seen += 1
         self._last_graph = None
         self.opt.zero_grad()
@@ -255,4 +277,7 @@ class Trainer:
         if self.arena is not None:
             self.arena.finish()
         self.opt.step()
-        return loss
+        # detached: a caller that keeps the returned loss must not keep this iteration's autograd graph (and with it the
+        # parameters' AccumulateGrad nodes, which remember the stream they were created on) alive -- a later graph
+        # capture of the iteration runs on its own stream and every node of the backward pass has to follow it there
+        return loss.detach()
