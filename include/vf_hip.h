@@ -72,6 +72,14 @@ int vf_conv_fwd_gn(const float* x, const float* w_packed, const float* bias, con
                    float* y, int store_y, const float* gn_gamma, const float* gn_beta, float* a_out, float* gn_stats,
                    int groups, float eps, int silu, float* ws, long ws_floats, int S, int Cin, int Cout, int H, int W,
                    int KS, int mode, void* stream);
+/* The sampler's convolutions at few stacked views (model/view_fusion.py:179-214 driving model/unet.py:42,189,198,214,
+ * 238,255,256 with S = 1 ... a dozen): ONE launch per layer, K split over the waves of a workgroup and summed in LDS in a
+ * fixed order; reads the UNPACKED OIHW parameter.  x2 != NULL (1x1 only): input channels [C1, Cin) come from x2.
+ * H, W = output map; mode as vf_conv_fwd (0, 1 = stride 2, 2 = upsampled input). */
+int vf_conv_small_supported(int Cin, int Cout, int H, int W, int KS, int mode);
+int vf_conv_small(const float* x, const float* x2 /*|NULL*/, int C1, const float* w_oihw, const float* bias /*|NULL*/,
+                  const float* view_bias /*|NULL*/, const float* residual /*|NULL*/, float* y, int S, int Cin, int Cout,
+                  int H, int W, int KS, int mode, void* stream);
 /* split-K workspace the call above wants at this shape (0 when the natural grid fills the chip) */
 long vf_conv_fwd_ws_floats(int S, int Cin, int Cout, int H, int W, int KS);
 /* 1x1 conv on the channel concatenation [x1 (C1 channels, multiple of 64) | x2] (residual conv of the decoder

@@ -109,6 +109,76 @@ def test_conv_small_batch_split_k_forward(dev, Cin, Cout, Hin, KS, mode, S):
     test_conv_fwd_bwd(dev, Cin, Cout, Hin, KS, mode, S)
 
 
+SMALL_CASES = [c for c in CONV_CASES if c[4] == "same" and c[0] % (4 if c[3] == 1 else 32) == 0] + [
+    (64, 100, 16, 3, "same"), (32, 40, 4, 3, "same"), (68, 33, 8, 1, "same"), (96, 50, 8, 3, "same"),
+    (384, 192, 16, 3, "same"), (512, 192, 16, 3, "same"), (256, 128, 32, 3, "same"), (192, 64, 64, 3, "same")]
+
+
+@pytest.mark.parametrize("S", [1, 3])
+@pytest.mark.parametrize("Cin,Cout,Hin,KS,mode", SMALL_CASES)
+def test_conv_small_sampler_kernel(dev, Cin, Cout, Hin, KS, mode, S):
+    """The sampler's one-launch conv (csrc/conv_small.hip: K split over the waves of a workgroup, unpacked weights)
+    against an fp64 convolution, through the same ops.conv2d call the no-grad UNet forward makes."""
+    from view_fusion_amd import ops
+    layer = torch.nn.Conv2d(Cin, Cout, KS, padding=KS // 2)
+    with torch.no_grad():
+        layer.weight.copy_(rnd(Cout, Cin, KS, KS, seed=5) / math.sqrt(Cin * KS * KS))
+        layer.bias.copy_(rnd(Cout, seed=6) * 0.1)
+    x = rnd(S, Cin, Hin, Hin, seed=7)
+    Hout = Hin // 2 if mode == "down2" else (Hin * 2 if mode == "up2" else Hin)
+    vb, res = rnd(S, Cout, seed=8) * 0.3, rnd(S, Cout, Hout, Hout, seed=9)
+    inp = F.interpolate(x.double(), scale_factor=2, mode="nearest") if mode == "up2" else x.double()
+    ref = F.conv2d(inp, layer.weight.double(), layer.bias.double(), stride=2 if mode == "down2" else 1, padding=KS // 2)
+    ref = ref + vb.double()[:, :, None, None] + res.double()
+    layer = layer.to(dev)
+    ops.KERNEL_LOG = []
+    saved = ops.SMALL_CONV_MAX_WGS, ops.SMALL_CONV_MAX_CIN3, ops.SMALL_CONV_MAX_S3
+    ops.SMALL_CONV_MAX_WGS, ops.SMALL_CONV_MAX_CIN3, ops.SMALL_CONV_MAX_S3 = (1 << 30, 1 << 30), 1 << 30, 1 << 30
+    try:
+        assert ops.use_small_conv(S, Cin, Cout, Hout, Hout, KS, ops._MODES[mode])
+        with torch.no_grad():
+            y = ops.conv2d(x.to(dev), layer, view_bias=vb.to(dev), residual=res.to(dev), mode=mode)
+            y0 = ops.conv2d(x.to(dev), layer, mode=mode)
+        torch.cuda.synchronize()
+        assert [e[5] for e in ops.KERNEL_LOG] == ["vf_conv_small", "vf_conv_small"]
+    finally:
+        ops.KERNEL_LOG = None
+        ops.SMALL_CONV_MAX_WGS, ops.SMALL_CONV_MAX_CIN3, ops.SMALL_CONV_MAX_S3 = saved
+    assert rel(y, ref) < 2e-6
+    assert rel(y0, ref - vb.double()[:, :, None, None] - res.double()) < 2e-6
+
+
+@pytest.mark.parametrize("S", [1, 4])
+def test_conv_small_cat_and_gn(dev, S):
+    """The decoder's 1x1 conv on the never-materialised concatenation, and conv + GroupNorm(+Swish) of the inference
+    path, at sampler sizes (both route through the one-launch kernel)."""
+    from view_fusion_amd import ops
+    C1, C2, Cout, H = 128, 64, 96, 16
+    layer = torch.nn.Conv2d(C1 + C2, Cout, 1)
+    with torch.no_grad():
+        layer.weight.copy_(rnd(Cout, C1 + C2, 1, 1, seed=5) / math.sqrt(C1 + C2))
+        layer.bias.copy_(rnd(Cout, seed=6) * 0.1)
+    x1, x2 = rnd(S, C1, H, H, seed=1), rnd(S, C2, H, H, seed=2)
+    ref = F.conv2d(torch.cat([x1, x2], 1).double(), layer.weight.double(), layer.bias.double())
+    layer = layer.to(dev)
+    with torch.no_grad():
+        y = ops.conv1x1_cat(x1.to(dev), x2.to(dev), layer)
+    assert rel(y, ref) < 2e-6
+    conv = torch.nn.Conv2d(64, 64, 3, padding=1)
+    gn = torch.nn.GroupNorm(32, 64)
+    with torch.no_grad():
+        conv.weight.copy_(rnd(64, 64, 3, 3, seed=7) / 24)
+        gn.weight.copy_(1 + 0.2 * rnd(64, seed=8)); gn.bias.copy_(0.2 * rnd(64, seed=9))
+    x = rnd(S, 64, 32, 32, seed=3)
+    yr = F.conv2d(x.double(), conv.weight.double(), conv.bias.double(), padding=1)
+    ar = F.group_norm(yr, 32, gn.weight.double(), gn.bias.double(), eps=1e-5)
+    ar = ar * torch.sigmoid(ar)
+    conv, gn = conv.to(dev), gn.to(dev)
+    with torch.no_grad():
+        yg, ag = ops.conv2d_gn(x.to(dev), conv, gn, 32, True, want_y=True)
+    assert rel(yg, yr) < 2e-6 and rel(ag, ar) < 1e-5
+
+
 @pytest.mark.parametrize("Cin,Cout,Hin,mode", [(64, 64, 64, "same"), (6, 64, 64, "same"), (64, 6, 64, "same"),
                                                (192, 64, 64, "same"), (128, 128, 32, "same"), (320, 128, 32, "same"),
                                                (128, 128, 32, "up2"), (192, 192, 16, "up2"), (32, 32, 32, "same"),

@@ -73,6 +73,8 @@ SIGNATURES = {
     "vf_concat_channels": [_P, _P, _P, _I, _L, _L, _I, _P],
     "vf_dropout": [_P, _P, _P, _L, _F, _P],
     "vf_adam_multi": [_P, _I, _L, _F, _F, _F, _F, _F, _F, _P],
+    "vf_conv_small_supported": [_I, _I, _I, _I, _I, _I],
+    "vf_conv_small": [_P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "vf_adam_multi_dev": [_P, _I, _L, _P, _F, _F, _F, _P],
     "vf_adam_set_scalars": [_P, _F, _F, _F, _P],
     "vf_psnr": [_P, _P, _P, _I, _I, _P],

@@ -1,0 +1,250 @@
+// Convolutions of the SAMPLER at few stacked views (reference model/view_fusion.py:179-214 driving model/unet.py's
+// convs with S = 1 ... a few views): a 64x64x64-channel layer is 0.3 GFLOP, the chip's matrix cores would be done in
+// 2 us -- what such a layer costs is the LATENCY of its longest dependent chain and the number of graph nodes it needs.
+// The training-size kernels (conv.hip) fill the chip at small S by splitting K over workgroups and summing the
+// partial outputs in a second launch; here the K split lives INSIDE the workgroup, so a layer is ONE node:
+//
+//   workgroup = 16 RS output channels x 16 output pixels of one view, 8 waves, each wave owning an eighth of the
+//   input channels; v_mfma_f32_16x16x4_f32, whose four k-rows are the four lane quarters' current products; the
+//   weights are read straight from the UNPACKED OIHW parameter (no packed copy to refresh); the eight partial tiles
+//   are summed through LDS in wave order (deterministic), then bias + per-view bias + residual.
+//
+//   3x3 (conv3_small_kernel): a wave stages the zero-haloed patch of its next 8-16 channels in its own LDS region (one
+//   dword per lane and channel, no workgroup barrier: a wave reads only what it wrote), the quarters take 4 channels
+//   of a group, the 9 taps are immediate LDS offsets and 9 consecutive weights per lane.
+//   1x1 (conv1_small_kernel): the B values are gathered from global memory directly (16 consecutive pixels per
+//   quarter), optionally from the decoder's never-materialised concatenation [x | x2].
+#include "common.h"
+
+namespace {
+
+struct SmallArgs {
+    const float* x;
+    const float* x2;
+    const float* w;       // OIHW, unpacked
+    const float* bias;
+    const float* vbias;
+    const float* res;
+    float* y;
+    int S, Cin, C1, Cout, logW, n;     // output map W = H = 1 << logW; 1x1: n = products per wave (multiple of 16)
+};
+
+constexpr int SM_PX = 16;
+
+// the eight waves' partial tiles -> LDS [wave][co 16 RS][px 16] -> fixed-order sum + epilogue
+template <int RS>
+__device__ __forceinline__ void small_epilogue(const SmallArgs& a, float* red, const f32x4* acc, int s, int cot, int pt) {
+    constexpr int TCO = 16 * RS;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 15, kk = lane >> 4;
+    const int HW = 1 << (2 * a.logW);
+    float* rw = red + w * (TCO * SM_PX);
+#pragma unroll
+    for (int rs = 0; rs < RS; ++rs)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rw[(16 * rs + 4 * kk + r) * SM_PX + j] = acc[rs][r];      // lane holds D[4 kk + r][j]
+    __syncthreads();
+    if (tid < TCO * SM_PX) {
+        const int co = cot * TCO + (tid >> 4), op = pt * SM_PX + (tid & 15);
+        if (co < a.Cout) {
+            float v = red[tid];
+#pragma unroll
+            for (int i = 1; i < 8; ++i) v += red[i * (TCO * SM_PX) + tid];
+            if (a.bias) v += a.bias[co];
+            if (a.vbias) v += a.vbias[(size_t)s * a.Cout + co];
+            const size_t o = ((size_t)s * a.Cout + co) * HW + op;
+            if (a.res) v += a.res[o];
+            a.y[o] = v;
+        }
+    }
+}
+
+// ---- 1x1: wave w owns products (= input channels) [w n, (w+1) n), n a multiple of 16; in its q-th group of 16 the lane
+// quarter kk holds the channels 16 q + 4 kk + (0..3): one 16-byte weight load per lane, the four quarters of a weight
+// row 64 contiguous bytes; B = the lane's pixel of those four channel planes
+constexpr int SM_NB = 8;
+template <bool CAT>
+__global__ __launch_bounds__(512) void conv1_small_kernel(SmallArgs a) {
+    __shared__ float red[8 * 32 * SM_PX];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 15, kk = lane >> 4;
+    const int HW = 1 << (2 * a.logW);
+    const int ptiles = HW / SM_PX, ncot = (a.Cout + 31) / 32;
+    int b = blockIdx.x;
+    const int pt = b % ptiles; b /= ptiles;
+    const int cot = b % ncot;
+    const int s = b / ncot;
+    const int K = a.Cin;
+    const int kw = w * a.n + 4 * kk;
+    // A rows of this lane (rows past Cout read the last row; their results are never stored)
+    const float* wa0 = a.w + (size_t)min(cot * 32 + j, a.Cout - 1) * K;
+    const float* wa1 = a.w + (size_t)min(cot * 32 + 16 + j, a.Cout - 1) * K;
+    const float* xs = a.x + (size_t)s * (CAT ? a.C1 : a.Cin) * HW + pt * SM_PX + j;
+    const float* xs2 = CAT ? a.x2 + (size_t)s * (a.Cin - a.C1) * HW + pt * SM_PX + j : nullptr;
+
+    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    for (int mb = 0; mb < a.n; mb += 16 * SM_NB) {
+        f32x4 A0[SM_NB], A1[SM_NB];
+        float B[4 * SM_NB];
+#pragma unroll
+        for (int q = 0; q < SM_NB; ++q) {
+            const int k = kw + mb + 16 * q;
+            const bool ok = mb + 16 * q < a.n && k < K;
+            A0[q] = ok ? *reinterpret_cast<const f32x4*>(wa0 + k) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            A1[q] = ok ? *reinterpret_cast<const f32x4*>(wa1 + k) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ci = k + e;
+                float v = 0.f;
+                if (ok) v = (CAT && ci >= a.C1) ? xs2[(size_t)(ci - a.C1) * HW] : xs[(size_t)ci * HW];
+                B[4 * q + e] = v;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < SM_NB; ++q) {
+            if (mb + 16 * q < a.n) {              // (wave-uniform)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(A0[q][e], B[4 * q + e], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[q][e], B[4 * q + e], acc[1], 0, 0, 0);
+                }
+            }
+        }
+    }
+    small_epilogue<2>(a, red, acc, s, cot, pt);
+}
+
+// ---- 3x3, stride 1.  LOGTC: log2 of the tile's columns (4: maps >= 16 wide, one row segment; 3: 8x8 maps, two rows;
+// 2: 4x4 maps, the whole map).  Cin a multiple of 32: every wave owns Cin/8 channels = whole groups of 4 (one channel
+// per lane quarter, the 9 taps = 9 MFMAs with immediate LDS offsets and 9 consecutive weights per lane).
+// A round = 16 / RS channels per wave: all its loads (patch + weights) are issued together, then 36 MFMAs.  The loads
+// are NOT double buffered: two register sets cost the second resident workgroup, which hides more latency than the
+// prefetch did (measured); so does a 16-byte-per-lane weight load pattern with a 36-entry LDS address table
+// (coalesced, but 140 VGPRs and 300 instructions of set-up per workgroup) -- at these sizes the fixed cost of a
+// workgroup decides, not its memory pattern.
+template <int LOGTC, int RS>
+__global__ __launch_bounds__(512) void conv3_small_kernel(SmallArgs a) {
+    constexpr int TC = 1 << LOGTC, TR = SM_PX / TC, PC = TC + 2, PR = TR + 2, PS = PR * PC;     // 54 / 40 / 36
+    constexpr int RND = 16 / RS, NG = RND / 4;     // channels per wave and round (36 MFMAs per round either way)
+    constexpr int TCO = 16 * RS;
+    constexpr int PATCH = 8 * RND * PS, REDF = 8 * TCO * SM_PX;
+    __shared__ float lds[PATCH > REDF ? PATCH : REDF];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 15, kk = lane >> 4;
+    const int W = 1 << a.logW, HW = W * W;
+    const int ptiles = HW / SM_PX, ncot = (a.Cout + TCO - 1) / TCO;
+    int b = blockIdx.x;
+    const int pt = b % ptiles; b /= ptiles;
+    const int cot = b % ncot;
+    const int s = b / ncot;
+    const int K = a.Cin * 9;
+    const int cw = a.Cin >> 3;                     // channels per wave (multiple of 4)
+    const int c0 = w * cw;
+    // tile origin
+    const int p0 = pt * SM_PX, ty0 = p0 >> a.logW, tx0 = p0 & (W - 1);
+    // staging duty: lane l < PS owns patch element (pr, pc) of every channel
+    const int pr = lane / PC, pc = lane - pr * PC;
+    const int gy = ty0 + pr - 1, gx = tx0 + pc - 1;
+    const bool pin = lane < PS && (unsigned)gy < (unsigned)W && (unsigned)gx < (unsigned)W;
+    const float* xp = a.x + ((size_t)s * a.Cin + c0) * HW + (pin ? gy * W + gx : 0);
+    float* pl = lds + w * (RND * PS);
+    // B fragment base of this lane: channel kk of a group, pixel j of the tile, tap (0,0)
+    const float* bl = pl + kk * PS + (j >> LOGTC) * PC + (j & (TC - 1));
+    // A: 9 consecutive weights of channel (group base + kk) per row
+    const float* wa[RS];
+#pragma unroll
+    for (int rs = 0; rs < RS; ++rs) wa[rs] = a.w + (size_t)min(cot * TCO + 16 * rs + j, a.Cout - 1) * K + (size_t)(c0 + kk) * 9;
+
+    f32x4 acc[RS];
+#pragma unroll
+    for (int rs = 0; rs < RS; ++rs) acc[rs] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int nr = (cw + RND - 1) / RND;
+    for (int r = 0; r < nr; ++r) {
+        float A[RS][NG][9];
+        float P[RND];
+#pragma unroll
+        for (int i = 0; i < RND; ++i) {
+            const int c = r * RND + i;
+            P[i] = (pin && c < cw) ? xp[(size_t)c * HW] : 0.f;
+        }
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            if (r * RND + 4 * g < cw) {            // (wave-uniform)
+#pragma unroll
+                for (int rs = 0; rs < RS; ++rs)
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) A[rs][g][t] = wa[rs][(size_t)(r * RND + 4 * g) * 9 + t];
+            }
+        }
+        if (lane < PS) {
+#pragma unroll
+            for (int i = 0; i < RND; ++i) pl[i * PS + lane] = P[i];
+        }
+        // (a wave reads only what it wrote itself: LDS operations of one wave execute in order, no workgroup barrier)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            if (r * RND + 4 * g < cw) {
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const float bv = bl[g * 4 * PS + (t / 3) * PC + (t % 3)];
+#pragma unroll
+                    for (int rs = 0; rs < RS; ++rs)
+                        acc[rs] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[rs][g][t], bv, acc[rs], 0, 0, 0);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();           // the next round's patch overwrites what this round read
+    }
+    __syncthreads();                               // the reduction buffer overlays the patches
+    small_epilogue<RS>(a, lds, acc, s, cot, pt);
+}
+
+template <int RS>
+int launch_conv3(const SmallArgs& a, hipStream_t st) {
+    const int W = 1 << a.logW;
+    const long grid = (long)a.S * ((a.Cout + 16 * RS - 1) / (16 * RS)) * (W * W / SM_PX);
+    if (W >= 16) hipLaunchKernelGGL((conv3_small_kernel<4, RS>), dim3((unsigned)grid), dim3(512), 0, st, a);
+    else if (W == 8) hipLaunchKernelGGL((conv3_small_kernel<3, RS>), dim3((unsigned)grid), dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((conv3_small_kernel<2, RS>), dim3((unsigned)grid), dim3(512), 0, st, a);
+    VF_RETURN_LAST_ERROR();
+}
+
+int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+
+}  // namespace
+
+extern "C" {
+
+// 1 if vf_conv_small handles this layer: square power-of-two output maps of at least 16 pixels, stride 1; 1x1 with Cin a
+// multiple of 4 (16-byte weight loads straight from the OIHW tensor), 3x3 with Cin a multiple of 32 (whole channel
+// groups per wave)
+int vf_conv_small_supported(int Cin, int Cout, int H, int W, int KS, int mode) {
+    if (H != W || H < 4 || (H & (H - 1)) || Cin < 1 || Cout < 1 || mode != 0) return 0;
+    if (KS == 1) return Cin % 4 == 0;
+    if (KS == 3) return Cin % 32 == 0;
+    return 0;
+}
+
+// y = conv(x [| x2 on channels C1..], w) + bias + view_bias + residual at the sampler's sizes (stride 1, H = W).
+// w: the unpacked OIHW parameter.  One launch, no workspace.
+int vf_conv_small(const float* x, const float* x2, int C1, const float* w, const float* bias, const float* view_bias,
+                  const float* residual, float* y, int S, int Cin, int Cout, int H, int W, int KS, int mode, void* stream) {
+    if (!vf_conv_small_supported(Cin, Cout, H, W, KS, mode) || (x2 && (KS != 1 || C1 <= 0 || C1 >= Cin)))
+        return (int)hipErrorInvalidValue;
+    if (S <= 0) return 0;
+    SmallArgs a;
+    a.x = x; a.x2 = x2; a.w = w; a.bias = bias; a.vbias = view_bias; a.res = residual; a.y = y;
+    a.S = S; a.Cin = Cin; a.C1 = x2 ? C1 : Cin; a.Cout = Cout; a.logW = ilog2(W);
+    a.n = (((Cin + 7) / 8) + 15) & ~15;
+    hipStream_t st = (hipStream_t)stream;
+    if (KS == 1) {
+        const long grid = (long)S * ((Cout + 31) / 32) * (H * W / SM_PX);
+        if (x2) hipLaunchKernelGGL((conv1_small_kernel<true>), dim3((unsigned)grid), dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((conv1_small_kernel<false>), dim3((unsigned)grid), dim3(512), 0, st, a);
+        VF_RETURN_LAST_ERROR();
+    }
+    // 32-channel tiles when they alone fill the chip, 16-channel tiles (twice the workgroups) otherwise
+    const long wgs32 = (long)S * ((Cout + 31) / 32) * (H * W / SM_PX);
+    return wgs32 >= 256 ? launch_conv3<2>(a, st) : launch_conv3<1>(a, st);
+}
+
+}  // extern "C"

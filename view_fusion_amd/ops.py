@@ -572,6 +572,38 @@ def _use_b3(KS, m, HW):
     return BF16X3 and KS == 1 and m == 0 and HW >= 64 and (HW & (HW - 1)) == 0
 
 
+# The sampler at few stacked views: one launch per conv layer (csrc/conv_small.hip, K split inside the workgroup)
+# instead of split-K partials + a reduce launch.  Taken without autograd only.  Measured per layer against the split-K
+# route (tools/small_conv.py): the 1x1 kernel wins 3 us per layer up to ~1000 workgroups of 32 channels x
+# 16 pixels (S <= 3-6 on the 16x16 maps where the attention projections live); the 3x3 kernel wins 2-5 us per layer for
+# ONE view and Cin <= 256 and loses from two views on (its workgroups are all fixed cost).
+SMALL_CONV = os.environ.get("VF_SMALL_CONV", "1") == "1"
+SMALL_CONV_MAX_WGS = (int(os.environ.get("VF_SMALL_CONV_MAX_WGS1", 1024)),      # 1x1 layers
+                      int(os.environ.get("VF_SMALL_CONV_MAX_WGS3", 512)))       # 3x3 layers
+SMALL_CONV_MAX_CIN3 = int(os.environ.get("VF_SMALL_CONV_MAX_CIN3", 256))
+SMALL_CONV_MAX_S3 = int(os.environ.get("VF_SMALL_CONV_MAX_S3", 1))
+
+
+def use_small_conv(S, Cin, Cout, H, W, KS, m):
+    """(only consulted with autograd off)"""
+    if not SMALL_CONV or not _lib.load().vf_conv_small_supported(Cin, Cout, H, W, KS, m):
+        return False
+    wgs = S * ((Cout + 31) // 32) * (H * W // 16)
+    if KS == 1:
+        return wgs <= SMALL_CONV_MAX_WGS[0]
+    return wgs <= SMALL_CONV_MAX_WGS[1] and Cin <= SMALL_CONV_MAX_CIN3 and S <= SMALL_CONV_MAX_S3
+
+
+def _conv_small(x, x2, weight, bias, view_bias, residual, S, Cin, Cout, H, W, KS, m):
+    wd = weight.detach()
+    _check(wd)
+    y = torch.empty(S, Cout, H, W, device=x.device, dtype=torch.float32)
+    _launch("conv_fwd", 2.0 * S * Cout * Cin * KS * KS * H * W, "vf_conv_small", _ptr(x), _ptr(x2),
+            x.shape[1] if x2 is not None else 0, _ptr(wd), _ptr(bias), _ptr(view_bias), _ptr(residual), _ptr(y), S, Cin,
+            Cout, H, W, KS, m, _stream(), tag=(Cin, Cout, H, KS, m))
+    return y
+
+
 class _Conv2dFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, view_bias, residual, layer, mode, training, twin):
@@ -766,6 +798,12 @@ class _Conv1x1CatFn(torch.autograd.Function):
 
 def conv1x1_cat(x1, x2, layer):
     """layer(cat(x1, x2)) for a 1x1 `layer` with bias, without building the concatenation."""
+    if not torch.is_grad_enabled():
+        S, C1, H, W = x1.shape
+        Cout, Cin = layer.weight.shape[0], layer.weight.shape[1]
+        if use_small_conv(S, Cin, Cout, H, W, 1, 0):
+            _check(x1, x2, layer.bias)
+            return _conv_small(x1, x2, layer.weight, layer.bias, None, None, S, Cin, Cout, H, W, 1, 0)
     training = torch.is_grad_enabled() and layer.weight.requires_grad
     return _Conv1x1CatFn.apply(x1, x2, layer.weight, layer.bias, layer, training)
 
@@ -777,6 +815,14 @@ def conv2d(x, layer, view_bias=None, residual=None, mode="same", twin=None):
     Epilogue adds bias[c] + view_bias[s,c] + residual.  twin: the 1x1 conv layer that produced `residual` (it has
     the same bias gradient, which this layer's weight-gradient kernel then writes for both).
     """
+    if not torch.is_grad_enabled():
+        S, Cin, Hi, Wi = x.shape
+        Cout, _, KS, _ = layer.weight.shape
+        m = _MODES[mode]
+        H, W = (Hi // 2, Wi // 2) if m == 1 else ((Hi * 2, Wi * 2) if m == 2 else (Hi, Wi))
+        if use_small_conv(S, Cin, Cout, H, W, KS, m):
+            _check(x, layer.bias, view_bias, residual)
+            return _conv_small(x, None, layer.weight, layer.bias, view_bias, residual, S, Cin, Cout, H, W, KS, m)
     training = torch.is_grad_enabled() and layer.weight.requires_grad
     return _Conv2dFn.apply(x, layer.weight, layer.bias, view_bias, residual, layer, mode, training, twin)
 
@@ -792,6 +838,7 @@ def conv2d_gn(x, layer, gn, groups, silu, view_bias=None, residual=None, mode="s
     H, W = (Hi // 2, Wi // 2) if m == 1 else ((Hi * 2, Wi * 2) if m == 2 else (Hi, Wi))
     lib = _lib.load()
     fused = (not torch.is_grad_enabled() and not use_winograd(S, Cin, Cout, H, W, KS, m) and not _use_b3(KS, m, H * W)
+             and not use_small_conv(S, Cin, Cout, H, W, KS, m)      # (one conv launch + the GroupNorm launch instead)
              and lib.vf_conv_fwd_ws_floats(S, Cin, Cout, H, W, KS) > 0)
     if not fused:
         y = conv2d(x, layer, view_bias=view_bias, residual=residual, mode=mode)
