@@ -176,3 +176,39 @@ def test_trainer_restores_training_mode_of_submodules():
     assert tr._mode_modules == [blk]
     blk.eval()
     assert root.training and any(not m.training for m in tr._mode_modules)
+
+
+def test_trainer_step_graph_gating_is_host_logic():
+    """Trainer(graph=True): a CPU model never takes the graph path; the geometry key is the tensor shapes plus the SUM
+    of view_count (the per-sample offsets are a graph input), and everything that cannot be replayed maps to None."""
+    import torch
+    from view_fusion_amd import train
+    from test_ddp_gloo import StandIn
+
+    tr = train.Trainer(StandIn(), graph=True, lr_warmup=1)
+    assert tr.use_graph is False                       # CPU parameters: eager by construction
+    bt = train.synthetic_batch(4, 3, 8, "cpu", seed=0)
+    for _ in range(4):
+        loss = tr.step(bt)
+    assert tr.graph_steps == 0 and not loss.requires_grad      # the eager step returns a detached loss
+
+    tr.use_graph = True                                # the key function itself (no GPU work involved)
+
+    class Fake(torch.Tensor):                          # a CPU tensor that claims to live on the GPU
+        is_cuda = property(lambda self: True)
+
+    f = lambda t: t.as_subclass(Fake)
+    gb = dict(y_0=f(bt["y_0"]), y_cond=f(bt["y_cond"]), angle=f(bt["angle"]))
+    k1, vc1 = tr._graph_key(dict(gb, view_count=torch.tensor([1, 2, 3, 3])), {})
+    k2, vc2 = tr._graph_key(dict(gb, view_count=[3, 3, 2, 1]), {})
+    assert k1 == k2 and k1[-1] == 9 and vc1 == (1, 2, 3, 3) and vc2 == (3, 3, 2, 1)
+    k3, _ = tr._graph_key(dict(gb, view_count=[3, 3, 3, 1]), {})
+    assert k3 != k1
+    assert tr._graph_key(dict(gb, view_count=[0, 3, 3, 3]), {}) is None          # the eager path raises the error
+    assert tr._graph_key(dict(gb, view_count=[4, 3, 1, 1]), {}) is None          # more views than y_cond holds
+    assert tr._graph_key(dict(gb, view_count=f(torch.tensor([1, 2, 3, 3]))), {}) is None    # device-resident counts
+    assert tr._graph_key(dict(gb, view_count=[1, 2, 3, 3]), {"generate": True}) is None
+    assert tr._graph_key(dict(gb, view_count=[1, 2, 3, 3]), {"t": torch.zeros(4)}) is None   # a CPU draw
+    kt, _ = tr._graph_key(dict(gb, view_count=[1, 2, 3, 3]), {"t": f(torch.zeros(4))})
+    assert kt != k1 and kt[-1] == 9
+    assert tr._graph_key(dict(bt, view_count=[1, 2, 3, 3]), {}) is None          # CPU images
