@@ -138,3 +138,27 @@ def test_sampling_after_graph_steps_sees_updated_weights():
         yb = mb.p_sample(y_t, bt["y_cond"], bt["view_count"], bt["angle"], t, z=z)[0]
         assert torch.equal(ya, yb), i
     assert tb.graph_steps == 3
+
+
+def test_graph_steps_survive_an_optimizer_state_reload():
+    """load_state_dict replaces the Adam moment tensors: captured steps that address the old ones are dropped and the
+    geometry is captured again -- the run continues bit-identically to an eager one that reloads the same state."""
+    from view_fusion_amd import train
+    ma, mb = _pair(TINY)
+    ta, tb = train.Trainer(ma, graph=False, lr_warmup=3), train.Trainer(mb, graph=True, lr_warmup=3)
+    bt = _batches(1, 2, 3, 16)[0]
+    for i in range(4):
+        assert torch.equal(ta.step(bt, **_draws(i, 2, 16)), tb.step(bt, **_draws(i, 2, 16)))
+    assert tb.graph_steps == 2
+    for tr in (ta, tb):
+        sd = copy.deepcopy(tr.opt.state_dict())
+        for st in sd["state"].values():                 # a state that differs from the live one
+            st["exp_avg"] = st["exp_avg"] * 0.5
+        tr.opt.load_state_dict(sd)
+    for i in range(4, 9):
+        assert torch.equal(ta.step(bt, **_draws(i, 2, 16)), tb.step(bt, **_draws(i, 2, 16))), i
+        _same(ma, mb)
+    assert tb.graph_steps == 2 + 3                      # two eager sightings after the reload, then replays again
+    sa, sb = ta.opt.state_dict()["state"], tb.opt.state_dict()["state"]
+    for k in sa:
+        assert float(sa[k]["step"]) == float(sb[k]["step"]) == 9 and torch.equal(sa[k]["exp_avg"], sb[k]["exp_avg"])

@@ -21,6 +21,7 @@ class FusedAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
         self._plans = {}          # per param group: buckets of {descriptor rows, staging buffers, step count}
+        self.graph_epoch = 0      # bumped whenever the state tensors a captured step addresses are replaced
 
     # -- descriptor tables ---------------------------------------------------------------------------------------
     def _flush_steps(self, gi):
@@ -38,6 +39,7 @@ class FusedAdam(torch.optim.Optimizer):
         if plan is not None and plan["key"] == key:
             return plan
         self._flush_steps(gi)                          # a changed parameter set must not restart the bias correction
+        self.graph_epoch += 1
         by_step = {}
         for p in params:
             if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
@@ -72,6 +74,7 @@ class FusedAdam(torch.optim.Optimizer):
     def load_state_dict(self, sd):
         super().load_state_dict(sd)
         self._plans = {}
+        self.graph_epoch += 1                          # new exp_avg / exp_avg_sq tensors: captured steps are stale
 
     # -- HIP-graph capture of a whole training step (train.Trainer) ------------------------------------------------
     # A captured step cannot carry step-dependent launch arguments, so the update reads {lr, 1-b1^t, 1-b2^t} from three
@@ -88,7 +91,7 @@ class FusedAdam(torch.optim.Optimizer):
         if len(b["params"]) != len(self.param_groups[0]["params"]):
             return None
         rows = b["host"][0].clone()
-        return dict(bucket=b, rows=rows, dev=torch.empty(rows.shape, dtype=torch.int64, device=b["params"][0].device))
+        return dict(bucket=b, rows=rows, epoch=self.graph_epoch, dev=torch.empty(rows.shape, dtype=torch.int64, device=b["params"][0].device))
 
     @torch.no_grad()
     def step_captured(self, h, scalars):

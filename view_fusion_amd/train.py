@@ -159,6 +159,7 @@ class Trainer:
         self._pool = None           # the graphs' shared private memory pool
         self._scal = None           # device {lr, 1-b1^t, 1-b2^t}
         self._last_graph = None
+        self._graph_epoch = None    # FusedAdam.graph_epoch the kept graphs were captured under (None: none captured)
         self.graph_steps = 0        # iterations that ran as a replay (diagnostics / tests)
 
     # -- whole-step HIP graph ---------------------------------------------------------------------------------------
@@ -216,6 +217,7 @@ class Trainer:
         if self._pool is None:
             self._pool = g.pool()
         e.adam = self.opt.graph_end(adam)
+        self._graph_epoch = adam["epoch"]
         e.loss, e.graph = loss.detach(), g
         e.keep = (fix, tables, offs)       # what the captured launches address besides the graph's own pool
         return True
@@ -251,6 +253,10 @@ class Trainer:
         if not self.model.training or any(not m.training for m in self._mode_modules):
             self.model.train()
         key, vc = self._graph_key(batch, extra) or (None, None)
+        if key is not None and self._graph_epoch is not None and self.opt.graph_epoch != self._graph_epoch:
+            # the optimizer state was replaced (load_state_dict, a changed parameter set): the captured steps still
+            # address the old moment tensors -- drop them; every geometry is captured again after its eager sightings
+            self._graphs, self._last_graph, self._pool, self._graph_epoch = {}, None, None, None
         if key is not None:
             e = self._graphs.get(key)
             if e is None and len(self._graphs) < self.GRAPH_MAX:
