@@ -145,7 +145,7 @@ class Trainer:
         # modules whose behaviour depends on train/eval mode (see step()): the blocks that carry a Dropout
         self._mode_modules = [m for m in model.modules() if getattr(m, "dropout", 0) and hasattr(m, "_drop")]
         self.sched = LrScheduler(peak_lr=1e-4, peak_it=lr_warmup, decay_it=decay_it, decay_rate=0.16)
-        params = list(model.parameters())
+        params = self._params = list(model.parameters())
         if params[0].is_cuda:       # one multi-tensor HIP launch per step
             from .optim import FusedAdam
             self.opt = FusedAdam(params, lr=self.sched.get_cur_lr(0))
@@ -182,7 +182,11 @@ class Trainer:
             return None                       # the eager path raises the reference's errors
         # the launch geometry depends on the stacked-view count S only: WHICH sample owns which views is the offsets
         # table the kernels read from device memory, a graph input like the images
-        return tuple((k, tuple(t.shape), t.dtype) for k, t in ts) + (sum(vc),), vc
+        # (+ the addresses of what a captured step reads besides its inputs and is replaceable from outside: the noise
+        # schedule buffer -- set_new_noise_schedule() makes new tensors -- and the parameter storage)
+        g = getattr(self.module, "gammas", None)
+        anchors = (g.data_ptr() if torch.is_tensor(g) else 0, self._params[0].data_ptr(), self._params[-1].data_ptr())
+        return tuple((k, tuple(t.shape), t.dtype) for k, t in ts) + (anchors, sum(vc)), vc
 
     def _capture(self, e, key, vc, batch, extra):
         from . import ops
@@ -192,7 +196,7 @@ class Trainer:
             return False
         if self._scal is None:
             self._scal = torch.zeros(3, device=dev, dtype=torch.float32)
-        e.inputs = {k: {**batch, **extra}[k].detach().clone().contiguous() for k, _, _ in key[:-1]}
+        e.inputs = {k: {**batch, **extra}[k].detach().clone().contiguous() for k, _, _ in key[:-2]}
         e.view_count = torch.tensor(vc, dtype=torch.int64, device=dev)
         offs = ops.view_offsets(e.view_count, dev)   # resolved (one read-back) and remembered BEFORE the capture
         e.off, e.vc = offs[0], vc                    # the offsets table: rewritten when a replay's view_count differs
@@ -219,7 +223,7 @@ class Trainer:
         e.adam = self.opt.graph_end(adam)
         self._graph_epoch = adam["epoch"]
         e.loss, e.graph = loss.detach(), g
-        e.keep = (fix, tables, offs)       # what the captured launches address besides the graph's own pool
+        e.keep = (fix, tables, offs, getattr(self.module, "gammas", None))       # what the captured launches address besides the graph's own pool
         return True
 
     def _graph_step(self, e, vc, batch, extra):
