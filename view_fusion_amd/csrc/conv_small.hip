@@ -31,30 +31,43 @@ struct SmallArgs {
 
 constexpr int SM_PX = 16;
 
+// Epilogue operands (bias + per-view bias + residual of the output element this thread will finish) are requested at
+// kernel start: their latency runs under the main loop instead of behind the workgroup's last barrier.
+template <int RS>
+struct SmallEpi {
+    float add;        // bias + per-view bias + residual
+    size_t o;         // output index, or ~0 for a thread without an output element
+    __device__ __forceinline__ void fetch(const SmallArgs& a, int s, int cot, int pt) {
+        constexpr int TCO = 16 * RS;
+        const int tid = threadIdx.x, HW = 1 << (2 * a.logW);
+        const int co = cot * TCO + (tid >> 4), op = pt * SM_PX + (tid & 15);
+        o = ~(size_t)0;
+        add = 0.f;
+        if (tid < TCO * SM_PX && co < a.Cout) {
+            o = ((size_t)s * a.Cout + co) * HW + op;
+            float b0 = a.bias ? a.bias[co] : 0.f, b1 = a.vbias ? a.vbias[(size_t)s * a.Cout + co] : 0.f;
+            float r = a.res ? a.res[o] : 0.f;
+            add = (b0 + b1) + r;
+        }
+    }
+};
+
 // the eight waves' partial tiles -> LDS [wave][co 16 RS][px 16] -> fixed-order sum + epilogue
 template <int RS>
-__device__ __forceinline__ void small_epilogue(const SmallArgs& a, float* red, const f32x4* acc, int s, int cot, int pt) {
+__device__ __forceinline__ void small_epilogue(const SmallArgs& a, float* red, const f32x4* acc, const SmallEpi<RS>& ep) {
     constexpr int TCO = 16 * RS;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 15, kk = lane >> 4;
-    const int HW = 1 << (2 * a.logW);
     float* rw = red + w * (TCO * SM_PX);
 #pragma unroll
     for (int rs = 0; rs < RS; ++rs)
 #pragma unroll
         for (int r = 0; r < 4; ++r) rw[(16 * rs + 4 * kk + r) * SM_PX + j] = acc[rs][r];      // lane holds D[4 kk + r][j]
     __syncthreads();
-    if (tid < TCO * SM_PX) {
-        const int co = cot * TCO + (tid >> 4), op = pt * SM_PX + (tid & 15);
-        if (co < a.Cout) {
-            float v = red[tid];
+    if (ep.o != ~(size_t)0) {
+        float v = red[tid];
 #pragma unroll
-            for (int i = 1; i < 8; ++i) v += red[i * (TCO * SM_PX) + tid];
-            if (a.bias) v += a.bias[co];
-            if (a.vbias) v += a.vbias[(size_t)s * a.Cout + co];
-            const size_t o = ((size_t)s * a.Cout + co) * HW + op;
-            if (a.res) v += a.res[o];
-            a.y[o] = v;
-        }
+        for (int i = 1; i < 8; ++i) v += red[i * (TCO * SM_PX) + tid];
+        a.y[ep.o] = v + ep.add;
     }
 }
 
@@ -72,6 +85,8 @@ __global__ __launch_bounds__(512) void conv1_small_kernel(SmallArgs a) {
     const int pt = b % ptiles; b /= ptiles;
     const int cot = b % ncot;
     const int s = b / ncot;
+    SmallEpi<2> ep;
+    ep.fetch(a, s, cot, pt);
     const int K = a.Cin;
     const int kw = w * a.n + 4 * kk;
     // A rows of this lane (rows past Cout read the last row; their results are never stored)
@@ -109,21 +124,23 @@ __global__ __launch_bounds__(512) void conv1_small_kernel(SmallArgs a) {
             }
         }
     }
-    small_epilogue<2>(a, red, acc, s, cot, pt);
+    small_epilogue<2>(a, red, acc, ep);
 }
 
 // ---- 3x3, stride 1.  LOGTC: log2 of the tile's columns (4: maps >= 16 wide, one row segment; 3: 8x8 maps, two rows;
-// 2: 4x4 maps, the whole map).  Cin a multiple of 32: every wave owns Cin/8 channels = whole groups of 4 (one channel
-// per lane quarter, the 9 taps = 9 MFMAs with immediate LDS offsets and 9 consecutive weights per lane).
-// A round = 16 / RS channels per wave: all its loads (patch + weights) are issued together, then 36 MFMAs.  The loads
-// are NOT double buffered: two register sets cost the second resident workgroup, which hides more latency than the
-// prefetch did (measured); so does a 16-byte-per-lane weight load pattern with a 36-entry LDS address table
-// (coalesced, but 140 VGPRs and 300 instructions of set-up per workgroup) -- at these sizes the fixed cost of a
-// workgroup decides, not its memory pattern.
+// 2: 4x4 maps, the whole map).  Cin a multiple of 32: every wave owns Cin/8 channels (a multiple of 4).
+// A round = 8 channels of the wave = 72 products, consecutive in the OIHW weight row.  In the q-th group of 16 products
+// (q < 5; the last group is half empty) the lane quarter kk holds products 16 q + 4 kk + (0..3): ONE 16-byte weight load
+// per lane and group, the four quarters of a row 64 contiguous bytes -- the scattered 4-byte loads of a channel-per-
+// quarter assignment cost 3-4x the address-coalescing cycles, and the texture path is what a workgroup of this kernel
+// waits for.  The matching B values come from the wave's LDS patch through a per-lane table of 20 LDS addresses
+// (channel and tap of product 16 q + 4 kk + e), computed once per workgroup.
+// The loads are NOT double buffered: two register sets cost the second resident workgroup, which hides more latency
+// than the prefetch did (measured).
 template <int LOGTC, int RS>
 __global__ __launch_bounds__(512) void conv3_small_kernel(SmallArgs a) {
     constexpr int TC = 1 << LOGTC, TR = SM_PX / TC, PC = TC + 2, PR = TR + 2, PS = PR * PC;     // 54 / 40 / 36
-    constexpr int RND = 16 / RS, NG = RND / 4;     // channels per wave and round (36 MFMAs per round either way)
+    constexpr int RND = 8, NQ = 5;                 // channels per wave and round; groups of 16 products (72 -> 80)
     constexpr int TCO = 16 * RS;
     constexpr int PATCH = 8 * RND * PS, REDF = 8 * TCO * SM_PX;
     __shared__ float lds[PATCH > REDF ? PATCH : REDF];
@@ -134,6 +151,8 @@ __global__ __launch_bounds__(512) void conv3_small_kernel(SmallArgs a) {
     const int pt = b % ptiles; b /= ptiles;
     const int cot = b % ncot;
     const int s = b / ncot;
+    SmallEpi<RS> ep;
+    ep.fetch(a, s, cot, pt);
     const int K = a.Cin * 9;
     const int cw = a.Cin >> 3;                     // channels per wave (multiple of 4)
     const int c0 = w * cw;
@@ -145,19 +164,34 @@ __global__ __launch_bounds__(512) void conv3_small_kernel(SmallArgs a) {
     const bool pin = lane < PS && (unsigned)gy < (unsigned)W && (unsigned)gx < (unsigned)W;
     const float* xp = a.x + ((size_t)s * a.Cin + c0) * HW + (pin ? gy * W + gx : 0);
     float* pl = lds + w * (RND * PS);
-    // B fragment base of this lane: channel kk of a group, pixel j of the tile, tap (0,0)
-    const float* bl = pl + kk * PS + (j >> LOGTC) * PC + (j & (TC - 1));
-    // A: 9 consecutive weights of channel (group base + kk) per row
+    // B table: LDS address of product 16 q + 4 kk + e of a round, for this lane's pixel
+    typedef const __attribute__((address_space(3))) float* lds_cptr;      // (32-bit: a generic pointer takes two VGPRs)
+    lds_cptr tb[NQ][4];
+    {
+        lds_cptr bl = (lds_cptr)(pl + (j >> LOGTC) * PC + (j & (TC - 1)));
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = min(16 * q + 4 * kk + e, 9 * RND - 1);      // (slots past the round: any valid address)
+                const int ci = (k * 57) >> 9;                  // k / 9 for k < 144
+                const int tap = k - 9 * ci, dy = (tap * 11) >> 5;          // tap / 3
+                tb[q][e] = bl + ci * PS + dy * PC + (tap - 3 * dy);
+            }
+    }
+    // A: this lane's 16-byte piece of each product group
     const float* wa[RS];
 #pragma unroll
-    for (int rs = 0; rs < RS; ++rs) wa[rs] = a.w + (size_t)min(cot * TCO + 16 * rs + j, a.Cout - 1) * K + (size_t)(c0 + kk) * 9;
+    for (int rs = 0; rs < RS; ++rs)
+        wa[rs] = a.w + (size_t)min(cot * TCO + 16 * rs + j, a.Cout - 1) * K + (size_t)c0 * 9 + 4 * kk;
 
     f32x4 acc[RS];
 #pragma unroll
     for (int rs = 0; rs < RS; ++rs) acc[rs] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int nr = (cw + RND - 1) / RND;
     for (int r = 0; r < nr; ++r) {
-        float A[RS][NG][9];
+        const int np = 9 * min(RND, cw - r * RND);     // products of this round (72 or 36)
+        f32x4 A[RS][NQ];
         float P[RND];
 #pragma unroll
         for (int i = 0; i < RND; ++i) {
@@ -165,37 +199,36 @@ __global__ __launch_bounds__(512) void conv3_small_kernel(SmallArgs a) {
             P[i] = (pin && c < cw) ? xp[(size_t)c * HW] : 0.f;
         }
 #pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            if (r * RND + 4 * g < cw) {            // (wave-uniform)
+        for (int q = 0; q < NQ; ++q) {
+            const bool ok = 16 * q + 4 * kk < np;
 #pragma unroll
-                for (int rs = 0; rs < RS; ++rs)
-#pragma unroll
-                    for (int t = 0; t < 9; ++t) A[rs][g][t] = wa[rs][(size_t)(r * RND + 4 * g) * 9 + t];
-            }
+            for (int rs = 0; rs < RS; ++rs)
+                A[rs][q] = ok ? *reinterpret_cast<const f32x4*>(wa[rs] + (size_t)r * (RND * 9) + 16 * q)
+                              : (f32x4){0.f, 0.f, 0.f, 0.f};
         }
         if (lane < PS) {
 #pragma unroll
-            for (int i = 0; i < RND; ++i) pl[i * PS + lane] = P[i];
+            for (int i = 0; i < RND; ++i) pl[i * PS + lane] = P[i];      // (channels past the wave's range: zeros)
         }
         // (a wave reads only what it wrote itself: LDS operations of one wave execute in order, no workgroup barrier)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            if (r * RND + 4 * g < cw) {
+        for (int q = 0; q < NQ; ++q) {
+            if (16 * q < np) {                     // (wave-uniform)
 #pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    const float bv = bl[g * 4 * PS + (t / 3) * PC + (t % 3)];
+                for (int e = 0; e < 4; ++e) {
+                    const float bv = *tb[q][e];
 #pragma unroll
                     for (int rs = 0; rs < RS; ++rs)
-                        acc[rs] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[rs][g][t], bv, acc[rs], 0, 0, 0);
+                        acc[rs] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[rs][q][e], bv, acc[rs], 0, 0, 0);
                 }
             }
         }
         __builtin_amdgcn_wave_barrier();           // the next round's patch overwrites what this round read
     }
     __syncthreads();                               // the reduction buffer overlays the patches
-    small_epilogue<RS>(a, lds, acc, s, cot, pt);
+    small_epilogue<RS>(a, lds, acc, ep);
 }
 
 template <int RS>
