@@ -12,7 +12,9 @@ from view_fusion_amd import ops, train  # noqa: E402
 dev = torch.device("cuda:0")
 model = train.build_model(device="cuda:0")
 tr = train.Trainer(model)
-batch = train.synthetic_batch(16, 6, 64, dev)
+import sys as _s
+B = int(_s.argv[1]) if len(_s.argv) > 1 else 16
+batch = train.synthetic_batch(B, 6, 64, dev)
 for _ in range(2):
     tr.step(batch)
 ops.KERNEL_LOG = []
