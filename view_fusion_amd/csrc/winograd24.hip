@@ -24,6 +24,7 @@
 //     once (A2), every wave finishes a quarter of the channels: bias + per-view bias + residual, float4 row stores.
 // MODE 0: plain input; MODE 2: nearest-x2-upsampled input (Upsample conv), as in conv.hip.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -687,13 +688,23 @@ __global__ __launch_bounds__(256) void wino_fixup_kernel(WinoArgs a, int ntail) 
 }
 
 constexpr int WINO_SLOTS = 256;       // one workgroup per CU
+constexpr double WINO_TAIL_F = 2.5;   // per-part overhead of a K-split tail part, in chunk-times (see wino_tail_time)
 
 // How a grid of T equal tiles is finished when T is not a multiple of the slot count: the last R = T mod 256
-// tiles are split over K into `split` parts each; the parts run in ceil(R*split/256) rounds of 1/split tile
-// time.  `split` is the value in [1, min(8, nch/4)] that wastes the least CU time (ties: fewer parts).
-inline double wino_tail_time(int R, int sp) { return (double)((R * sp + WINO_SLOTS - 1) / WINO_SLOTS) / sp; }
+// tiles are split over K into `split` parts each; the parts run in ceil(R*split/256) rounds.  A part of `per` chunks
+// costs per + F chunk-times, F = the prologue + epilogue + partial-output store of a workgroup in units of one chunk
+// (measured: a tile's epilogue is 23 % of an 8-chunk tile; VF_WINO_TAIL_F overrides, tuning aid).  `split` is the value
+// in [1, min(8, nch/4)] with the shortest tail (ties: fewer parts).
+inline double wino_tail_overhead() {
+    static const double f = getenv("VF_WINO_TAIL_F") ? atof(getenv("VF_WINO_TAIL_F")) : WINO_TAIL_F;
+    return f;
+}
+inline double wino_tail_time(int R, int sp, int nch, double F) {      // in units of one whole tile
+    const int per = (nch + sp - 1) / sp;
+    return (double)((R * sp + WINO_SLOTS - 1) / WINO_SLOTS) * (per + F) / (nch + F);
+}
 
-inline void wino_tail_plan(int T, int nch, int* nfull, int* split) {
+inline void wino_tail_plan(int T, int nch, int* nfull, int* split, double F = wino_tail_overhead()) {
     *nfull = T;
     *split = 1;
     const int R = T % WINO_SLOTS;
@@ -702,7 +713,7 @@ inline void wino_tail_plan(int T, int nch, int* nfull, int* split) {
     for (int sp = 2; sp <= 8 && sp <= nch / 4; ++sp) {    // at least 4 chunks per part
         const int per = (nch + sp - 1) / sp;              // the kernel gives each part `per` chunks:
         if ((nch + per - 1) / per != sp) continue;        // no part may start beyond the last chunk
-        if (wino_tail_time(R, sp) < wino_tail_time(R, best) - 1e-9) best = sp;
+        if (wino_tail_time(R, sp, nch, F) < wino_tail_time(R, best, nch, F) - 1e-9) best = sp;
     }
     if (best < 2) return;
     *nfull = T - R;
@@ -772,15 +783,17 @@ long vf_wino_conv_ws_floats(int S, int Cin, int Cout, int H, int W) {
     return (long)(T - nfull) * split * WTCO * WTT * 8;
 }
 
-// Expected CU fill (percent) of vf_wino_conv_fwd at this shape under its tail plan, and the tile count;
-// hosts use it to choose between this path and the direct kernel.
+// Expected CU fill (percent) of vf_wino_conv_fwd at this shape, and the tile count; hosts use it to choose between
+// this path and the direct kernel.  (Pure occupancy figure: the tail is priced WITHOUT the per-part overhead that
+// the launch's own plan uses, so the hosts' thresholds keep their meaning.)
 int vf_wino_conv_fill_pct(int S, int Cin, int Cout, int H, int W, int* tiles_out) {
     const int T = wino_groups(S, H, W) * (rup(Cout, WTCO) / WTCO);
+    const int nch = rup(Cin, WCK) / WCK;
     int nfull, split;
-    wino_tail_plan(T, rup(Cin, WCK) / WCK, &nfull, &split);
+    wino_tail_plan(T, nch, &nfull, &split, 0.0);
     if (tiles_out) *tiles_out = T;
     if (T <= 0) return 0;
-    const double time = (nfull + WINO_SLOTS - 1) / WINO_SLOTS + (T > nfull ? wino_tail_time(T - nfull, split) : 0.0);
+    const double time = (nfull + WINO_SLOTS - 1) / WINO_SLOTS + (T > nfull ? wino_tail_time(T - nfull, split, nch, 0.0) : 0.0);
     return (int)(100.0 * T / WINO_SLOTS / time);
 }
 
