@@ -9,9 +9,10 @@
 //   weights are read straight from the UNPACKED OIHW parameter (no packed copy to refresh); the eight partial tiles
 //   are summed through LDS in wave order (deterministic), then bias + per-view bias + residual.
 //
-//   3x3 (conv3_small_kernel): a wave stages the zero-haloed patch of its next 8-16 channels in its own LDS region (one
-//   dword per lane and channel, no workgroup barrier: a wave reads only what it wrote), the quarters take 4 channels
-//   of a group, the 9 taps are immediate LDS offsets and 9 consecutive weights per lane.
+//   3x3 (conv3_small_kernel): a wave stages the zero-haloed patch of its next 8 channels in its own LDS region (one
+//   dword per lane and channel, no workgroup barrier: a wave reads only what it wrote); the 72 products of a round are
+//   dealt to the lane quarters in runs of four (one 16-byte weight load per lane and 16 products), their input values
+//   found through a per-lane table of LDS addresses.
 //   1x1 (conv1_small_kernel): the B values are gathered from global memory directly (16 consecutive pixels per
 //   quarter), optionally from the decoder's never-materialised concatenation [x | x2].
 #include "common.h"
