@@ -120,7 +120,9 @@ class Trainer:
     kernel log, world > 1.  The captured step is the same launches on the same data: with the same random draws its
     parameters match the eager step's bit for bit (tests/test_gpu_step_graph.py).  Learning rate and Adam bias
     corrections are read from device memory refreshed before each replay; torch's device RNG advances per replay
-    exactly as it does per eager step."""
+    exactly as it does per eager step.  One rule for callers: keep no tensor with autograd history of THIS model alive
+    across iterations (step() itself returns a detached loss) -- it would keep the parameters' AccumulateGrad nodes
+    bound to the stream they were made on, and a capture that has to follow them there cannot end."""
     GRAPH_AFTER = 2
     GRAPH_MAX = 96
 
