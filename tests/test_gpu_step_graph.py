@@ -162,3 +162,19 @@ def test_graph_steps_survive_an_optimizer_state_reload():
     sa, sb = ta.opt.state_dict()["state"], tb.opt.state_dict()["state"]
     for k in sa:
         assert float(sa[k]["step"]) == float(sb[k]["step"]) == 9 and torch.equal(sa[k]["exp_avg"], sb[k]["exp_avg"])
+
+
+def test_graph_capture_with_an_autograd_graph_of_the_model_kept_alive():
+    """A caller that keeps a tensor with autograd history of the model (a loss it never backpropagated) keeps the
+    parameters' AccumulateGrad nodes bound to the default stream; the captured step must not route through them."""
+    from view_fusion_amd import train
+    ma, mb = _pair(TINY)
+    ta, tb = train.Trainer(ma, graph=False), train.Trainer(mb, graph=True)
+    bt = _batches(1, 2, 3, 16)[0]
+    kept = [m(y_0=bt["y_0"], y_cond=bt["y_cond"], view_count=bt["view_count"], angle=bt["angle"]) for m in (ma, mb)]
+    assert all(k.requires_grad for k in kept)
+    for i in range(5):
+        assert torch.equal(ta.step(bt, **_draws(i, 2, 16)), tb.step(bt, **_draws(i, 2, 16)))
+        for p, q in zip(ma.parameters(), mb.parameters()):
+            assert torch.equal(p, q) and torch.equal(p.grad, q.grad)
+    assert tb.graph_steps == 3 and all(k.requires_grad for k in kept)

@@ -120,9 +120,9 @@ class Trainer:
     kernel log, world > 1.  The captured step is the same launches on the same data: with the same random draws its
     parameters match the eager step's bit for bit (tests/test_gpu_step_graph.py).  Learning rate and Adam bias
     corrections are read from device memory refreshed before each replay; torch's device RNG advances per replay
-    exactly as it does per eager step.  One rule for callers: keep no tensor with autograd history of THIS model alive
-    across iterations (step() itself returns a detached loss) -- it would keep the parameters' AccumulateGrad nodes
-    bound to the stream they were made on, and a capture that has to follow them there cannot end."""
+    exactly as it does per eager step.  The capture runs the forward on fresh leaf aliases of the parameters and takes
+    the gradients with autograd.grad, so autograd state that callers keep alive (a loss with history) cannot pull
+    another stream into it."""
     GRAPH_AFTER = 2
     GRAPH_MAX = 96
 
@@ -147,7 +147,8 @@ class Trainer:
         # modules whose behaviour depends on train/eval mode (see step()): the blocks that carry a Dropout
         self._mode_modules = [m for m in model.modules() if getattr(m, "dropout", 0) and hasattr(m, "_drop")]
         self.sched = LrScheduler(peak_lr=1e-4, peak_it=lr_warmup, decay_it=decay_it, decay_rate=0.16)
-        params = self._params = list(model.parameters())
+        self._named = list(model.named_parameters())
+        params = self._params = [p for _, p in self._named]
         if params[0].is_cuda:       # one multi-tensor HIP launch per step
             from .optim import FusedAdam
             self.opt = FusedAdam(params, lr=self.sched.get_cur_lr(0))
@@ -211,8 +212,17 @@ class Trainer:
         try:
             with torch.cuda.graph(g, capture_error_mode="relaxed", **kw):
                 try:        # an exception must not unwind through the capture: let it end, then report
-                    loss = self.model(view_count=e.view_count, **e.inputs)
-                    loss.backward()
+                    # The captured forward runs on FRESH leaf tensors that alias the parameters' storage
+                    # (functional_call), and its gradients are taken with autograd.grad: nothing passes through the
+                    # parameters' own AccumulateGrad nodes.  Those remember the stream they were created on; if a
+                    # caller keeps ANY tensor with autograd history of this model alive (a loss from an earlier
+                    # forward), they are bound to the default stream, the backward pass forks the capture onto it, and
+                    # hipStreamEndCapture takes the process down.
+                    leaves = {n: p.detach().requires_grad_(True) for n, p in self._named}
+                    loss = torch.func.functional_call(self.model, leaves, (), dict(view_count=e.view_count, **e.inputs))
+                    grads = torch.autograd.grad(loss, list(leaves.values()), allow_unused=True)
+                    for (_, p), gr in zip(self._named, grads):
+                        p.grad = gr
                     self.opt.step_captured(adam, self._scal)
                 except Exception as err:      # noqa: BLE001
                     failed = err
