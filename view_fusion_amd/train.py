@@ -235,7 +235,8 @@ class Trainer:
         e.adam = self.opt.graph_end(adam)
         self._graph_epoch = adam["epoch"]
         e.loss, e.graph = loss.detach(), g
-        e.keep = (fix, tables, offs, getattr(self.module, "gammas", None))       # what the captured launches address besides the graph's own pool
+        # what the captured launches address besides the graph's own pool
+        e.keep = (fix, tables, offs, getattr(self.module, "gammas", None))
         return True
 
     def _graph_step(self, e, vc, batch, extra):
@@ -299,7 +300,6 @@ class Trainer:
         if self.arena is not None:
             self.arena.finish()
         self.opt.step()
-        # detached: a caller that keeps the returned loss must not keep this iteration's autograd graph (and with it the
-        # parameters' AccumulateGrad nodes, which remember the stream they were created on) alive -- a later graph
-        # capture of the iteration runs on its own stream and every node of the backward pass has to follow it there
+        # detached: a caller that keeps the returned loss should not keep this iteration's autograd graph (its saved
+        # activations: several GB at B=16) alive with it
         return loss.detach()
