@@ -109,6 +109,29 @@ def test_conv_small_batch_split_k_forward(dev, Cin, Cout, Hin, KS, mode, S):
     test_conv_fwd_bwd(dev, Cin, Cout, Hin, KS, mode, S)
 
 
+@pytest.mark.parametrize("Cin,Hin,S,use_tap", [(64, 64, 3, True), (128, 32, 2, True), (192, 16, 5, True), (32, 16, 3, False)])
+def test_conv_down2_tap_adds_the_skip_gradient_in_the_dgrad_epilogue(dev, Cin, Hin, S, use_tap):
+    """The encoder's stride-2 conv hands out a second handle on its input (the decoder's skip connection); the
+    gradient arriving through it is added in the sub-pixel dgrad kernel's epilogue."""
+    from view_fusion_amd import ops
+    layer = torch.nn.Conv2d(Cin, Cin, 3, 2, 1)
+    with torch.no_grad():
+        layer.weight.copy_(rnd(Cin, Cin, 3, 3, seed=5) / math.sqrt(Cin * 9))
+        layer.bias.copy_(rnd(Cin, seed=6) * 0.1)
+    x = rnd(S, Cin, Hin, Hin, seed=7)
+    gy, gt = rnd(S, Cin, Hin // 2, Hin // 2, seed=8), rnd(S, Cin, Hin, Hin, seed=9)
+    xc = x.clone().requires_grad_(True)
+    yc = F.conv2d(xc, layer.weight, layer.bias, stride=2, padding=1)
+    ((yc * gy).sum() + ((xc * gt).sum() if use_tap else 0)).backward()
+    wgc = layer.weight.grad.clone()
+    layer.zero_grad()
+    layer = layer.to(dev)
+    xg = x.to(dev).requires_grad_(True)
+    yg, xt = ops.conv2d(xg, layer, mode="down2", tap=True)
+    ((yg * gy.to(dev)).sum() + ((xt * gt.to(dev)).sum() if use_tap else 0)).backward()
+    assert rel(yg, yc) < 2e-5 and rel(xg.grad, xc.grad) < 2e-5 and rel(layer.weight.grad, wgc) < 1e-4
+
+
 SMALL_CASES = [c for c in CONV_CASES if c[4] == "same" and c[0] % (4 if c[3] == 1 else 32) == 0] + [
     (64, 100, 16, 3, "same"), (32, 40, 4, 3, "same"), (68, 33, 8, 1, "same"), (96, 50, 8, 3, "same"),
     (384, 192, 16, 3, "same"), (512, 192, 16, 3, "same"), (256, 128, 32, 3, "same"), (192, 64, 64, 3, "same")]

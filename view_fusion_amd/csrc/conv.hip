@@ -322,14 +322,31 @@ __global__ __launch_bounds__(256, (KS == 1 && NPT == 1 && NCO == 1) ? 5 : 1) voi
             if (s >= a.S) continue;
             const int pi = pix >> LOGW, pj = pix & (G::W - 1);
             const int cob = co0 + cw * 32 + 4 * lh;
-            float* ob = a.y + ((size_t)s * a.Cout + cob) * (4 * G::HW) + (size_t)(2 * pi) * (2 * G::W) + 2 * pj;
+            const size_t oo = ((size_t)s * a.Cout + cob) * (4 * G::HW) + (size_t)(2 * pi) * (2 * G::W) + 2 * pj;
+            float* ob = a.y + oo;
+            // residual (same layout as dx): the gradient that reaches this conv's INPUT through its other consumer
+            // (the decoder's skip connection), added here instead of by an autograd add kernel
+            float2 ra[16], rb[16];
+            if (a.res) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int dco = (r & 3) + 8 * (r >> 2);
+                    if (cob + dco < a.Cout) {
+                        const float* q = a.res + oo + (size_t)dco * (4 * G::HW);
+                        ra[r] = *reinterpret_cast<const float2*>(q);
+                        rb[r] = *reinterpret_cast<const float2*>(q + 2 * G::W);
+                    }
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int dco = (r & 3) + 8 * (r >> 2);
                 if (cob + dco < a.Cout) {
                     float* o = ob + (size_t)dco * (4 * G::HW);
-                    *reinterpret_cast<float2*>(o) = make_float2(acc[0][nt][r], acc[1][nt][r]);
-                    *reinterpret_cast<float2*>(o + 2 * G::W) = make_float2(acc[2][nt][r], acc[3][nt][r]);
+                    float2 v0 = make_float2(acc[0][nt][r], acc[1][nt][r]), v1 = make_float2(acc[2][nt][r], acc[3][nt][r]);
+                    if (a.res) { v0.x += ra[r].x; v0.y += ra[r].y; v1.x += rb[r].x; v1.y += rb[r].y; }
+                    *reinterpret_cast<float2*>(o) = v0;
+                    *reinterpret_cast<float2*>(o + 2 * G::W) = v1;
                 }
             }
         }

@@ -605,9 +605,16 @@ def _conv_small(x, x2, weight, bias, view_bias, residual, S, Cin, Cout, H, W, KS
 
 
 class _Conv2dFn(torch.autograd.Function):
+    """tap (stride-2 convs of the encoder): also return a handle on the INPUT x for the decoder's skip connection,
+    whose gradient is then added in the dgrad kernel's epilogue instead of by an autograd add (as _GroupNormSkipFn
+    does for the residual blocks)."""
+
     @staticmethod
-    def forward(ctx, x, weight, bias, view_bias, residual, layer, mode, training, twin):
+    def forward(ctx, x, weight, bias, view_bias, residual, layer, mode, training, twin, tap=False):
         _check(x, bias, view_bias, residual)
+        ctx.tap = tap
+        if tap:
+            ctx.set_materialize_grads(False)      # an unused handle must not cost a zero tensor
         S, Cin, Hi, Wi = x.shape
         Cout, _, KS, _ = weight.shape
         m = _MODES[mode]
@@ -641,12 +648,13 @@ class _Conv2dFn(torch.autograd.Function):
         ctx.wb, ctx.m, ctx.KS, ctx.Cout = wb, m, KS, Cout
         ctx.has = (bias is not None, view_bias is not None, residual is not None)
         ctx.pw, ctx.pb, ctx.twin = weight, bias, (twin.bias if twin is not None else None)
-        return y
+        return (y, x.view_as(x)) if tap else y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dtap=None):
         (x,) = ctx.saved_tensors
         dy = _c(dy)
+        dtap = _c(dtap) if dtap is not None else None
         S, Cin, Hi, Wi = x.shape
         _, Cout, H, W = dy.shape
         KS, m = ctx.KS, ctx.m
@@ -675,8 +683,9 @@ class _Conv2dFn(torch.autograd.Function):
                         _ptr(ws), nws, S, Cout, Cin, H, W, KS, 0, st, tag=ctx.tag)
             elif m == 1:      # stride-2 conv: sub-pixel transposed conv (each output parity gets its own taps)
                 dx = torch.empty_like(x)
-                _launch("conv_dgrad", ctx.flops, "vf_conv_fwd", _ptr(dy), _ptr(ctx.wb), None, None, None, _ptr(dx),
+                _launch("conv_dgrad", ctx.flops, "vf_conv_fwd", _ptr(dy), _ptr(ctx.wb), None, None, _ptr(dtap), _ptr(dx),
                         None, 0, S, Cout, Cin, H, W, KS, 4, st, tag=ctx.tag)
+                dtap = None
             else:             # upsample + conv: dgrad at the upsampled size, then 2x2 sum-pool
                 dup = torch.empty(S, Cin, H, W, device=x.device, dtype=torch.float32)
                 _launch("conv_dgrad", ctx.flops, "vf_conv_fwd", _ptr(dy), _ptr(ctx.wb), None, None, None, _ptr(dup),
@@ -732,7 +741,9 @@ class _Conv2dFn(torch.autograd.Function):
                 dvb = None
         if hr and ctx.needs_input_grad[4]:
             dres = dy
-        return dx, dw, db, dvb, dres, None, None, None, None
+        if dtap is not None:                          # (a path without the fused epilogue)
+            dx = dtap if dx is None else dx + dtap
+        return dx, dw, db, dvb, dres, None, None, None, None, None
 
 
 class _Conv1x1CatFn(torch.autograd.Function):
@@ -808,8 +819,9 @@ def conv1x1_cat(x1, x2, layer):
     return _Conv1x1CatFn.apply(x1, x2, layer.weight, layer.bias, layer, training)
 
 
-def conv2d(x, layer, view_bias=None, residual=None, mode="same", twin=None):
+def conv2d(x, layer, view_bias=None, residual=None, mode="same", twin=None, tap=False):
     """3x3 (pad 1) or 1x1 convolution with the parameters of `layer` (an nn.Conv2d holder).
+    tap=True: returns (y, x') with x' a handle on x for a second consumer (see _Conv2dFn).
 
     mode "same": stride 1; "down2": stride 2; "up2": nearest x2 upsample fused into the load.
     Epilogue adds bias[c] + view_bias[s,c] + residual.  twin: the 1x1 conv layer that produced `residual` (it has
@@ -822,9 +834,13 @@ def conv2d(x, layer, view_bias=None, residual=None, mode="same", twin=None):
         H, W = (Hi // 2, Wi // 2) if m == 1 else ((Hi * 2, Wi * 2) if m == 2 else (Hi, Wi))
         if use_small_conv(S, Cin, Cout, H, W, KS, m):
             _check(x, layer.bias, view_bias, residual)
-            return _conv_small(x, None, layer.weight, layer.bias, view_bias, residual, S, Cin, Cout, H, W, KS, m)
+            y = _conv_small(x, None, layer.weight, layer.bias, view_bias, residual, S, Cin, Cout, H, W, KS, m)
+            return (y, x) if tap else y
     training = torch.is_grad_enabled() and layer.weight.requires_grad
-    return _Conv2dFn.apply(x, layer.weight, layer.bias, view_bias, residual, layer, mode, training, twin)
+    if tap and torch.is_grad_enabled():
+        return _Conv2dFn.apply(x, layer.weight, layer.bias, view_bias, residual, layer, mode, training, twin, True)
+    y = _Conv2dFn.apply(x, layer.weight, layer.bias, view_bias, residual, layer, mode, training, twin)
+    return (y, x) if tap else y
 
 
 def conv2d_gn(x, layer, gn, groups, silu, view_bias=None, residual=None, mode="same", want_y=False):

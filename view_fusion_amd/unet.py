@@ -154,9 +154,10 @@ class _Resample(nn.Module):
         self.up = up
         self.conv = nn.Conv2d(ch, ch, 3, padding=1) if up else nn.Conv2d(ch, ch, 3, 2, 1)
 
-    def forward(self, x):
+    def forward(self, x, tap=False):
+        """tap (Downsample in the encoder): -> (y, x'), x' = the handle on x that the decoder's skip connection takes."""
         from . import ops
-        return ops.conv2d(x, self.conv, mode="up2" if self.up else "down2")
+        return ops.conv2d(x, self.conv, mode="up2" if self.up else "down2", tap=tap)
 
 
 class UNet(nn.Module):
@@ -305,8 +306,9 @@ class UNet(nn.Module):
         if not torch.is_grad_enabled() and not (self.training and self._has_dropout()):
             return self._forward_inference(x, es)       # (Dropout active: the general path below applies it)
 
-        # feats[i] feeds the next encoder layer AND the decoder: where that next layer is a residual block, the
-        # decoder takes the block's handle on its input instead (see _ResBlock.forward, tap)
+        # feats[i] feeds the next encoder layer AND the decoder: where that next layer is a residual block or a
+        # Downsample conv, the decoder takes that layer's handle on its input instead (see _ResBlock.forward, tap):
+        # the two gradients of feats[i] are then summed inside that layer's backward kernel
         feats = []
         for layer in self.downs:
             if isinstance(layer, _ResAttnBlock):
@@ -314,7 +316,9 @@ class UNet(nn.Module):
                 if feats:
                     feats[-1] = xin
             elif isinstance(layer, _Resample):
-                x = layer(x)
+                x, xin = layer(x, tap=True)
+                if feats:
+                    feats[-1] = xin
             else:
                 x = ops.conv2d(x, layer)
             feats.append(x)
