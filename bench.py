@@ -202,11 +202,14 @@ def _family(kind, name):
     return kind
 
 
-def roofline(trainer, batch, S, ms_step, steps=2):
+def roofline(trainer, batch, S, ms_step, steps=3):
     """Per-launch HIP-event timing (events recorded on the launch stream) of the kernel families over `steps` extra
     iterations after the timed region.  The headline `frac` is the EXECUTED fp32-MFMA fraction of the dominant
     kernel, wino_conv_kernel: its launches' algorithmic direct-convolution FLOPs / 3 (the nested Winograd F(2,3)xF(4,3)
     multiplies 24 values per 2x4 outputs x 9 taps = 72 direct ones) / its own event time / 157.3 TF."""
+    ops.KERNEL_LOG = []
+    trainer.step(batch)              # untimed: the first eager iteration after graph replays (re-made gradient tensors,
+    torch.cuda.synchronize()         # descriptor uploads) runs its first kernels 1-5 % slower than the following ones
     ops.KERNEL_LOG = []
     for _ in range(steps):
         trainer.step(batch)
