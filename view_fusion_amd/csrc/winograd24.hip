@@ -688,6 +688,7 @@ __global__ __launch_bounds__(256) void wino_fixup_kernel(WinoArgs a, int ntail) 
 }
 
 constexpr int WINO_SLOTS = 256;       // one workgroup per CU
+constexpr double WINO_TAIL_G = 4.0;   // cost of the fix-up launch behind a split tail, in chunk-times
 constexpr double WINO_TAIL_F = 2.5;   // per-part overhead of a K-split tail part, in chunk-times (see wino_tail_time)
 
 // How a grid of T equal tiles is finished when T is not a multiple of the slot count: the last R = T mod 256
@@ -699,9 +700,14 @@ inline double wino_tail_overhead() {
     static const double f = getenv("VF_WINO_TAIL_F") ? atof(getenv("VF_WINO_TAIL_F")) : WINO_TAIL_F;
     return f;
 }
+inline double wino_tail_fixup() {     // the fix-up launch a split costs, in chunk-times (VF_WINO_TAIL_G overrides, tuning aid)
+    static const double g = getenv("VF_WINO_TAIL_G") ? atof(getenv("VF_WINO_TAIL_G")) : WINO_TAIL_G;
+    return g;
+}
 inline double wino_tail_time(int R, int sp, int nch, double F) {      // in units of one whole tile
     const int per = (nch + sp - 1) / sp;
-    return (double)((R * sp + WINO_SLOTS - 1) / WINO_SLOTS) * (per + F) / (nch + F);
+    const double fix = (sp > 1 && F > 0.0) ? wino_tail_fixup() : 0.0;
+    return ((double)((R * sp + WINO_SLOTS - 1) / WINO_SLOTS) * (per + F) + fix) / (nch + F);
 }
 
 inline void wino_tail_plan(int T, int nch, int* nfull, int* split, double F = wino_tail_overhead()) {
