@@ -157,6 +157,19 @@ def cpu_baseline(hw, n_views, threads_all=None):
                                     "extrapolated linearly to T=1000"))
 
 
+def pmc_launches():
+    """Launch counts per kernel name in the committed PMC table (whole profiled run): a family's HBM bytes per launcher
+    call = sum over its kernels of bytes per launch x that kernel's launches per launch of the family's main kernels."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_pmc_traffic_kib_per_launch.json")), reverse=True):
+        try:
+            tab = json.load(open(path))
+            return {k: float(d.get("launches", 0)) for k, d in tab.items()}
+        except (OSError, ValueError, AttributeError):
+            continue
+    return {}
+
+
 def pmc_traffic():
     """HBM bytes per launch per kernel from the committed rocprofv3 PMC passes of this same bench command
     (profiles/rNN_bench_pmc_traffic_kib_per_launch.json, newest round first: FETCH_SIZE and WRITE_SIZE collected in
@@ -181,10 +194,29 @@ FAMILIES = {
     "wino_wgrad": ("wino44_wgrad_kernel (Winograd F(4x4,3x3), + slab-sum launch): weight gradient of the stride-1 3x3 layers", "mfma"),
     "direct_wgrad": ("conv1x1_wgrad_kernel / conv_wgrad_kernel (+ reduce): weight gradient of the 1x1 / stride-2 layers", "mfma"),
     "attn_fwd": ("attn_fwd_kh_kernel / attn_fwd_split_kernel", "mfma"),
-    "attn_bwd": ("attention backward", "mfma"),
+    "attn_bwd": ("attention backward: bgemm_v2_kernel x4 + softmax_bwd_kernel on the materialised P", "mfma"),
+    "bgemm": ("bgemm kernels outside attention (noise-level MLP linears)", "mfma"),
+    "reduce": ("colsum / colsum_multi / rowsum / bias_grad / sumpool2 (parameter-gradient and pooling reductions)", "hbm"),
+    "pack": ("pack_weights_multi / wino_pack_multi (weight re-layout, once per step)", "hbm"),
+    "embed": ("time-embedding kernels (sincos, swish, grouped FeatureWiseAffine fwd/bwd)", "hbm"),
+    "diffusion": ("stack_views (q_sample) / compose_fwd / compose_mse_bwd / gather_level", "hbm"),
+    "misc": ("other launchers (concat fallback, dropout, ...)", "hbm"),
     "gn_fwd": ("gn_fwd_kernel (GroupNorm + Swish)", "hbm"),
     "gn_bwd": ("gn_bwd_fused_kernel (+ fused residual / skip gradient adds)", "hbm"),
     "adam": ("adam_multi_kernel", "hbm"),
+}
+
+
+# rocprofv3 kernel names whose PMC bytes make up a family's HBM traffic (profiles/rNN_bench_pmc_traffic_kib_per_launch.json):
+# (kernels the launcher always runs, follow-up kernels it runs for some launches)
+FAMILY_PMC = {
+    "wino_conv": (("wino_conv_kernel", "wino44_conv_kernel"), ("wino_fixup_kernel", "wino44_fixup_kernel")),
+    "wino_wgrad": (("wino44_wgrad_kernel",), ("wino44_reduce_kernel",)),
+    "direct_conv": (("conv_mfma_kernel",), ()),
+    "direct_wgrad": (("conv1x1_wgrad_kernel", "conv_wgrad_kernel"), ("wgrad_reduce_kernel",)),
+    "attn_fwd": (("attn_fwd_kh_kernel",), ()),
+    "attn_bwd": (("bgemm_v2_kernel", "softmax_bwd_kernel"), ()),      # (one launcher call per kernel)
+    "gn_fwd": (("gn_fwd_kernel",), ()), "gn_bwd": (("gn_bwd_fused_kernel",), ()), "adam": (("adam_multi_kernel",), ()),
 }
 
 
@@ -211,9 +243,18 @@ def roofline(trainer, batch, S, ms_step, steps=3):
     trainer.step(batch)              # untimed: the first eager iteration after graph replays (re-made gradient tensors,
     torch.cuda.synchronize()         # descriptor uploads) runs its first kernels 1-5 % slower than the following ones
     ops.KERNEL_LOG = []
+    # the instrumented iterations run EAGERLY (a kernel log forces it) with two events around every launcher: their
+    # own GPU time, bracketed by one more event pair per iteration, is what the family table must sum to -- not the
+    # graph-replay step time of the headline (different launch regime: eager launches carry gaps)
+    step_ev = []
     for _ in range(steps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
         trainer.step(batch)
+        e1.record()
+        step_ev.append((e0, e1))
     torch.cuda.synchronize()
+    eager_ms = sum(a.elapsed_time(b) for a, b in step_ev) / steps
     log, ops.KERNEL_LOG = ops.KERNEL_LOG, None
     agg = {}
     for kind, flops, e0, e1, _tag, name, nbytes in log:
@@ -223,6 +264,7 @@ def roofline(trainer, batch, S, ms_step, steps=3):
         a[2] += 1
         a[3] += nbytes
     traffic, source = pmc_traffic()
+    launches = pmc_launches()
     table = {}
     for fam, (f, s, n, nb) in agg.items():
         label, bound = FAMILIES.get(fam, (fam, "hbm"))
@@ -235,6 +277,14 @@ def roofline(trainer, batch, S, ms_step, steps=3):
         if nb:
             row.update(algorithmic_gbs=nb / s / 1e9, frac_of_hbm_peak=nb / s / 1e9 / PEAK_HBM_GBS,
                        algorithmic_mb_per_launch=nb / n / 1e6)
+        # both roofs per family: HBM bytes of the family's kernels from the committed PMC passes (bytes per
+        # launch x this run's launches per step) over this run's event time
+        mains, helpers = FAMILY_PMC.get(fam, ((), ()))
+        n_main = sum(launches.get(k, 0.0) for k in mains)
+        if n_main:
+            per_call = sum(traffic.get(k, 0.0) * launches.get(k, 0.0) for k in mains + helpers) / n_main
+            row.update(pmc_hbm_mb_per_launch=per_call / 1e6, pmc_gbs=per_call * n / s / 1e9,
+                       frac_of_hbm_peak_pmc=per_call * n / s / 1e9 / PEAK_HBM_GBS)
         table[fam] = row
     # headline family: the Winograd forward/dgrad kernel when any launch took it, else the MFMA-bound family with the
     # largest time (small S: every 3x3 layer runs the direct kernel)
@@ -269,7 +319,12 @@ def roofline(trainer, batch, S, ms_step, steps=3):
                                   winograd_adjusted=floor_ms,
                                   hbm=HBM_MB_PER_VIEW_TRAIN * S / 1e3 / PEAK_HBM_GBS * 1e3),
                step_frac_of_floor=floor_ms / ms_step, kernels=table,
-               unattributed_ms_per_step=ms_step - sum(r["ms_per_step"] for r in table.values()))
+               instrumented_eager_ms_per_step=eager_ms,
+               unattributed_ms_per_step=eager_ms - sum(r["ms_per_step"] for r in table.values()),
+               unattributed_note="GPU time of the instrumented EAGER iteration (one event pair around it) minus the sum "
+                                 "of the per-launcher event pairs of every family: torch's own kernels (randn / rand / "
+                                 "randint, a few copies) and the gaps between launches; the headline ms_per_step is the "
+                                 "graph replay of the same launches")
     return out
 
 
@@ -296,17 +351,21 @@ def sampler_leg():
         S, ms = B * N, r["ms_per_step"]
         gflop = GFLOP_PER_VIEW_FWD * S
         nbytes = PARAM_BYTES + 141.7e6 * S
-        mfma_floor_ms = gflop / PEAK_FP32_MATRIX_TFLOPS
+        # the stride-1 3x3 layers run the nested Winograd kernel from S = 48 on (1/3 of the direct multiplies): the
+        # fraction of the fp32 MFMA peak is priced on EXECUTED multiplies, so it cannot exceed 1
+        wino = S >= 48
+        gflop_exec = gflop - (GFLOP_3X3_S1_PER_VIEW_FWD * S * (1 - 1 / WINO_REDUCTION["wino_conv"]) if wino else 0.0)
+        mfma_floor_ms = gflop_exec / PEAK_FP32_MATRIX_TFLOPS
         row = dict(sampled_views_per_sec=r["sampled_views_per_sec"], ms_per_step=ms,
                    view_unet_evals_per_sec=r["view_unet_evals_per_sec"], steps_timed=steps, graph_replay=bool(S <= 16),
-                   roofline=dict(gflop_per_step=gflop, achieved_tflops=gflop / ms, mfma_floor_ms=mfma_floor_ms,
-                                 frac_of_fp32_mfma_peak=mfma_floor_ms / ms,
+                   roofline=dict(gflop_per_step=gflop, executed_gflop_per_step=gflop_exec,
+                                 direct_equivalent_tflops=gflop / ms, achieved_tflops=gflop_exec / ms,
+                                 mfma_floor_ms=mfma_floor_ms, frac_of_fp32_mfma_peak=mfma_floor_ms / ms,
                                  mbytes_per_step=nbytes / 1e6, hbm_floor_ms=nbytes / PEAK_HBM_GBS / 1e6,
                                  frac_of_hbm_peak=nbytes / PEAK_HBM_GBS / 1e6 / ms,
                                  weight_stream_floor_ms=PARAM_BYTES / PEAK_HBM_GBS / 1e6))
-        if S >= 48:      # the stride-1 3x3 layers run the nested Winograd kernel (1/3 of the direct multiplies)
-            wino_gflop = gflop - GFLOP_3X3_S1_PER_VIEW_FWD * S * (1 - 1 / WINO_REDUCTION["wino_conv"])
-            row["roofline"]["frac_of_winograd_floor"] = wino_gflop / PEAK_FP32_MATRIX_TFLOPS / ms
+        if wino:
+            row["roofline"]["frac_of_winograd_floor"] = mfma_floor_ms / ms
         n_launch = getattr(sampling_bench, "LAST_LAUNCHES_PER_STEP", None)
         if n_launch:
             row["roofline"].update(abi_launcher_calls_per_step=n_launch, us_per_launcher_call=ms * 1e3 / n_launch)
@@ -328,7 +387,8 @@ def main():
     ap.add_argument("--graph", type=int, default=int(os.environ.get("VF_STEP_GRAPH", "1")),
                     help="1 (default): single-process runs replay the iteration as one HIP graph per batch geometry -- the "
                          "same launches on the same data, host enqueue 0.4 instead of 13 ms per step; 0: eager launches. "
-                         "Multi-process runs (gradient arena + RCCL) always launch eagerly.")
+                         "Multi-process runs with the gradient arena replay too (the segment all-reduces are part of "
+                         "the graph on RCCL); VF_REDUCER=ddp stays eager.")
     args = ap.parse_args()
 
     rank, local_rank, world = train.init_distributed()
@@ -347,7 +407,9 @@ def main():
         torch.cuda.synchronize()
 
     # a graph is captured on the (GRAPH_AFTER+1)-th iteration of a geometry: keep the capture out of the timed region
-    for _ in range(max(args.warmup, train.Trainer.GRAPH_AFTER + 1) if trainer.use_graph else args.warmup):
+    # (with the gradient arena one more: its first iteration lays the arena out and is not a sighting)
+    need = train.Trainer.GRAPH_AFTER + 1 + (1 if trainer.arena is not None else 0)
+    for _ in range(max(args.warmup, need) if trainer.use_graph else args.warmup):
         trainer.step(batch)
     barrier()
     t0 = time.perf_counter()

@@ -230,8 +230,10 @@ def test_gradient_arena_matches_plain_training(dev):
     """§8(e): the data-parallel reducer on the GPU over RCCL (a world of one rank -- the box has one GPU): with
     the gradient arena every dW/db/dgamma/dbeta is written into the communication buffer by the backward kernels
     (no gradient is copied from the second iteration on), segments are all-reduced asynchronously, and the
-    parameters after three Adam steps are bit-identical to single-process training (same kernels, only the
-    destination of the gradients differs).  World-size-2 semantics are covered on CPU (tests/test_ddp_gloo.py)."""
+    parameters after eight Adam steps are bit-identical to single-process training (same kernels, only the
+    destination of the gradients differs) -- launched eagerly AND with the whole iteration, the six segment
+    all-reduces on RCCL's stream included, replayed as one HIP graph (the launch path of bench.py --gpus N).
+    World-size-2 semantics are covered on CPU (tests/test_ddp_gloo.py) and by tests/test_gpu_two_rank.py."""
     import socket
     import torch.distributed as dist
     from view_fusion_amd import reducer, train
@@ -241,9 +243,9 @@ def test_gradient_arena_matches_plain_training(dev):
     s.close()
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     g = torch.Generator().manual_seed(9)
-    B, N = 4, 3
+    B, N, STEPS = 4, 3, 8
     batches = []
-    for _ in range(3):
+    for _ in range(STEPS):
         batches.append(dict(y_0=torch.rand(B, 3, 16, 16, generator=g).to(dev),
                             y_cond=torch.rand(B, N, 3, 16, 16, generator=g).to(dev),
                             angle=(2 * np.pi / 24 * torch.randint(0, 24, (B, 1), generator=g).float()).to(dev),
@@ -251,9 +253,9 @@ def test_gradient_arena_matches_plain_training(dev):
                             noise=torch.randn(B, 3, 16, 16, generator=g).to(dev),
                             t=torch.randint(1, 2000, (B,), generator=g).to(dev), u=torch.rand(B, 1, generator=g).to(dev)))
 
-    def run(world):
+    def run(world, graph):
         vf = make_vf(TINY, SCHED_TRAIN, dev, True)
-        tr = train.Trainer(vf, world=world, lr_warmup=1)
+        tr = train.Trainer(vf, world=world, lr_warmup=1, graph=graph)
         tr.it = 0
         copied = []
         for b in batches:
@@ -265,17 +267,23 @@ def test_gradient_arena_matches_plain_training(dev):
             copied.append(tr.arena.copied if tr.arena is not None else None)
         return vf, tr, copied
 
-    plain, _, _ = run(1)
+    plain, _, _ = run(1, False)
     train.init_rccl_group(0, rank=0, world_size=1)            # the harness' own group setup (high-priority RCCL streams)
     try:
-        vf, tr, copied = run(2)                          # world=2 only selects the reducer; the group has one rank
-        a = tr.arena
-        assert a is not None and reducer.ACTIVE is a
-        assert copied[1:] == [0, 0], copied              # zero-copy from the second iteration on
-        assert all(p.grad.data_ptr() == a.base + 4 * a.off[i] for i, p in enumerate(a.params))
-        assert len(a.seg_range) >= 2 and a.seg_range[-1][1] == a.flat.numel()
-        for (k, p), q in zip(vf.state_dict().items(), plain.state_dict().values()):
-            assert torch.equal(p, q), k
+        for graph in (False, True):
+            vf, tr, copied = run(2, graph)               # world=2 only selects the reducer; the group has one rank
+            a = tr.arena
+            assert a is not None and reducer.ACTIVE is a
+            assert copied[1:] == [0] * (STEPS - 1), copied   # zero-copy from the second iteration on (capture included)
+            assert all(p.grad.data_ptr() == a.base + 4 * a.off[i] for i, p in enumerate(a.params))
+            assert len(a.seg_range) >= 2 and a.seg_range[-1][1] == a.flat.numel()
+            if graph:                                    # iterations 0-2 eager (layout, two sightings), then replays
+                assert a.capturable and tr.graph_steps == STEPS - 1 - train.Trainer.GRAPH_AFTER, tr.graph_steps
+            else:
+                assert tr.graph_steps == 0
+            for (k, p), q in zip(vf.state_dict().items(), plain.state_dict().values()):
+                assert torch.equal(p, q), (graph, k)
+            reducer.ACTIVE = None
     finally:
         reducer.ACTIVE = None
         dist.destroy_process_group()
@@ -337,6 +345,28 @@ def test_full_size_train_step_vs_oracle(dev, B, N, ragged):
             if err > worst:
                 worst, wk = err, k
     assert worst < 1e-4, (worst, wk)
+    if B != 16 or ragged:
+        return
+    # ... and the path bench.py TIMES: the same iteration replayed from the Trainer's HIP graph (learning rate 0, so
+    # that every iteration starts from the same parameters; the third one is a replay) against the same oracle values
+    from view_fusion_amd import train
+    vf.zero_grad(set_to_none=True)
+    tr = train.Trainer(vf, graph=True, lr_warmup=1)
+    tr.sched.peak_lr = 0.0
+    bt = dict(y_0=y_0.to(dev), y_cond=y_cond.to(dev), angle=angle.to(dev), view_count=vc)
+    draws = dict(t=t.to(dev), u=u.to(dev), noise=noise.to(dev))
+    for _ in range(train.Trainer.GRAPH_AFTER + 1):
+        lg = tr.step(bt, **draws)
+    assert tr.graph_steps == 1
+    assert abs(lg.item() - lref) <= 1e-5 * abs(lref), (lg.item(), lref)
+    worst, wk = 0.0, None
+    for k, p in vf.denoise_fn.named_parameters():
+        a, b = p.grad.detach().cpu().double(), sd[k].grad.double()
+        if float(b.norm()) > 1e-4:
+            err = float((a - b).norm() / b.norm())
+            if err > worst:
+                worst, wk = err, k
+    assert worst < 1e-4, ("graph replay", worst, wk)
 
 
 @pytest.mark.parametrize("use_graph", [True, False])

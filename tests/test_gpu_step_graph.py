@@ -35,25 +35,29 @@ def _same(ma, mb):
         assert torch.equal(p, q), k
 
 
-@pytest.mark.parametrize("hp,B,N,hw", [(TINY, 2, 3, 16), (SMALL, 4, 2, 64)])
-def test_graph_step_matches_eager_bitwise_with_injected_draws(hp, B, N, hw):
+@pytest.mark.parametrize("hp,B,N,hw,n", [(TINY, 2, 3, 16, 6), (SMALL, 4, 2, 64, 6),
+                                         # the geometries bench.py times: BASELINE C2 (S = 96: Winograd tail-split
+                                         # workspaces, wino_pack_multi, the deferred colsum_multi table inside the
+                                         # capture) and C4 (S = 48), three replays each
+                                         (SMALL, 16, 6, 64, 5), (SMALL, 8, 6, 64, 5)])
+def test_graph_step_matches_eager_bitwise_with_injected_draws(hp, B, N, hw, n):
     from view_fusion_amd import train
     ma, mb = _pair(hp)
     ta, tb = train.Trainer(ma, graph=False, lr_warmup=4), train.Trainer(mb, graph=True, lr_warmup=4)
-    batches = _batches(6, B, N, hw)
+    batches = _batches(n, B, N, hw)
     vc = batches[0]["view_count"]
     for i, bt in enumerate(batches):
         bt["view_count"] = vc                        # one geometry
         la, lb = ta.step(bt, **_draws(i, B, hw)), tb.step(bt, **_draws(i, B, hw))
         assert torch.equal(la, lb), i
         _same(ma, mb)
-    assert ta.graph_steps == 0 and tb.graph_steps == 6 - train.Trainer.GRAPH_AFTER
+    assert ta.graph_steps == 0 and tb.graph_steps == n - train.Trainer.GRAPH_AFTER
     # .grad shows the last iteration's gradients, the optimizer state continues where the eager one is
     for p, q in zip(ma.parameters(), mb.parameters()):
         assert torch.equal(p.grad, q.grad)
     sa, sb = ta.opt.state_dict()["state"], tb.opt.state_dict()["state"]
     for k in sa:
-        assert float(sa[k]["step"]) == float(sb[k]["step"]) == 6
+        assert float(sa[k]["step"]) == float(sb[k]["step"]) == n
         assert torch.equal(sa[k]["exp_avg"], sb[k]["exp_avg"]) and torch.equal(sa[k]["exp_avg_sq"], sb[k]["exp_avg_sq"])
     # an eager iteration after the replays (a kernel log forces it) continues from the same state
     bt = batches[0]

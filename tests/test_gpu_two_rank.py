@@ -18,14 +18,17 @@ from conftest import TINY
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SCHED = dict(schedule="linear", num_timesteps=2000, linear_start=1e-6, linear_end=1e-2)
-B, N, HW, STEPS = 12, 6, 16, 3
+B, N, HW = 12, 6, 16
 
 
-def _batch(step, rank):
+def _batch(step, rank, ragged=True):
     g = torch.Generator().manual_seed(100 * step + rank)
+    vc = torch.randint(1, N + 1, (B,), generator=g)
+    if not ragged:                                # one geometry for every step: the graph variant replays it
+        vc = torch.full((B,), N)
     return dict(y_0=torch.rand(B, 3, HW, HW, generator=g), y_cond=torch.rand(B, N, 3, HW, HW, generator=g),
                 angle=2 * np.pi / 24 * torch.randint(0, 24, (B, 1), generator=g).float(),
-                view_count=torch.randint(1, N + 1, (B,), generator=g),
+                view_count=vc,
                 noise=torch.randn(B, 3, HW, HW, generator=g), t=torch.randint(1, 2000, (B,), generator=g),
                 u=torch.rand(B, 1, generator=g))
 
@@ -56,23 +59,26 @@ def _run(tr, vf, batches, dev):
     return grads
 
 
-def _worker(rank, world, port, out, lr):
+def _worker(rank, world, port, out, lr, kind, graph, steps):
     sys.path.insert(0, ROOT)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      VF_REDUCER=kind)
     import torch.distributed as dist
     from view_fusion_amd import train
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     vf = _model(dev)
-    tr = train.Trainer(vf, world=world, lr_warmup=1)
+    tr = train.Trainer(vf, world=world, lr_warmup=1, graph=graph)
+    assert (tr.arena is not None) == (kind == "arena")
     tr.it, tr.sched.peak_lr = 0, lr
     copied = []
     grads = []
-    for s in range(STEPS):
-        grads += _run(tr, vf, [_batch(s, rank)], dev)
-        copied.append(tr.arena.copied)
-    out[rank] = dict(grads=grads, copied=copied, params=[p.detach().cpu().clone() for p in vf.parameters()])
+    for s in range(steps):
+        grads += _run(tr, vf, [_batch(s, rank, ragged=not graph)], dev)
+        copied.append(tr.arena.copied if tr.arena is not None else 0)
+    out[rank] = dict(grads=grads, copied=copied, params=[p.detach().cpu().clone() for p in vf.parameters()],
+                     graph_steps=tr.graph_steps)
     dist.destroy_process_group()
 
 
@@ -84,24 +90,30 @@ def _free_port():
     return p
 
 
-def _spawn(lr):
+def _spawn(lr, kind="arena", graph=False, steps=3):
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_worker, args=(2, _free_port(), out, lr), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), out, lr, kind, graph, steps), nprocs=2, join=True)
     return out[0], out[1]
 
 
-def test_two_rank_arena_gradients_match_the_global_batch():
+# arena: eager launches / the iteration replayed as a HIP graph (gloo cannot be captured: the graph ends with the
+# backward pass, the segment all-reduces and the Adam launch follow each replay -- train.Trainer, "split" mode);
+# ddp: torch's DistributedDataParallel around the same HIP model (VF_REDUCER=ddp, the fallback of tools/scale_run.md)
+@pytest.mark.parametrize("kind,graph,STEPS", [("arena", False, 3), ("arena", True, 6), ("ddp", False, 3)])
+def test_two_rank_arena_gradients_match_the_global_batch(kind, graph, STEPS):
     from view_fusion_amd import train
-    r0, r1 = _spawn(lr=0.0)                       # lr 0: every iteration starts from the same parameters
+    r0, r1 = _spawn(0.0, kind, graph, STEPS)      # lr 0: every iteration starts from the same parameters
     assert r0["copied"][1:] == [0] * (STEPS - 1) and r1["copied"][1:] == [0] * (STEPS - 1), (r0["copied"], r1["copied"])
+    want = STEPS - 1 - train.Trainer.GRAPH_AFTER if graph else 0
+    assert r0["graph_steps"] == r1["graph_steps"] == want, (r0["graph_steps"], r1["graph_steps"])
     dev = torch.device("cuda:0")
     vf = _model(dev)
-    tr = train.Trainer(vf, world=1, lr_warmup=1)
+    tr = train.Trainer(vf, world=1, lr_warmup=1, graph=False)
     tr.it, tr.sched.peak_lr = 0, 0.0
     glob = []
     for s in range(STEPS):
-        a, b = _batch(s, 0), _batch(s, 1)
+        a, b = _batch(s, 0, not graph), _batch(s, 1, not graph)
         glob.append({k: torch.cat([a[k], b[k]]) for k in a})
     ref = _run(tr, vf, glob, dev)
     names = [k for k, _ in vf.named_parameters()]
@@ -112,8 +124,9 @@ def test_two_rank_arena_gradients_match_the_global_batch():
             assert err <= 2e-5 * float(gr.double().norm()) + 1e-7 * gr.numel() ** 0.5, (s, k, err)
 
 
-def test_two_rank_arena_replicas_stay_in_lock_step():
-    r0, r1 = _spawn(lr=1e-4)
+@pytest.mark.parametrize("kind,graph,STEPS", [("arena", False, 3), ("arena", True, 6), ("ddp", False, 3)])
+def test_two_rank_arena_replicas_stay_in_lock_step(kind, graph, STEPS):
+    r0, r1 = _spawn(1e-4, kind, graph, STEPS)
     for a, b in zip(r0["params"], r1["params"]):
         assert torch.equal(a, b)
     moved = max(float((a - b).abs().max()) for a, b in zip(r0["params"], [p.detach().cpu() for p in _model(torch.device("cuda:0")).parameters()]))

@@ -61,6 +61,26 @@ def _launch(kind, flops, name, *args, tag=None, nbytes=0.0):
     KERNEL_LOG.append((kind, flops, e0, e1, tag, name, nbytes))
 
 
+# Launchers without a roofline of their own still get a family in the bench's table (so that the table sums to the
+# instrumented step): kind by entry point, "misc" otherwise.
+_CALL_KIND = {"vf_bgemm": "bgemm", "vf_softmax_bwd": "attn_bwd", "vf_softmax_fwd": "attn_fwd",
+              "vf_colsum": "reduce", "vf_colsum_multi": "reduce", "vf_rowsum": "reduce", "vf_bias_grad": "reduce",
+              "vf_sumpool2": "reduce", "vf_conv_pack_weights": "pack", "vf_wino_pack_weights": "pack",
+              "vf_conv_pack_weights_multi": "pack", "vf_wino_pack_weights_multi": "pack",
+              "vf_time_affine_fwd": "embed", "vf_time_affine_bwd": "embed", "vf_sincos_embed": "embed",
+              "vf_swish_fwd": "embed", "vf_swish_bwd": "embed",
+              "vf_stack_views": "diffusion", "vf_compose_fwd": "diffusion", "vf_compose_mse_bwd": "diffusion",
+              "vf_gather_level": "diffusion", "vf_p_sample_tail": "diffusion"}
+_KIND_OVERRIDE = None       # (attention backward labels its batched GEMMs)
+
+
+def _call(name, *args, flops=0.0, nbytes=0.0):
+    if KERNEL_LOG is None:
+        _lib.call(name, *args)
+        return
+    _launch(_KIND_OVERRIDE or _CALL_KIND.get(name, "misc"), flops, name, *args, nbytes=nbytes)
+
+
 # ---------------------------------------------------------------------------------------------
 # split-K / slab workspace: one buffer per (device, stream) -- launches on one stream are ordered, so consecutive
 # kernels may reuse it; two streams (two models driven concurrently) get separate buffers.  Grown on demand.
@@ -133,18 +153,28 @@ def _gout(p, *shape, like):
 
 
 # GroupNorm weight / bias gradients = column sums over the views of the per-(view, channel) partials the backward kernel
-# emits: ~70 launches of 5 us per backward pass.  Single-process training defers them: every GroupNorm backward only
-# registers its (partials, destination) pair, and ONE multi-tensor launch at the end of the backward pass (an autograd
-# engine callback) fills all destinations.  Deferral needs the destination to be adopted by AccumulateGrad without being
-# READ, so it is taken only when both parameters' .grad is None (zero_grad(set_to_none=True), what Trainer.step does);
-# with the data-parallel gradient arena active the sums stay immediate (a segment's all-reduce is launched as soon as
-# its last gradient is registered).  COLSUM_DEFER = False restores the immediate launches.
+# emits: ~70 launches of 5 us per backward pass.  They are deferred: every GroupNorm backward only registers its
+# (partials, destination) pair, and ONE multi-tensor launch fills all destinations -- at the end of the backward pass (an
+# autograd engine callback) in single-process training, or, with the data-parallel gradient arena, right before a
+# segment's all-reduce is issued (reducer.GradArena calls flush_colsums(): ~6 launches per pass instead of 73).
+# Deferral hands autograd a destination that is FILLED LATER, so it is only taken when nothing can read the gradient
+# before the flush:
+#   * both parameters' .grad is None (AccumulateGrad then adopts the tensor without reading it; zero_grad(set_to_none=
+#     True), what Trainer.step does);
+#   * no tensor hook / post-accumulate-grad hook sits on the parameters (the arena's own hook is the one exception: it
+#     flushes before it lets a segment go);
+#   * nobody has switched COLSUM_DEFER off: torch's DistributedDataParallel copies a gradient into its bucket from a
+#     hook on the AccumulateGrad NODE (invisible from the tensor) while the backward pass is still running, so Trainer
+#     sets COLSUM_DEFER = False when it wraps the model in DDP (VF_REDUCER=ddp).
+# A backward pass that raises never runs its engine callbacks: the entries it left behind are recognised by their
+# autograd graph-task id and dropped by the next pass (their destinations belong to a pass that produced no step).
 COLSUM_DEFER = True
 _PENDING_COLSUMS = []
+_PENDING_TASK = None      # torch._C._current_graph_task_id() of the backward pass the pending entries belong to
 
 
 _CS_TABLE = {}          # device -> {"rows": last uploaded table, "ring": [[pinned, device table, event, rows], ...], "next": i}
-_CS_RING = 4            # staging buffers in rotation: an upload never waits for a copy younger than four backward passes
+_CS_RING = 16           # staging buffers in rotation (the gradient arena flushes once per segment: ~6 tables per pass)
 
 
 # A captured training step (train.Trainer) launches its table-driven kernels on device tables whose CONTENTS are only
@@ -158,7 +188,7 @@ _CAPTURE_TABLE = None   # [device table (rows x 6 int64), rows used, host rows, 
 
 def begin_capture(device, max_rows):
     global _CAPTURE_TABLE
-    _CAPTURE_TABLE = [torch.empty(max(1, max_rows), 6, dtype=torch.int64, device=device), 0, None, None]
+    _CAPTURE_TABLE = [torch.empty(max(1, max_rows), 6, dtype=torch.int64, device=device), 0, [], []]
 
 
 def prime_tables(net, S, device):
@@ -182,27 +212,31 @@ def end_capture():
     long as it replays the graph."""
     global _CAPTURE_TABLE
     ct, _CAPTURE_TABLE = _CAPTURE_TABLE, None
+    drop_pending_colsums()          # (only a capture that failed half-way leaves any)
     if ct is not None and ct[1]:
-        ct[0][:ct[1]].copy_(ct[2])
+        ct[0][:ct[1]].copy_(torch.tensor(ct[2], dtype=torch.int64))
     return ct
 
 
 def _flush_colsums():
-    global _PENDING_COLSUMS
-    pend, _PENDING_COLSUMS = _PENDING_COLSUMS, []
+    global _PENDING_COLSUMS, _PENDING_TASK
+    pend, _PENDING_COLSUMS, _PENDING_TASK = _PENDING_COLSUMS, [], None
     if not pend:
         return
     if torch.cuda.is_current_stream_capturing():
+        # (several flushes per capture with the gradient arena: each takes the next rows of the pre-allocated table)
         ct = _CAPTURE_TABLE
         rows, first = [], 0
         for parts, dgb, batch, S, C in pend:
             rows.append([parts.data_ptr(), dgb.data_ptr(), S, C, batch, first])
             first += ((C + 63) // 64) * batch
-        if ct is None or ct[1] or len(rows) > ct[0].shape[0]:
+        if ct is None or ct[1] + len(rows) > ct[0].shape[0]:
             raise _lib.VFHipError("deferred GroupNorm parameter sums inside a stream capture need ops.begin_capture() "
                                   "with room for every GroupNorm layer (one backward pass per capture)")
-        _lib.call("vf_colsum_multi", ctypes.c_void_p(ct[0].data_ptr()), len(rows), first, _stream())
-        ct[1], ct[2], ct[3] = len(rows), torch.tensor(rows, dtype=torch.int64), pend
+        _call("vf_colsum_multi", ctypes.c_void_p(ct[0].data_ptr() + 48 * ct[1]), len(rows), first, _stream())
+        ct[1] += len(rows)
+        ct[2] += rows
+        ct[3].append(pend)
         return
     key = tuple(v for e in pend for v in (e[0].data_ptr(), e[1].data_ptr(), e[3], e[4]))
     dev = pend[0][0].device
@@ -233,20 +267,47 @@ def _flush_colsums():
         slot[1][:len(rows)].copy_(slot[0][:len(rows)], non_blocking=True)
         slot[2].record()
         slot[3], slot[4], slot[5] = key, len(rows), first
-    _lib.call("vf_colsum_multi", ctypes.c_void_p(slot[1].data_ptr()), slot[4], slot[5], _stream())
+    _call("vf_colsum_multi", ctypes.c_void_p(slot[1].data_ptr()), slot[4], slot[5], _stream())
     _flush_colsums.keep = pend          # the partials / destinations stay referenced until the next flush
 
 
+def _defer_ok(params):
+    a = reducer.ACTIVE
+    for p in params:
+        if p is None or p.grad is not None or getattr(p, "_backward_hooks", None):
+            return False
+        if a is None and getattr(p, "_post_accumulate_grad_hooks", None):
+            return False
+    return a is None or getattr(a, "flushes_colsums", False)
+
+
 def _colsum(parts, dgb, batch, S, C, params):
-    """dgb[b][c] = sum_s parts[b][s][c], now or (see above) at the end of the running backward pass."""
-    if (COLSUM_DEFER and reducer.ACTIVE is None and all(p is not None and p.grad is None for p in params)
-            and torch._C._current_graph_task_id() != -1
+    """dgb[b][c] = sum_s parts[b][s][c], now or (see above) deferred to the flush of the running backward pass."""
+    global _PENDING_TASK
+    task = torch._C._current_graph_task_id()
+    if (COLSUM_DEFER and task != -1 and _defer_ok(params)
             and (_CAPTURE_TABLE is not None or not torch.cuda.is_current_stream_capturing())):
+        if _PENDING_COLSUMS and _PENDING_TASK != task:
+            _PENDING_COLSUMS.clear()          # left behind by a backward pass that failed (its callback never ran)
         if not _PENDING_COLSUMS:
+            _PENDING_TASK = task
             torch.autograd.Variable._execution_engine.queue_callback(_flush_colsums)
         _PENDING_COLSUMS.append((parts, dgb, batch, S, C))
         return
-    _lib.call("vf_colsum", _ptr(parts), _ptr(dgb), batch, S, C, _stream())
+    _call("vf_colsum", _ptr(parts), _ptr(dgb), batch, S, C, _stream())
+
+
+def flush_colsums():
+    """Fill the destinations registered so far (the gradient arena calls this before a segment's all-reduce)."""
+    if _PENDING_COLSUMS:
+        _flush_colsums()
+
+
+def drop_pending_colsums():
+    """Forget deferred sums of a backward pass that did not complete (capture failure paths)."""
+    global _PENDING_TASK
+    _PENDING_COLSUMS.clear()
+    _PENDING_TASK = None
 
 
 def _gn_backward(ctx, dy, addend, addend2=None):
@@ -416,7 +477,7 @@ def _packed(layer, force):
         wb = torch.empty(nb.value, device=w.device, dtype=torch.float32)
     wd = w.detach()
     _check(wd)
-    _lib.call("vf_conv_pack_weights", _ptr(wd), _ptr(wf), _ptr(wb), Cout, Cin, KS, _stream())
+    _call("vf_conv_pack_weights", _ptr(wd), _ptr(wf), _ptr(wb), Cout, Cin, KS, _stream())
     object.__setattr__(layer, "_vf_pack", (None if force else key, wf, wb))   # training packs are never cache hits
     return wf, wb
 
@@ -469,7 +530,7 @@ def _packed_wino(layer, force):
         ub = torch.empty(nb.value, device=w.device, dtype=torch.float32)
     wd = w.detach()
     _check(wd)
-    _lib.call("vf_wino_pack_weights", _ptr(wd), _ptr(uf), _ptr(ub), Cout, Cin, _stream())
+    _call("vf_wino_pack_weights", _ptr(wd), _ptr(uf), _ptr(ub), Cout, Cin, _stream())
     object.__setattr__(layer, "_vf_wpack", (None if force else key, uf, ub))
     return uf, ub
 
@@ -522,9 +583,9 @@ def pack_all(root, S=None):
         object.__setattr__(root, "_vf_pack_plan", plan)
     (desc_d, nd, blk_d), (desc_w, nw, blk_w) = plan[2], plan[3]
     if nd:
-        _lib.call("vf_conv_pack_weights_multi", ctypes.c_void_p(desc_d.data_ptr()), nd, blk_d, _stream())
+        _call("vf_conv_pack_weights_multi", ctypes.c_void_p(desc_d.data_ptr()), nd, blk_d, _stream())
     if nw:
-        _lib.call("vf_wino_pack_weights_multi", ctypes.c_void_p(desc_w.data_ptr()), nw, blk_w, _stream())
+        _call("vf_wino_pack_weights_multi", ctypes.c_void_p(desc_w.data_ptr()), nw, blk_w, _stream())
     # A training pack is consumed once, through its `_fresh` flag, by this forward's conv2d call.  Its cache key stays
     # None (and the key of the layer's OTHER format is dropped too): an optimizer may update the weights without
     # touching `_version` (torch._fused_adam_), so after a training forward no cached pack of either format may be
@@ -562,7 +623,7 @@ def _packed_b3(layer, force):
         wb = torch.empty(nb, device=w.device, dtype=torch.int32)
     wd = w.detach()
     _check(wd)
-    _lib.call("vf_conv1x1_bf16x3_pack", _ptr(wd), ctypes.c_void_p(wf.data_ptr()), ctypes.c_void_p(wb.data_ptr()), Cout, Cin,
+    _call("vf_conv1x1_bf16x3_pack", _ptr(wd), ctypes.c_void_p(wf.data_ptr()), ctypes.c_void_p(wb.data_ptr()), Cout, Cin,
               _stream())
     object.__setattr__(layer, "_vf_pack3", (None if force else key, wf, wb))
     return wf, wb
@@ -668,7 +729,7 @@ class _Conv2dFn(torch.autograd.Function):
                     nbytes=4.0 * (dy.numel() + dfull.numel() + ctx.pw.numel()))
             if m == 2:                                 # upsample + conv: 2x2 sum-pool back to the source size
                 dx = torch.empty_like(x)
-                _lib.call("vf_sumpool2", _ptr(dfull), _ptr(dx), dx.numel(), Wi, st)
+                _call("vf_sumpool2", _ptr(dfull), _ptr(dx), dx.numel(), Wi, st)
             else:
                 dx = dfull
         elif ctx.needs_input_grad[0] and ctx.b3:
@@ -691,7 +752,7 @@ class _Conv2dFn(torch.autograd.Function):
                 _launch("conv_dgrad", ctx.flops, "vf_conv_fwd", _ptr(dy), _ptr(ctx.wb), None, None, None, _ptr(dup),
                         None, 0, S, Cout, Cin, H, W, KS, 0, st, tag=ctx.tag)
                 dx = torch.empty_like(x)
-                _lib.call("vf_sumpool2", _ptr(dup), _ptr(dx), dx.numel(), Wi, st)
+                _call("vf_sumpool2", _ptr(dup), _ptr(dx), dx.numel(), Wi, st)
         hb, hv, hr = ctx.has
         want_b, want_v = hb and ctx.needs_input_grad[2], hv and ctx.needs_input_grad[3]
         arena = reducer.ACTIVE is not None
@@ -723,14 +784,14 @@ class _Conv2dFn(torch.autograd.Function):
                 if Cout >= 192:                  # one launch, one workgroup per channel (enough channels to fill the chip)
                     db_new = _gout(ctx.pb, Cout, like=x) if (want_b and db is None) else None
                     dvb = torch.empty(S, Cout, device=x.device, dtype=torch.float32) if want_v else None
-                    _lib.call("vf_bias_grad", _ptr(dy), _ptr(db_new), _ptr(dvb), S, Cout, H * W, st)
+                    _call("vf_bias_grad", _ptr(dy), _ptr(db_new), _ptr(dvb), S, Cout, H * W, st)
                     db = db_new if db_new is not None else db
                 else:                            # few channels: wave-per-row partial sums, then the column sum
                     dvb = torch.empty(S, Cout, device=x.device, dtype=torch.float32)
-                    _lib.call("vf_rowsum", _ptr(dy), _ptr(dvb), S * Cout, H * W, st)
+                    _call("vf_rowsum", _ptr(dy), _ptr(dvb), S * Cout, H * W, st)
             if want_b and db is None:
                 db = _gout(ctx.pb, Cout, like=x)
-                _lib.call("vf_colsum", _ptr(dvb), _ptr(db), 1, S, Cout, st)
+                _call("vf_colsum", _ptr(dvb), _ptr(db), 1, S, Cout, st)
             if hr and want_b:                    # the residual branch (1x1 conv) receives this very dY
                 # a tensor living in the gradient arena is all-reduced in place as soon as its segment is complete:
                 # it must never be handed to a second layer (which gets db2, or re-derives db from the row sums)
@@ -801,9 +862,9 @@ class _Conv1x1CatFn(torch.autograd.Function):
                 dvb = hit[1] if hit is not None else None
                 if dvb is None:
                     dvb = torch.empty(S, Cout, device=x1.device, dtype=torch.float32)
-                    _lib.call("vf_rowsum", _ptr(dy), _ptr(dvb), S * Cout, H * W, st)
+                    _call("vf_rowsum", _ptr(dy), _ptr(dvb), S * Cout, H * W, st)
                 db = _gout(ctx.pb, Cout, like=x1)
-                _lib.call("vf_colsum", _ptr(dvb), _ptr(db), 1, S, Cout, st)
+                _call("vf_colsum", _ptr(dvb), _ptr(db), 1, S, Cout, st)
         return dx1, dx2, dw, db, None, None
 
 
@@ -865,7 +926,7 @@ def conv2d_gn(x, layer, gn, groups, silu, view_bias=None, residual=None, mode="s
     stats = torch.empty(2 * S * groups, device=x.device, dtype=torch.float32)
     wf, _ = _packed(layer, force=False)
     ws, nws = _conv_ws(x.device, S, Cin, Cout, H, W, KS)
-    _lib.call("vf_conv_fwd_gn", _ptr(x), _ptr(wf), _ptr(layer.bias), _ptr(view_bias), _ptr(residual), _ptr(y), int(want_y),
+    _call("vf_conv_fwd_gn", _ptr(x), _ptr(wf), _ptr(layer.bias), _ptr(view_bias), _ptr(residual), _ptr(y), int(want_y),
               _ptr(gn.weight), _ptr(gn.bias), _ptr(a), _ptr(stats), groups, 1e-5, int(silu), _ptr(ws), nws, S, Cin, Cout,
               H, W, KS, m, _stream())
     return (y if want_y else None), a
@@ -873,8 +934,8 @@ def conv2d_gn(x, layer, gn, groups, silu, view_bias=None, residual=None, mode="s
 
 # ---------------------------------------------------------------------------------------------
 def _bgemm(A, B, C, bias, batch, M, N, K, sA, sB, sC, alpha=1.0, beta=0.0, offA=0, offB=0, offC=0):
-    _lib.call("vf_bgemm", _ptr(A, offA), _ptr(B, offB), _ptr(C, offC), _ptr(bias), batch, M, N, K, sA[0], sA[1],
-              sA[2], sB[0], sB[1], sB[2], sC[0], sC[1], sC[2], alpha, beta, _stream())
+    _call("vf_bgemm", _ptr(A, offA), _ptr(B, offB), _ptr(C, offC), _ptr(bias), batch, M, N, K, sA[0], sA[1],
+              sA[2], sB[0], sB[1], sB[2], sC[0], sC[1], sC[2], alpha, beta, _stream(), flops=2.0 * batch * M * N * K)
 
 
 class _LinearFn(torch.autograd.Function):
@@ -904,7 +965,7 @@ class _LinearFn(torch.autograd.Function):
             _bgemm(dy, x, dw, None, 1, O, I, S, (0, 1, O), (0, I, 1), (0, I, 1))
         if ctx.needs_input_grad[2]:
             db = _gout(ctx.pb, O, like=x)
-            _lib.call("vf_colsum", _ptr(dy), _ptr(db), 1, S, O, _stream())
+            _call("vf_colsum", _ptr(dy), _ptr(db), 1, S, O, _stream())
         return dx, dw, db
 
 
@@ -941,7 +1002,7 @@ class _TimeAffineFn(torch.autograd.Function):
         S, K = emb.shape
         desc, Cs, coffs, CT = _ta_desc(layers, S, emb.device)
         out = torch.empty(S * CT, device=emb.device, dtype=torch.float32)
-        _lib.call("vf_time_affine_fwd", ctypes.c_void_p(desc.data_ptr()), len(Cs), _ptr(emb), _ptr(out), S, K, CT,
+        _call("vf_time_affine_fwd", ctypes.c_void_p(desc.data_ptr()), len(Cs), _ptr(emb), _ptr(out), S, K, CT,
                   _stream())
         ctx.save_for_backward(emb)
         ctx.plan = (desc, Cs, coffs, CT)
@@ -961,12 +1022,16 @@ class _TimeAffineFn(torch.autograd.Function):
             if any(t is None for t in slots):
                 slots = None
             else:
-                key = (id(arena), arena.base)
-                hit = _TA_GDST.get(id(ctx.params[0]))
-                if hit is None or hit[0] != key:
+                # (keyed on the slots, not on the parameter objects: a captured step runs on leaf aliases of the
+                # parameters and must find the table the eager iterations before it uploaded -- no copy in a capture)
+                key = (id(arena), arena.base, slots[0].data_ptr(), len(slots))
+                hit = _TA_GDST.get(key)
+                if hit is None:
                     rows = [[slots[2 * g].data_ptr(), slots[2 * g + 1].data_ptr()] for g in range(len(Cs))]
                     hit = (key, torch.tensor(rows, dtype=torch.int64).to(emb.device))
-                    _TA_GDST[id(ctx.params[0])] = hit
+                    if len(_TA_GDST) > 8:
+                        _TA_GDST.clear()
+                    _TA_GDST[key] = hit
                 gdst = hit[1]
         if slots is None:
             dw = torch.empty(CT, K, device=emb.device, dtype=torch.float32)
@@ -975,7 +1040,7 @@ class _TimeAffineFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             demb = torch.empty_like(emb)
             ws = torch.empty(_lib.load().vf_time_affine_ws_floats(S, K), device=emb.device, dtype=torch.float32)
-        _lib.call("vf_time_affine_bwd", ctypes.c_void_p(desc.data_ptr()), len(Cs), _ptr(emb), _ptr(de), _ptr(dw),
+        _call("vf_time_affine_bwd", ctypes.c_void_p(desc.data_ptr()), len(Cs), _ptr(emb), _ptr(de), _ptr(dw),
                   _ptr(db), ctypes.c_void_p(gdst.data_ptr()) if gdst is not None else None, _ptr(demb), _ptr(ws), S, K,
                   CT, _stream())
         out = [demb, None]
@@ -999,7 +1064,7 @@ class _SwishFn(torch.autograd.Function):
     def forward(ctx, x):
         _check(x)
         y = torch.empty_like(x)
-        _lib.call("vf_swish_fwd", _ptr(x), _ptr(y), x.numel(), _stream())
+        _call("vf_swish_fwd", _ptr(x), _ptr(y), x.numel(), _stream())
         ctx.save_for_backward(x)
         return y
 
@@ -1008,7 +1073,7 @@ class _SwishFn(torch.autograd.Function):
         (x,) = ctx.saved_tensors
         dy = _c(dy)
         dx = torch.empty_like(x)
-        _lib.call("vf_swish_bwd", _ptr(x), _ptr(dy), _ptr(dx), x.numel(), _stream())
+        _call("vf_swish_bwd", _ptr(x), _ptr(dy), _ptr(dx), x.numel(), _stream())
         return dx
 
 
@@ -1021,7 +1086,7 @@ class _DropoutFn(torch.autograd.Function):
     def forward(ctx, x, u, p):
         _check(x, u)
         y = torch.empty_like(x)
-        _lib.call("vf_dropout", _ptr(x), _ptr(u), _ptr(y), x.numel(), float(p), _stream())
+        _call("vf_dropout", _ptr(x), _ptr(u), _ptr(y), x.numel(), float(p), _stream())
         ctx.save_for_backward(u)
         ctx.p = float(p)
         return y
@@ -1031,7 +1096,7 @@ class _DropoutFn(torch.autograd.Function):
         (u,) = ctx.saved_tensors
         dy = _c(dy)
         dx = torch.empty_like(dy)
-        _lib.call("vf_dropout", _ptr(dy), _ptr(u), _ptr(dx), dy.numel(), ctx.p, _stream())
+        _call("vf_dropout", _ptr(dy), _ptr(u), _ptr(dx), dy.numel(), ctx.p, _stream())
         return dx, None, None
 
 
@@ -1050,7 +1115,7 @@ def sincos_embedding(level, angle, dim):
     _check(level, angle)
     S = level.numel()
     out = torch.empty(S, dim, device=level.device, dtype=torch.float32)
-    _lib.call("vf_sincos_embed", _ptr(level), _ptr(angle), _ptr(out), S, dim, _stream())
+    _call("vf_sincos_embed", _ptr(level), _ptr(angle), _ptr(out), S, dim, _stream())
     return out
 
 
@@ -1073,7 +1138,7 @@ class _AttentionFn(torch.autograd.Function):
             P = torch.empty(S, L, L, device=qkv.device, dtype=torch.float32)
             _bgemm(qkv, qkv, P, None, S, L, L, C, (C3 * L, 1, L), (C3 * L, L, 1), (L * L, L, 1), alpha,
                    offA=0, offB=C * L)
-            _lib.call("vf_softmax_fwd", _ptr(P), _ptr(P), S * L, L, _stream())
+            _call("vf_softmax_fwd", _ptr(P), _ptr(P), S * L, L, _stream())
             _bgemm(qkv, P, out, None, S, C, L, L, (C3 * L, L, 1), (L * L, 1, L), (C * L, L, 1), offA=2 * C * L)
         ctx.save_for_backward(qkv, P)
         return out
@@ -1087,17 +1152,20 @@ class _AttentionFn(torch.autograd.Function):
         alpha = 1.0 / math.sqrt(C)
         dqkv = torch.empty_like(qkv)
         dS = torch.empty_like(P)
+        global _KIND_OVERRIDE
+        _KIND_OVERRIDE = "attn_bwd" if KERNEL_LOG is not None else None
         # dP[i][j] = sum_c dO[c][i] v[c][j]
         _bgemm(dO, qkv, dS, None, S, L, L, C, (C * L, 1, L), (C3 * L, L, 1), (L * L, L, 1), offB=2 * C * L)
         # dV[c][j] = sum_i dO[c][i] P[i][j]
         _bgemm(dO, P, dqkv, None, S, C, L, L, (C * L, L, 1), (L * L, L, 1), (C3 * L, L, 1), offC=2 * C * L)
-        _lib.call("vf_softmax_bwd", _ptr(P), _ptr(dS), _ptr(dS), S * L, L, _stream())
+        _call("vf_softmax_bwd", _ptr(P), _ptr(dS), _ptr(dS), S * L, L, _stream())
         # dQ[c][i] = alpha sum_j k[c][j] dS[i][j]
         _bgemm(qkv, dS, dqkv, None, S, C, L, L, (C3 * L, L, 1), (L * L, 1, L), (C3 * L, L, 1), alpha,
                offA=C * L, offC=0)
         # dK[c][j] = alpha sum_i q[c][i] dS[i][j]
         _bgemm(qkv, dS, dqkv, None, S, C, L, L, (C3 * L, L, 1), (L * L, L, 1), (C3 * L, L, 1), alpha,
                offA=0, offC=C * L)
+        _KIND_OVERRIDE = None
         return dqkv, None
 
 
@@ -1112,7 +1180,7 @@ class _ConcatFn(torch.autograd.Function):
         S, Ca, H, W = a.shape
         Cb = b.shape[1]
         out = torch.empty(S, Ca + Cb, H, W, device=a.device, dtype=torch.float32)
-        _lib.call("vf_concat_channels", _ptr(a), _ptr(b), _ptr(out), S, Ca * H * W, Cb * H * W, 0, _stream())
+        _call("vf_concat_channels", _ptr(a), _ptr(b), _ptr(out), S, Ca * H * W, Cb * H * W, 0, _stream())
         ctx.shapes = (a.shape, b.shape)
         return out
 
@@ -1122,7 +1190,7 @@ class _ConcatFn(torch.autograd.Function):
         sa, sb = ctx.shapes
         da = torch.empty(sa, device=dout.device, dtype=torch.float32)
         db = torch.empty(sb, device=dout.device, dtype=torch.float32)
-        _lib.call("vf_concat_channels", _ptr(da), _ptr(db), _ptr(dout), sa[0], da[0].numel(), db[0].numel(), 1,
+        _call("vf_concat_channels", _ptr(da), _ptr(db), _ptr(dout), sa[0], da[0].numel(), db[0].numel(), 1,
                   _stream())
         return da, db
 
@@ -1176,7 +1244,7 @@ def gather_level(gammas, t, u=None):
     t = _c(t.to(torch.int64))
     B = t.numel()
     level = torch.empty(B, device=gammas.device, dtype=torch.float32)
-    _lib.call("vf_gather_level", _ptr(gammas), ctypes.c_void_p(t.data_ptr()), _ptr(u), _ptr(level), B, _stream())
+    _call("vf_gather_level", _ptr(gammas), ctypes.c_void_p(t.data_ptr()), _ptr(u), _ptr(level), B, _stream())
     return level
 
 
@@ -1193,7 +1261,7 @@ def stack_views(y_cond, y_t, noise, level, angle, off, S, x=None, copy_cond=True
         x = torch.empty(S, Cc + 3, H, W, device=y_cond.device, dtype=torch.float32)
     ls = torch.empty(S, 1, device=y_cond.device, dtype=torch.float32)
     as_ = torch.empty(S, 1, device=y_cond.device, dtype=torch.float32)
-    _lib.call("vf_stack_views", _ptr(y_cond), _ptr(y_t), _ptr(noise), _ptr(level), _ptr(angle),
+    _call("vf_stack_views", _ptr(y_cond), _ptr(y_t), _ptr(noise), _ptr(level), _ptr(angle),
               ctypes.c_void_p(off.data_ptr()), _ptr(x), _ptr(ls), _ptr(as_), B, Nmax, Cc, H * W, S, int(copy_cond),
               _stream())
     return x, ls, as_
@@ -1209,7 +1277,7 @@ class _ComposeLossFn(torch.autograd.Function):
         nh = torch.empty(B, 3, H, W, device=out.device, dtype=torch.float32)
         part = torch.empty(B * 64 + 1, device=out.device, dtype=torch.float32)
         loss = part[B * 64:]
-        _lib.call("vf_compose_fwd", _ptr(out), ctypes.c_void_p(off.data_ptr()), _ptr(target), _ptr(nh), None,
+        _call("vf_compose_fwd", _ptr(out), ctypes.c_void_p(off.data_ptr()), _ptr(target), _ptr(nh), None,
                   _ptr(part), _ptr(loss), B, Cout, H * W, 0, int(weighting), _stream())
         ctx.save_for_backward(out, target, nh, off)
         ctx.B, ctx.weighting = B, int(weighting)
@@ -1221,7 +1289,7 @@ class _ComposeLossFn(torch.autograd.Function):
         S, Cout, H, W = out.shape
         gloss = _c(gloss.reshape(1).float())
         dout = torch.empty_like(out)
-        _lib.call("vf_compose_mse_bwd", _ptr(out), ctypes.c_void_p(off.data_ptr()), _ptr(target), _ptr(nh),
+        _call("vf_compose_mse_bwd", _ptr(out), ctypes.c_void_p(off.data_ptr()), _ptr(target), _ptr(nh),
                   _ptr(gloss), _ptr(dout), ctx.B, Cout, H * W, ctx.weighting, _stream())
         return dout, None, None, None, None
 
@@ -1238,7 +1306,7 @@ def compose(unet_out, off, B, max_views, weighting, want_weights=True):
     wts = None
     if weighting and want_weights:
         wts = torch.empty(B, max_views, 3, H, W, device=unet_out.device, dtype=torch.float32)
-    _lib.call("vf_compose_fwd", _ptr(unet_out), ctypes.c_void_p(off.data_ptr()), None, _ptr(nh), _ptr(wts), None,
+    _call("vf_compose_fwd", _ptr(unet_out), ctypes.c_void_p(off.data_ptr()), None, _ptr(nh), _ptr(wts), None,
               None, B, Cout, H * W, max_views, int(weighting), _stream())
     return nh, wts
 
@@ -1255,7 +1323,7 @@ def p_sample_tail(unet_out, off, y_t, z, t, sched, B, max_views, weighting, clip
     wts = None
     if weighting and want_weights:
         wts = torch.empty(B, max_views, 3, H, W, device=y_t.device, dtype=torch.float32)
-    _lib.call("vf_p_sample_tail", _ptr(unet_out), ctypes.c_void_p(off.data_ptr()), _ptr(y_t), _ptr(z),
+    _call("vf_p_sample_tail", _ptr(unet_out), ctypes.c_void_p(off.data_ptr()), _ptr(y_t), _ptr(z),
               ctypes.c_void_p(t.data_ptr()), _ptr(sched["sqrt_recip_gammas"]), _ptr(sched["sqrt_recipm1_gammas"]),
               _ptr(sched["posterior_log_variance_clipped"]), _ptr(sched["posterior_mean_coef1"]),
               _ptr(sched["posterior_mean_coef2"]), _ptr(y_next), _ptr(mean), _ptr(wts), B, Cout, H * W, max_views,
@@ -1269,5 +1337,5 @@ def psnr(generated, target):
     _check(generated, target)
     B = generated.shape[0]
     out = torch.empty(B, device=generated.device, dtype=torch.float32)
-    _lib.call("vf_psnr", _ptr(generated), _ptr(target), _ptr(out), B, generated[0].numel(), _stream())
+    _call("vf_psnr", _ptr(generated), _ptr(target), _ptr(out), B, generated[0].numel(), _stream())
     return out

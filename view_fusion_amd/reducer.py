@@ -22,8 +22,20 @@ Gradient accumulation over several backward passes per optimizer step is NOT sup
 reference never does it, experiment.py:286-293) and raises.
 
 Single-process training (world 1) never constructs an arena.
+
+Deferred GroupNorm column sums (ops._colsum): with the arena the ~70 per-layer launches of a backward pass collapse into
+one multi-tensor launch per SEGMENT -- `_ready` flushes what is pending right before it lets a segment's all-reduce go.
+
+Captured iteration (train.Trainer with a HIP graph, world > 1): the forward runs on leaf aliases of the parameters and
+the gradients come from autograd.grad, so AccumulateGrad and its hooks never run.  `capture_begin(leaves)` maps the
+aliases onto the slots and puts a tensor hook on every alias that does what `_ready` does -- on RCCL the segment
+all-reduces are issued (and recorded into the graph, on RCCL's own stream: a parallel branch) while the backward pass
+is still being captured; `capture_finish()` joins them in front of the Adam launch.  A transport whose collectives are
+host-driven (gloo) cannot be captured: there the graph ends with the backward pass, and `reduce_all()` + the Adam launch
+follow every replay eagerly (no overlap of the exchange with the backward pass, ~8 host calls instead of ~1000).
 """
 import functools
+import os
 
 import torch
 import torch.distributed as dist
@@ -35,6 +47,8 @@ _ALIGN_IN = 4            # ... and within a layer every slot is 16-byte aligned 
 
 
 class GradArena:
+    flushes_colsums = True      # ops._colsum may defer: every path that releases a gradient flushes first
+
     def __init__(self, module, world, segments=6, group=None):
         self.params = [p for p in module.parameters() if p.requires_grad]
         assert self.params and all(p.dtype == torch.float32 for p in self.params)
@@ -48,6 +62,10 @@ class GradArena:
                 if i is not None and self.owner[i] is None:
                     self.owner[i] = m_ord
         self.avg = dist.get_backend(group) == "nccl"          # RCCL has ncclAvg; gloo only SUM
+        # RCCL collectives are stream work and can be recorded into a HIP graph; gloo's run on the host
+        self.capturable = self.avg and os.environ.get("VF_CAPTURE_COLLECTIVES", "1") == "1"
+        self._alias = {}                                      # id(leaf alias of a parameter) -> index (captured step)
+        self._hooks = []
         self.flat = None                                      # laid out at the end of the first iteration
         self.fired = []                                       # first iteration: parameter indices in ready order
         self.got = [False] * len(self.params)
@@ -103,11 +121,15 @@ class GradArena:
         p, o = self.params[i], self.off[i]
         return self.flat[o:o + p.numel()].view(p.shape)
 
+    def _idx(self, p):
+        i = self.index.get(id(p))
+        return i if i is not None else self._alias.get(id(p))
+
     # -- called from the backward kernels' host code ------------------------------------------------------------
     def slot(self, p):
         """Fresh alias of p's gradient slot, or None when there is no layout yet, p is unknown, or p already holds
         a gradient (accumulation over several backward passes must add, not overwrite)."""
-        i = self.index.get(id(p))
+        i = self._idx(p)
         if i is None or self.flat is None or p.grad is not None or i in self.handed:
             return None                                       # second use of a shared layer: autograd must ADD
         self.handed.add(i)
@@ -115,7 +137,7 @@ class GradArena:
 
     def slot_pair(self, p, q):
         """One (2, n) alias covering the adjacent, equally sized slots of p and q (GroupNorm gamma / beta), or None."""
-        i, j = self.index.get(id(p)), self.index.get(id(q))
+        i, j = self._idx(p), self._idx(q)
         if i is None or j is None or self.flat is None or p.grad is not None or q.grad is not None:
             return None
         n = p.numel()
@@ -130,23 +152,38 @@ class GradArena:
             self.got[i] = True
             self.fired.append(i)
             return
+        g = p.grad
+        s = self._arrived(i, g)
+        if s is not g:
+            p.grad = s
+
+    def _arrived(self, i, g):
+        """Gradient g of parameter i exists (enqueued): move it into its slot unless it was born there, count its
+        segment down and let the segment go when it is complete.  Returns the slot view."""
         if self.got[i]:
             # a second backward pass before finish(): the slot's segment may already have been averaged in place
             raise RuntimeError("GradArena does not support gradient accumulation over several backward passes per "
                                "optimizer step (use VF_REDUCER=ddp with no_sync() for that)")
         self.got[i] = True
-        g = p.grad
         if g.data_ptr() != self.base + 4 * self.off[i] or not g.is_contiguous():
+            from . import ops
+            ops.flush_colsums()                               # g may be a deferred destination: fill it before reading
             s = self._view(i)
             s.copy_(g)
-            p.grad = s
+            g = s
             self.copied += 1
         k = self.seg_of[i]
         self.pending[k] -= 1
-        if self.pending[k] == 0:
+        if self.pending[k] == 0 and self._may_launch():
             self._launch(k)
+        return g
+
+    def _may_launch(self):
+        return self.capturable or not (self.flat.is_cuda and torch.cuda.is_current_stream_capturing())
 
     def _launch(self, k):
+        from . import ops
+        ops.flush_colsums()                                   # deferred GroupNorm sums of this (and earlier) segments
         lo, hi = self.seg_range[k]
         t = self.flat[lo:hi]
         op = dist.ReduceOp.AVG if self.avg else dist.ReduceOp.SUM
@@ -172,9 +209,60 @@ class GradArena:
                     if self.seg_of[i] == k and not self.got[i]:
                         self._view(i).zero_()
                 self._launch(k)
+        self._join()
+
+    def _join(self):
         for w, t in self.works:
             w.wait()
             if not self.avg:
                 t.mul_(1.0 / self.world)
         self.works = []
         self._reset()
+
+    # -- captured iteration (train.Trainer) ---------------------------------------------------------------------
+    def capture_begin(self, leaves):
+        """`leaves`: fresh leaf aliases of self.params (same order) that the captured forward runs on."""
+        assert self.flat is not None and len(leaves) == len(self.params)
+        self._reset()
+        self._alias = {id(l): i for i, l in enumerate(leaves)}
+        self._hooks = [l.register_hook(functools.partial(self._arrived, i)) for i, l in enumerate(leaves)]
+
+    def capture_finish(self, grads):
+        """After autograd.grad inside the capture: every gradient into its slot (those that no tensor hook saw: a
+        parameter autograd reported as unused gets zeros), then -- capturable transport only -- the remaining segments
+        go and all of them are joined.  Returns the slot views in parameter order."""
+        for h in self._hooks:
+            h.remove()
+        self._hooks, self._alias = [], {}
+        out = []
+        for i, g in enumerate(grads):
+            if not self.got[i]:
+                if g is None:
+                    self._view(i).zero_()
+                    self.got[i] = True
+                    self.pending[self.seg_of[i]] -= 1
+                else:
+                    g = self._arrived(i, g)
+            out.append(self._view(i))
+        if self.capturable:
+            self.reduce_all()
+        else:
+            from . import ops
+            ops.flush_colsums()
+            self._reset()
+        return out
+
+    def capture_abort(self):
+        """The capture failed half-way: forget its hooks, aliases and recorded collectives."""
+        for h in self._hooks:
+            h.remove()
+        self._hooks, self._alias, self.works = [], {}, []
+        self._reset()
+
+    def reduce_all(self):
+        """All-reduce every segment that has not been launched yet and join (eagerly after a replay on a host-driven
+        transport; inside the capture on RCCL)."""
+        for k, done in enumerate(self.launched):
+            if not done:
+                self._launch(k)
+        self._join()

@@ -98,7 +98,7 @@ def build_model(unet_params=None, beta_schedule=None, device="cuda", phase="trai
 
 class _StepGraph:
     """One captured training iteration (forward, backward, Adam) for one batch geometry."""
-    __slots__ = ("graph", "inputs", "view_count", "off", "vc", "loss", "adam", "keep", "seen")
+    __slots__ = ("graph", "inputs", "view_count", "off", "vc", "loss", "adam", "keep", "seen", "grads")
 
     def __init__(self):
         self.graph, self.seen = None, 0
@@ -133,7 +133,9 @@ class Trainer:
         if world > 1 and os.environ.get("VF_REDUCER", "arena") != "ddp":
             try:
                 self.arena = reducer.ACTIVE = reducer.GradArena(model, world)
-            except Exception as e:       # first collective of the job (parameter broadcast) or hook set-up failed
+            except (RuntimeError, dist.DistBackendError) as e:    # first collective of the job (parameter broadcast)
+                import traceback
+                traceback.print_exc()    # (anything else -- a programming error in the hook set-up -- propagates as is)
                 reducer.ACTIVE = None
                 raise SystemExit(
                     f"[view_fusion_amd] gradient-arena set-up failed at world={world}: {type(e).__name__}: {e}\n"
@@ -144,6 +146,10 @@ class Trainer:
             if next(model.parameters()).is_cuda:
                 kw.update(device_ids=[local_rank], output_device=local_rank)
             self.model = DistributedDataParallel(model, **kw)
+            # DDP copies a gradient into its bucket from a hook on the AccumulateGrad node, during the backward pass:
+            # a GroupNorm gradient whose column sum is deferred to the end of the pass would be read before it exists
+            from . import ops
+            ops.COLSUM_DEFER = False
         # modules whose behaviour depends on train/eval mode (see step()): the blocks that carry a Dropout
         self._mode_modules = [m for m in model.modules() if getattr(m, "dropout", 0) and hasattr(m, "_drop")]
         self.sched = LrScheduler(peak_lr=1e-4, peak_it=lr_warmup, decay_it=decay_it, decay_rate=0.16)
@@ -156,8 +162,9 @@ class Trainer:
             self.opt = torch.optim.Adam(params, lr=self.sched.get_cur_lr(0))
         self.it = -1
         if graph is None:
-            graph = os.environ.get("VF_STEP_GRAPH") == "1"
-        self.use_graph = bool(graph) and world == 1 and params[0].is_cuda
+            graph = os.environ.get("VF_STEP_GRAPH", "1") == "1"
+        # (with torch DDP the iteration stays eager: its reducer is driven by autograd hooks on the host)
+        self.use_graph = bool(graph) and params[0].is_cuda and (world == 1 or self.arena is not None)
         self._graphs = {}           # geometry key -> _StepGraph
         self._pool = None           # the graphs' shared private memory pool
         self._scal = None           # device {lr, 1-b1^t, 1-b2^t}
@@ -168,7 +175,7 @@ class Trainer:
     # -- whole-step HIP graph ---------------------------------------------------------------------------------------
     def _graph_key(self, batch, extra):
         from . import ops
-        if not self.use_graph or ops.KERNEL_LOG is not None or self.arena is not None:
+        if not self.use_graph or ops.KERNEL_LOG is not None or (self.arena is not None and self.arena.flat is None):
             return None
         if any(k not in ("t", "u", "noise") for k in extra):       # injected draws are graph inputs, nothing else is
             return None
@@ -194,8 +201,12 @@ class Trainer:
     def _capture(self, e, key, vc, batch, extra):
         from . import ops
         dev = batch["y_0"].device
-        adam = self.opt.graph_begin()
-        if adam is None:
+        arena = self.arena
+        # With a host-driven transport (gloo) the graph ends with the backward pass; the exchange and the Adam launch
+        # follow each replay eagerly.  On RCCL the segment all-reduces and Adam are part of the graph.
+        split = arena is not None and not arena.capturable
+        adam = None if split else self.opt.graph_begin()
+        if adam is None and not split:
             return False
         if self._scal is None:
             self._scal = torch.zeros(3, device=dev, dtype=torch.float32)
@@ -219,22 +230,30 @@ class Trainer:
                     # forward), they are bound to the default stream, the backward pass forks the capture onto it, and
                     # hipStreamEndCapture takes the process down.
                     leaves = {n: p.detach().requires_grad_(True) for n, p in self._named}
+                    if arena is not None:              # gradients are born in (or moved into) the all-reduce buffer
+                        arena.capture_begin(list(leaves.values()))
                     loss = torch.func.functional_call(self.model, leaves, (), dict(view_count=e.view_count, **e.inputs))
                     grads = torch.autograd.grad(loss, list(leaves.values()), allow_unused=True)
+                    if arena is not None:
+                        grads = arena.capture_finish(grads)
                     for (_, p), gr in zip(self._named, grads):
                         p.grad = gr
-                    self.opt.step_captured(adam, self._scal)
+                    if not split:
+                        self.opt.step_captured(adam, self._scal)
                 except Exception as err:      # noqa: BLE001
                     failed = err
         finally:
             fix = ops.end_capture()
         if failed is not None:
+            if arena is not None:
+                arena.capture_abort()
             raise failed
         if self._pool is None:
             self._pool = g.pool()
-        e.adam = self.opt.graph_end(adam)
-        self._graph_epoch = adam["epoch"]
+        e.adam = None if split else self.opt.graph_end(adam)
+        self._graph_epoch = self.opt.graph_epoch if split else adam["epoch"]
         e.loss, e.graph = loss.detach(), g
+        e.grads = list(grads)
         # what the captured launches address besides the graph's own pool
         e.keep = (fix, tables, offs, getattr(self.module, "gammas", None))
         return True
@@ -250,11 +269,16 @@ class Trainer:
             src = extra[k] if k in extra else batch[k]
             dst.copy_(src.reshape(dst.shape), non_blocking=True)
         if self._last_graph is not e:                  # .grad shows the gradients of the graph that ran last
-            for p, gr in zip(e.adam["bucket"]["params"], e.adam["grads"]):
+            for p, gr in zip(self._params, e.grads):
                 p.grad = gr
             self._last_graph = e
-        self.opt.graph_tick(e.adam, self._scal)
-        e.graph.replay()
+        if e.adam is None:                             # host-driven transport: exchange + Adam follow the replay
+            e.graph.replay()
+            self.arena.reduce_all()
+            self.opt.step()
+        else:
+            self.opt.graph_tick(e.adam, self._scal)
+            e.graph.replay()
         self.graph_steps += 1
         return e.loss.clone()
 
