@@ -188,8 +188,8 @@ def pmc_traffic():
 
 # kind (ops._launch) -> (label, binding roof).  Events bracket the C-ABI launcher, i.e. the kernel family it enqueues.
 FAMILIES = {
-    "wino_conv": ("wino_conv_kernel<LOGW,MODE> (nested Winograd F(2,3)xF(4,3), + tail fixup): forward + dgrad of every "
-                  "stride-1 3x3 layer", "mfma"),
+    "wino_conv": ("wino44_conv_kernel<LOGW,MODE> (Winograd F(4x4,3x3): 64x64 / 32x32 maps) + wino_conv_kernel<LOGW,MODE> "
+                  "(nested F(2,3)xF(4,3): 16x16 / 8x8 maps), + tail fix-ups: forward + dgrad of every stride-1 3x3 layer", "mfma"),
     "direct_conv": ("conv_mfma_kernel<KS,LOGW,MODE,NPT>: forward + dgrad of the 1x1 / stride-2 layers", "mfma"),
     "wino_wgrad": ("wino44_wgrad_kernel (Winograd F(4x4,3x3), + slab-sum launch): weight gradient of the stride-1 3x3 layers", "mfma"),
     "direct_wgrad": ("conv1x1_wgrad_kernel / conv_wgrad_kernel (+ reduce): weight gradient of the 1x1 / stride-2 layers", "mfma"),
@@ -220,10 +220,16 @@ FAMILY_PMC = {
 }
 
 
-# direct-convolution multiplies per multiply the Winograd kernels execute: forward / dgrad run the nested
-# F(2,3) x F(4,3) (24 products per 2x4 outputs x 9 taps = 72 direct ones), the weight gradient F(4x4,3x3) (36 products
-# per 4x4 outputs x 9 taps = 144 direct ones)
+# direct-convolution multiplies per multiply the Winograd kernels execute: the nested F(2,3) x F(4,3) forward / dgrad
+# kernel (16x16 / 8x8 maps) 24 products per 2x4 outputs x 9 taps = 72 direct ones; F(4x4,3x3) -- forward / dgrad on the
+# 64x64 / 32x32 maps and every weight gradient -- 36 products per 4x4 outputs x 9 taps = 144 direct ones
 WINO_REDUCTION = {"wino_conv": 3.0, "wino_wgrad": 4.0}
+
+
+def _reduction(fam, name):
+    if fam == "wino_conv":
+        return 4.0 if name.startswith("vf_wino44_conv") else 3.0
+    return WINO_REDUCTION.get(fam, 1.0)
 
 
 def _family(kind, name):
@@ -258,17 +264,18 @@ def roofline(trainer, batch, S, ms_step, steps=3):
     log, ops.KERNEL_LOG = ops.KERNEL_LOG, None
     agg = {}
     for kind, flops, e0, e1, _tag, name, nbytes in log:
-        a = agg.setdefault(_family(kind, name), [0.0, 0.0, 0, 0.0])
+        fam = _family(kind, name)
+        a = agg.setdefault(fam, [0.0, 0.0, 0, 0.0, 0.0])
         a[0] += flops
         a[1] += e0.elapsed_time(e1) * 1e-3
         a[2] += 1
         a[3] += nbytes
+        a[4] += flops / _reduction(fam, name)          # multiplies the matrix cores execute
     traffic, source = pmc_traffic()
     launches = pmc_launches()
     table = {}
-    for fam, (f, s, n, nb) in agg.items():
+    for fam, (f, s, n, nb, executed) in agg.items():
         label, bound = FAMILIES.get(fam, (fam, "hbm"))
-        executed = f / WINO_REDUCTION.get(fam, 1.0)
         row = dict(kernel=label, bound=bound, launches_per_step=n // steps, ms_per_step=s / steps * 1e3,
                    avg_launch_us=s / n * 1e6)
         if f:
@@ -289,25 +296,30 @@ def roofline(trainer, batch, S, ms_step, steps=3):
     # headline family: the Winograd forward/dgrad kernel when any launch took it, else the MFMA-bound family with the
     # largest time (small S: every 3x3 layer runs the direct kernel)
     head = "wino_conv" if "wino_conv" in agg else max((k for k in agg if agg[k][0] > 0), key=lambda k: agg[k][1])
-    f, s, n, nb_head = agg[head]
-    executed = f / WINO_REDUCTION.get(head, 1.0)
+    f, s, n, nb_head, executed = agg[head]
+    head_traffic = table[head].get("pmc_hbm_mb_per_launch")
+    head_traffic = head_traffic * 1e6 if head_traffic else None
     # floor of the whole step: every conv at the fp32 MFMA peak, the stride-1 3x3 layers at Winograd's multiply count
     # (forward + dgrad: nested F(2,3)xF(4,3); weight gradient: F(4x4,3x3))
     step_tflop_direct = GFLOP_PER_VIEW_TRAIN * S / 1e3
     g3 = GFLOP_3X3_S1_PER_VIEW_FWD * S / 1e3
-    step_tflop_wino = step_tflop_direct - 2 * g3 * (1 - 1 / WINO_REDUCTION["wino_conv"]) - g3 * (1 - 1 / WINO_REDUCTION["wino_wgrad"])
+    # (executed multiplies of THIS run's forward + dgrad launches: F(4x4) where it ran, nested elsewhere)
+    fwd_dgrad_exec = agg["wino_conv"][4] / steps / 1e12 if "wino_conv" in agg else 2 * g3 / 3.0
+    fwd_dgrad_direct = agg["wino_conv"][0] / steps / 1e12 if "wino_conv" in agg else 2 * g3
+    step_tflop_wino = step_tflop_direct - (fwd_dgrad_direct - fwd_dgrad_exec) - g3 * (1 - 1 / WINO_REDUCTION["wino_wgrad"])
     floor_ms = step_tflop_wino / PEAK_FP32_MATRIX_TFLOPS * 1e3
     out = dict(bound="mfma", kernel=FAMILIES.get(head, (head,))[0], achieved=executed / s / 1e12, peak=PEAK_FP32_MATRIX_TFLOPS,
                unit="TFLOP/s", frac=executed / s / 1e12 / PEAK_FP32_MATRIX_TFLOPS,
                note="achieved = multiplies the matrix cores EXECUTE: algorithmic direct-convolution FLOPs "
-                    "(2*S*Cout*Cin*9*H*W per launch) / 3 / HIP-event time of the vf_wino_conv_fwd launches "
-                    "(forward + dgrad); direct_equivalent_tflops prices the same launches at the direct count",
+                    "(2*S*Cout*Cin*9*H*W per launch) / 4 for the F(4x4,3x3) launches (64x64 / 32x32 maps), / 3 for the "
+                    "nested F(2,3)xF(4,3) ones (16x16 / 8x8 maps), over the HIP-event time of all of them (forward + "
+                    "dgrad); direct_equivalent_tflops prices the same launches at the direct count",
                direct_equivalent_tflops=f / s / 1e12, launches_per_step=n // steps, avg_launch_us=s / n * 1e6,
                algorithmic_gflop_per_launch=f / n / 1e9, executed_gflop_per_launch=executed / n / 1e9,
-               traffic=traffic.get("wino_conv_kernel"), traffic_unit="HBM bytes per launch", traffic_source=source,
+               traffic=head_traffic, traffic_unit="HBM bytes per launch (launch-weighted mean over the family's kernels, "
+                                                  "fix-up launches included)", traffic_source=source,
                algorithmic_bytes_per_launch=nb_head / n if nb_head else None,
-               traffic_ratio=(traffic["wino_conv_kernel"] / (nb_head / n)
-                              if nb_head and traffic.get("wino_conv_kernel") and head == "wino_conv" else None),
+               traffic_ratio=(head_traffic / (nb_head / n) if nb_head and head_traffic else None),
                traffic_note="algorithmic bytes = input + output activations (+ residual) + the layer's weights, once "
                             "each; the PMC figure on top of that is: the 2-row halo re-read of every 2-row tile strip "
                             "(input rows fetched 2x on 64^2/32^2 maps when the halo misses L2), one more input read "

@@ -123,6 +123,20 @@ int vf_wino_conv_fill_pct(int S, int Cin, int Cout, int H, int W, int* tiles_out
 int vf_wino_conv_fwd(const float* x, const float* u_packed, const float* bias, const float* view_bias,
                      const float* residual, float* y, float* ws, long ws_floats, int S, int Cin, int Cout, int H,
                      int W, int mode, void* stream);
+/* fused Winograd F(4x4,3x3) path (36 products per 4x4 outputs: 2.25 multiplies per output instead of the nested
+ * kernel's 3) for the stride-1 3x3 convs on the 32x32 / 64x64 maps, forward and dgrad -- replaces nn.Conv2d 3x3
+ * at reference model/unet.py:42,189,214 on those maps; same calling convention as the vf_wino_* entries above, its own
+ * pack layout (U = G4 w G4^T, 36 slices in wave order). */
+int vf_wino44_supported(int H, int W, int mode);
+int vf_wino44_pack_sizes(int Cout, int Cin, long* fwd_floats, long* bwd_floats);
+int vf_wino44_pack_weights(const float* w_oihw, float* u_fwd, float* u_bwd /*or NULL*/, int Cout, int Cin,
+                           void* stream);
+int vf_wino44_pack_weights_multi(const void* desc, int nlayers, long total_blocks, void* stream);
+long vf_wino44_conv_ws_floats(int S, int Cin, int Cout, int H, int W);
+int vf_wino44_conv_fill_pct(int S, int Cin, int Cout, int H, int W, int* tiles_out);
+int vf_wino44_conv_fwd(const float* x, const float* u_packed, const float* bias, const float* view_bias,
+                       const float* residual, float* y, float* ws, long ws_floats, int S, int Cin, int Cout, int H,
+                       int W, int mode, void* stream);
 /* weight gradient of a stride-1 3x3 conv (modes 0 and 2, output H = W in {8,16,32,64}) through the same
  * transform: dU = sum over tiles of (A dY A^T) (B^T d B)^T per Winograd slice, split over tile ranges into `ws`
  * slabs that are summed in a fixed order, then dW = G^T dU G */

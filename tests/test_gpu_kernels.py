@@ -68,7 +68,7 @@ CONV_CASES = [
 
 @pytest.mark.parametrize("Cin,Cout,Hin,KS,mode", CONV_CASES)
 @pytest.mark.parametrize("S", [3])
-def test_conv_fwd_bwd(dev, Cin, Cout, Hin, KS, mode, S):
+def test_conv_fwd_bwd(dev, Cin, Cout, Hin, KS, mode, S, tol=2e-5):
     from view_fusion_amd import ops
     layer = torch.nn.Conv2d(Cin, Cout, KS, padding=KS // 2)
     with torch.no_grad():
@@ -92,8 +92,8 @@ def test_conv_fwd_bwd(dev, Cin, Cout, Hin, KS, mode, S):
     xg = x.to(dev).requires_grad_(True); vbg = vb.to(dev).requires_grad_(True); rg = res.to(dev).requires_grad_(True)
     yg = ops.conv2d(xg, layer, view_bias=vbg, residual=rg, mode=mode)
     yg.backward(gy.to(dev))
-    assert rel(yg, yc) < 2e-5
-    assert rel(xg.grad, xc.grad) < 2e-5
+    assert rel(yg, yc) < tol
+    assert rel(xg.grad, xc.grad) < tol
     assert rel(layer.weight.grad, wgc) < 1e-4
     assert rel(layer.bias.grad, bgc) < 2e-5
     assert rel(vbg.grad, vbc.grad) < 2e-5
@@ -217,6 +217,26 @@ def test_conv_winograd_path(dev, Cin, Cout, Hin, mode):
         test_conv_fwd_bwd(dev, Cin, Cout, Hin, 3, mode, 3)
     finally:
         ops.FORCE_WINOGRAD = False
+
+
+@pytest.mark.parametrize("Cin,Cout,Hin,mode,S", [
+    (64, 64, 64, "same", 3), (6, 64, 64, "same", 3), (64, 6, 64, "same", 3), (192, 64, 64, "same", 2),
+    (128, 128, 32, "same", 3), (320, 128, 32, "same", 3), (128, 128, 32, "up2", 2), (192, 192, 16, "up2", 3),
+    (96, 160, 32, "same", 5), (40, 96, 64, "same", 2), (13, 70, 32, "same", 7),
+    # more than 256 workgroup tiles: persistent workgroups walk on to a second tile (next-tile staging under the epilogue)
+    (16, 64, 64, "same", 40), (24, 128, 32, "same", 70),
+    # a tail round whose tiles are K-split (partial outputs + fix-up launch) behind a full round
+    (128, 128, 32, "same", 80)])
+def test_conv_winograd44_path(dev, Cin, Cout, Hin, mode, S):
+    """Fused Winograd F(4x4,3x3) forward + dgrad (csrc/winograd44f.hip), forced on wherever the kernel supports the map
+    (32x32 / 64x64 outputs), vs CPU conv2d.  rel = max|a - b| / max|b| < 3e-5 (the 4-point transform on both axes:
+    measured 4-9e-6; the nested kernel is held to 2e-5)."""
+    from view_fusion_amd import ops
+    ops.FORCE_WINOGRAD44 = True
+    try:
+        test_conv_fwd_bwd(dev, Cin, Cout, Hin, 3, mode, S, tol=3e-5)
+    finally:
+        ops.FORCE_WINOGRAD44 = False
 
 
 @pytest.mark.parametrize("Cin,Cout,Hin,mode,S", [(320, 320, 8, "same", 6), (192, 320, 8, "same", 9), (64, 96, 4, "up2", 5),

@@ -27,7 +27,7 @@ agg = {}
 for kind, flops, e0, e1, tag, name, _nb in log:
     if tag is None:
         continue
-    a = agg.setdefault((kind + ('/W' if name.startswith('vf_wino') else '/D'),) + tag, [0.0, 0.0, 0])
+    a = agg.setdefault((kind + ('/W44' if name.startswith('vf_wino44_conv') else '/W' if name.startswith('vf_wino') else '/D'),) + tag, [0.0, 0.0, 0])
     a[0] += flops; a[1] += e0.elapsed_time(e1) * 1e-3; a[2] += 1
 tot = {}
 for k, (f, t, n) in sorted(agg.items(), key=lambda kv: -kv[1][1]):

@@ -56,6 +56,13 @@ SIGNATURES = {
     "vf_wino_conv_ws_floats": [_I, _I, _I, _I, _I],
     "vf_wino_conv_fill_pct": [_I, _I, _I, _I, _I, ctypes.POINTER(_I)],
     "vf_wino_conv_fwd": [_P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P],
+    "vf_wino44_supported": [_I, _I, _I],
+    "vf_wino44_pack_sizes": [_I, _I, ctypes.POINTER(_L), ctypes.POINTER(_L)],
+    "vf_wino44_pack_weights": [_P, _P, _P, _I, _I, _P],
+    "vf_wino44_pack_weights_multi": [_P, _I, _L, _P],
+    "vf_wino44_conv_ws_floats": [_I, _I, _I, _I, _I],
+    "vf_wino44_conv_fill_pct": [_I, _I, _I, _I, _I, ctypes.POINTER(_I)],
+    "vf_wino44_conv_fwd": [_P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P],
     "vf_wino_wgrad_ws_floats": [_I, _I, _I, _I, _I],
     "vf_wino_wgrad_supported": [_I, _I, _I],
     "vf_wino_wgrad": [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P],
@@ -84,7 +91,7 @@ SIGNATURES = {
     "vf_compose_mse_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "vf_p_sample_tail": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
 }
-_RESTYPE = {"vf_conv1x1_bf16x3_pack_dwords": _L, "vf_conv_wgrad_ws_floats": _L, "vf_time_affine_ws_floats": _L, "vf_wino_conv_ws_floats": _L, "vf_wino_wgrad_ws_floats": _L, "vf_conv_fwd_ws_floats": _L}
+_RESTYPE = {"vf_conv1x1_bf16x3_pack_dwords": _L, "vf_conv_wgrad_ws_floats": _L, "vf_time_affine_ws_floats": _L, "vf_wino_conv_ws_floats": _L, "vf_wino44_conv_ws_floats": _L, "vf_wino_wgrad_ws_floats": _L, "vf_conv_fwd_ws_floats": _L}
 
 _lib = None
 N_CALLS = 0          # C-ABI launcher invocations so far (bench.py: launches per sampler step)

@@ -63,7 +63,7 @@ def _launch(kind, flops, name, *args, tag=None, nbytes=0.0):
 
 # Launchers without a roofline of their own still get a family in the bench's table (so that the table sums to the
 # instrumented step): kind by entry point, "misc" otherwise.
-_CALL_KIND = {"vf_bgemm": "bgemm", "vf_softmax_bwd": "attn_bwd", "vf_softmax_fwd": "attn_fwd",
+_CALL_KIND = {"vf_wino44_pack_weights": "pack", "vf_wino44_pack_weights_multi": "pack", "vf_bgemm": "bgemm", "vf_softmax_bwd": "attn_bwd", "vf_softmax_fwd": "attn_fwd",
               "vf_colsum": "reduce", "vf_colsum_multi": "reduce", "vf_rowsum": "reduce", "vf_bias_grad": "reduce",
               "vf_sumpool2": "reduce", "vf_conv_pack_weights": "pack", "vf_wino_pack_weights": "pack",
               "vf_conv_pack_weights_multi": "pack", "vf_wino_pack_weights_multi": "pack",
@@ -203,7 +203,7 @@ def prime_tables(net, S, device):
     layers = net._affine_layers()
     _ta_desc(layers, S, device)
     return (getattr(net, "_vf_pack_plan", None), _TA_DESC.get(id(layers[0])),
-            [(getattr(m, "_vf_pack", None), getattr(m, "_vf_wpack", None)) for m in net.modules()
+            [(getattr(m, "_vf_pack", None), getattr(m, "_vf_wpack", None), getattr(m, "_vf_w4pack", None)) for m in net.modules()
              if isinstance(m, torch.nn.Conv2d)])
 
 
@@ -442,9 +442,9 @@ def _conv_ws(device, S, Cin, Cout, H, W, KS):
     return ws, ws.numel()
 
 
-def _wino_ws(device, S, Cin, Cout, H, W):
+def _wino_ws(device, S, Cin, Cout, H, W, kind=1):
     """Room for the K-split tail tiles of a Winograd launch whose tile count does not divide the CUs."""
-    need = _lib.load().vf_wino_conv_ws_floats(S, Cin, Cout, H, W)
+    need = getattr(_lib.load(), _WINO_ABI[kind][4])(S, Cin, Cout, H, W)
     if need <= 0:
         return None, 0
     ws = _workspace(device, need)
@@ -490,17 +490,45 @@ WINO_WGRAD_MIN_TILES = int(os.environ.get("VF_WINO_WGRAD_MIN_TILES", 256))   # m
 WINOGRAD_WGRAD = True     # weight gradients of those layers (plain stride-1 ones) through the same transform
 
 
-def use_winograd(S, Cin, Cout, H, W, KS, m):
-    """The Winograd kernel runs ONE 64-tile workgroup per CU: take it when its tile count (after the
-    K-split of the tail tiles) keeps >= 65 % of the CUs busy; small batches (sampler) stay on the
-    direct kernel (+ split-K)."""
-    if not WINOGRAD or KS != 3 or m not in (0, 2) or not _lib.load().vf_wino_supported(H, W, m):
-        return False
+WINOGRAD44 = os.environ.get("VF_WINO44", "1") == "1"     # F(4x4,3x3) forward / dgrad kernel on the large maps
+WINO44_MIN_TILES = int(os.environ.get("VF_WINO44_MIN_TILES", 256))
+FORCE_WINOGRAD44 = False  # tests: F(4x4) wherever the kernel supports the map
+
+
+def wino_kind(S, Cin, Cout, H, W, KS, m):
+    """Which kernel runs the forward AND the dgrad pass of a conv layer (they share one packed-weight format):
+    0 direct (conv.hip), 1 nested Winograd F(2,3)xF(4,3) (winograd24.hip), 2 Winograd F(4x4,3x3) (winograd44f.hip).
+
+    F(4x4) executes 25 % fewer multiplies than the nested kernel but its workgroup tile is 64 channels x 512 pixels:
+    taken on the 32x32 / 64x64 maps when BOTH passes have at least one full round of tiles (256, one workgroup per
+    CU) and the tail plan keeps >= 65 % of the CUs busy.  The nested kernel runs ONE 256-pixel workgroup per CU: taken
+    when its tile count (after the K-split of the tail tiles) keeps >= 65 % of the CUs busy; small batches (sampler)
+    stay on the direct kernel (+ split-K)."""
+    if not WINOGRAD or KS != 3 or m not in (0, 2):
+        return 0
+    lib = _lib.load()
+    if WINOGRAD44 and lib.vf_wino44_supported(H, W, m):
+        if FORCE_WINOGRAD44:
+            return 2
+        if not FORCE_WINOGRAD:
+            ok = True
+            for ci, co in ((Cin, Cout), (Cout, Cin)):
+                tiles = ctypes.c_int(0)
+                fill = lib.vf_wino44_conv_fill_pct(S, ci, co, H, W, ctypes.byref(tiles))
+                ok = ok and tiles.value >= WINO44_MIN_TILES and fill >= WINO_MIN_FILL
+            if ok:
+                return 2
+    if not lib.vf_wino_supported(H, W, m):
+        return 0
     if FORCE_WINOGRAD:
-        return True
+        return 1
     tiles = ctypes.c_int(0)
-    fill = _lib.load().vf_wino_conv_fill_pct(S, Cin, Cout, H, W, ctypes.byref(tiles))
-    return tiles.value >= WINO_MIN_TILES and fill >= WINO_MIN_FILL
+    fill = lib.vf_wino_conv_fill_pct(S, Cin, Cout, H, W, ctypes.byref(tiles))
+    return 1 if (tiles.value >= WINO_MIN_TILES and fill >= WINO_MIN_FILL) else 0
+
+
+def use_winograd(S, Cin, Cout, H, W, KS, m):
+    return wino_kind(S, Cin, Cout, H, W, KS, m) != 0
 
 
 def use_winograd_wgrad(S, Cin, Cout, H, W, KS, m):
@@ -510,19 +538,25 @@ def use_winograd_wgrad(S, Cin, Cout, H, W, KS, m):
     return FORCE_WINOGRAD or S * (H // 2) * (W // 2) >= WINO_WGRAD_MIN_TILES
 
 
-def _packed_wino(layer, force):
-    """Winograd-transformed packed weights (forward / dgrad) of a 3x3 layer; same caching rules as _packed."""
+_WINO_ABI = {1: ("_vf_wpack", "vf_wino_pack_sizes", "vf_wino_pack_weights", "vf_wino_conv_fwd", "vf_wino_conv_ws_floats"),
+             2: ("_vf_w4pack", "vf_wino44_pack_sizes", "vf_wino44_pack_weights", "vf_wino44_conv_fwd", "vf_wino44_conv_ws_floats")}
+
+
+def _packed_wino(layer, force, kind=1):
+    """Winograd-transformed packed weights (forward / dgrad) of a 3x3 layer in the format of kernel `kind`
+    (wino_kind); same caching rules as _packed."""
+    attr, f_sizes, f_pack = _WINO_ABI[kind][:3]
     w = layer.weight
-    cache = getattr(layer, "_vf_wpack", None)
+    cache = getattr(layer, attr, None)
     key = (w._version, w.data_ptr(), w.device)
     if not force and cache is not None and cache[0] == key:
         return cache[1], cache[2]
-    if force and cache is not None and getattr(layer, "_vf_wpack_fresh", False):
-        object.__setattr__(layer, "_vf_wpack_fresh", False)
+    if force and cache is not None and getattr(layer, attr + "_fresh", False):
+        object.__setattr__(layer, attr + "_fresh", False)
         return cache[1], cache[2]
     Cout, Cin = w.shape[0], w.shape[1]
     nf, nb = ctypes.c_long(), ctypes.c_long()
-    _lib.call("vf_wino_pack_sizes", Cout, Cin, ctypes.byref(nf), ctypes.byref(nb))
+    _lib.call(f_sizes, Cout, Cin, ctypes.byref(nf), ctypes.byref(nb))
     if cache is not None and cache[1].numel() == nf.value and cache[1].device == w.device:
         uf, ub = cache[1], cache[2]
     else:
@@ -530,8 +564,8 @@ def _packed_wino(layer, force):
         ub = torch.empty(nb.value, device=w.device, dtype=torch.float32)
     wd = w.detach()
     _check(wd)
-    _call("vf_wino_pack_weights", _ptr(wd), _ptr(uf), _ptr(ub), Cout, Cin, _stream())
-    object.__setattr__(layer, "_vf_wpack", (None if force else key, uf, ub))
+    _call(f_pack, _ptr(wd), _ptr(uf), _ptr(ub), Cout, Cin, _stream())
+    object.__setattr__(layer, attr, (None if force else key, uf, ub))
     return uf, ub
 
 
@@ -547,58 +581,53 @@ def pack_all(root, S=None):
         return
     _check(layers[0].weight.detach())
 
-    def wants_wino(l):
+    def kind_of(l):
         geom = getattr(l, "_vf_geom", None)
         if geom is None or S is None:
-            return False
-        return use_winograd(S, l.weight.shape[1], l.weight.shape[0], geom[0], geom[0], l.weight.shape[2],
-                            _MODES[geom[1]])
+            return 0
+        return wino_kind(S, l.weight.shape[1], l.weight.shape[0], geom[0], geom[0], l.weight.shape[2], _MODES[geom[1]])
 
-    key = tuple((l.weight.data_ptr(), wants_wino(l)) for l in layers)
+    key = tuple((l.weight.data_ptr(), kind_of(l)) for l in layers)
     if plan is None or plan[1] != key:
         dev = layers[0].weight.device
-        rows_d, rows_w, first_d, first_w = [], [], 0, 0
-        for l, (_, wino) in zip(layers, key):
+        rows, first = {0: [], 1: [], 2: []}, {0: 0, 1: 0, 2: 0}
+        for l, (_, kind) in zip(layers, key):
             w = l.weight
             Cout, Cin, KS, _ = w.shape
             nf, nb = ctypes.c_long(), ctypes.c_long()
-            if wino:
-                _lib.call("vf_wino_pack_sizes", Cout, Cin, ctypes.byref(nf), ctypes.byref(nb))
+            if kind:
+                _lib.call(_WINO_ABI[kind][1], Cout, Cin, ctypes.byref(nf), ctypes.byref(nb))
             else:
                 _lib.call("vf_conv_pack_sizes", Cout, Cin, KS, ctypes.byref(nf), ctypes.byref(nb))
             pf = torch.empty(nf.value, device=dev, dtype=torch.float32)
             pb = torch.empty(nb.value, device=dev, dtype=torch.float32)
             nblk = (nf.value + nb.value + 255) // 256
-            if wino:
-                object.__setattr__(l, "_vf_wpack", (None, pf, pb))
-                rows_w.append([w.data_ptr(), pf.data_ptr(), pb.data_ptr(), Cout, Cin, nf.value, nb.value, first_w])
-                first_w += nblk
+            if kind:
+                object.__setattr__(l, _WINO_ABI[kind][0], (None, pf, pb))
+                rows[kind].append([w.data_ptr(), pf.data_ptr(), pb.data_ptr(), Cout, Cin, nf.value, nb.value, first[kind]])
             else:
                 object.__setattr__(l, "_vf_pack", (None, pf, pb))
-                rows_d.append([w.data_ptr(), pf.data_ptr(), pb.data_ptr(), Cout, Cin, KS, nf.value, nb.value, first_d])
-                first_d += nblk
-        desc_d = torch.tensor(rows_d, dtype=torch.int64).to(dev) if rows_d else None
-        desc_w = torch.tensor(rows_w, dtype=torch.int64).to(dev) if rows_w else None
-        plan = (layers, key, (desc_d, len(rows_d), first_d), (desc_w, len(rows_w), first_w))
+                rows[0].append([w.data_ptr(), pf.data_ptr(), pb.data_ptr(), Cout, Cin, KS, nf.value, nb.value, first[0]])
+            first[kind] += nblk
+        descs = tuple((torch.tensor(rows[k], dtype=torch.int64).to(dev) if rows[k] else None, len(rows[k]), first[k])
+                      for k in (0, 1, 2))
+        plan = (layers, key, descs)
         object.__setattr__(root, "_vf_pack_plan", plan)
-    (desc_d, nd, blk_d), (desc_w, nw, blk_w) = plan[2], plan[3]
-    if nd:
-        _call("vf_conv_pack_weights_multi", ctypes.c_void_p(desc_d.data_ptr()), nd, blk_d, _stream())
-    if nw:
-        _call("vf_wino_pack_weights_multi", ctypes.c_void_p(desc_w.data_ptr()), nw, blk_w, _stream())
+    for k, fn in ((0, "vf_conv_pack_weights_multi"), (1, "vf_wino_pack_weights_multi"), (2, "vf_wino44_pack_weights_multi")):
+        desc, n, blk = plan[2][k]
+        if n:
+            _call(fn, ctypes.c_void_p(desc.data_ptr()), n, blk, _stream())
     # A training pack is consumed once, through its `_fresh` flag, by this forward's conv2d call.  Its cache key stays
-    # None (and the key of the layer's OTHER format is dropped too): an optimizer may update the weights without
-    # touching `_version` (torch._fused_adam_), so after a training forward no cached pack of either format may be
+    # None (and the keys of the layer's OTHER formats are dropped too): an optimizer may update the weights without
+    # touching `_version` (torch._fused_adam_), so after a training forward no cached pack of any format may be
     # trusted by a later no-grad forward (generate / p_sample after Trainer.step()).
-    for l, (_, wino) in zip(layers, plan[1]):
-        attr, other = ("_vf_wpack", "_vf_pack") if wino else ("_vf_pack", "_vf_wpack")
-        c = getattr(l, attr)
-        if c[0] is not None:
-            object.__setattr__(l, attr, (None, c[1], c[2]))
-        o = getattr(l, other, None)
-        if o is not None and o[0] is not None:
-            object.__setattr__(l, other, (None, o[1], o[2]))
-        object.__setattr__(l, attr + "_fresh", True)
+    attrs = ("_vf_pack", "_vf_wpack", "_vf_w4pack")
+    for l, (_, kind) in zip(layers, plan[1]):
+        for k, attr in enumerate(attrs):
+            c = getattr(l, attr, None)
+            if c is not None and c[0] is not None:
+                object.__setattr__(l, attr, (None, c[1], c[2]))
+        object.__setattr__(l, attrs[kind] + "_fresh", True)
 
 
 # EXPERIMENT, default off: VF_BF16X3=1 routes the forward and dgrad passes of the 1x1 convolutions (maps >= 8x8) through
@@ -684,7 +713,7 @@ class _Conv2dFn(torch.autograd.Function):
         flops = 2.0 * S * Cout * Cin * KS * KS * H * W
         # algorithmic HBM bytes: input, output (+ residual) and the weights, each once
         nb = 4.0 * (x.numel() + y.numel() + weight.numel() + (residual.numel() if residual is not None else 0))
-        wino = use_winograd(S, Cin, Cout, H, W, KS, m)
+        wino = wino_kind(S, Cin, Cout, H, W, KS, m)
         ctx.b3 = _use_b3(KS, m, H * W)
         if ctx.b3:
             wf, wb = _packed_b3(layer, force=training)
@@ -692,9 +721,9 @@ class _Conv2dFn(torch.autograd.Function):
                     _ptr(view_bias), _ptr(residual), _ptr(y), None, 0, S, Cin, Cout, H * W, _stream(),
                     tag=(Cin, Cout, H, KS, m))
         elif wino:
-            wf, wb = _packed_wino(layer, force=training)
-            ws, nws = _wino_ws(x.device, S, Cin, Cout, H, W)
-            _launch("conv_fwd", flops, "vf_wino_conv_fwd", _ptr(x), _ptr(wf), _ptr(bias), _ptr(view_bias),
+            wf, wb = _packed_wino(layer, training, wino)
+            ws, nws = _wino_ws(x.device, S, Cin, Cout, H, W, wino)
+            _launch("conv_fwd", flops, _WINO_ABI[wino][3], _ptr(x), _ptr(wf), _ptr(bias), _ptr(view_bias),
                     _ptr(residual), _ptr(y), _ptr(ws), nws, S, Cin, Cout, H, W, m, _stream(),
                     tag=(Cin, Cout, H, KS, m), nbytes=nb)
         else:
@@ -723,8 +752,8 @@ class _Conv2dFn(torch.autograd.Function):
         dx = dw = db = dvb = dres = None
         if ctx.needs_input_grad[0] and ctx.wino:      # Winograd dgrad (dy and dx have the conv's output size)
             dfull = torch.empty(S, Cin, H, W, device=x.device, dtype=torch.float32)
-            ws, nws = _wino_ws(x.device, S, Cout, Cin, H, W)
-            _launch("conv_dgrad", ctx.flops, "vf_wino_conv_fwd", _ptr(dy), _ptr(ctx.wb), None, None, None,
+            ws, nws = _wino_ws(x.device, S, Cout, Cin, H, W, ctx.wino)
+            _launch("conv_dgrad", ctx.flops, _WINO_ABI[ctx.wino][3], _ptr(dy), _ptr(ctx.wb), None, None, None,
                     _ptr(dfull), _ptr(ws), nws, S, Cout, Cin, H, W, 0, st, tag=ctx.tag,
                     nbytes=4.0 * (dy.numel() + dfull.numel() + ctx.pw.numel()))
             if m == 2:                                 # upsample + conv: 2x2 sum-pool back to the source size
