@@ -84,8 +84,16 @@ struct FGeo {
 #ifdef VF_STAMPS44F
 __device__ unsigned long long g_stamps44f[16];
 #endif
+// rows outside the image are loaded from here (as large as the largest per-lane offset of a row load: 3 channels of a
+// 64x64 map + one row; never written)
+__device__ float g_f44_zero[16384];
 
-template <int LOGW, int MODE>
+// An LDS-only workgroup barrier: __syncthreads() also drains the wave's outstanding GLOBAL stores (vmcnt), which in the
+// epilogue are the output rows just issued -- thousands of cycles; the exchange only needs the LDS traffic ordered.
+#define VF_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+// RAGGED: Cin is no multiple of 8 (stem, dgrad of the head): the last chunk's channel offsets are clamped per lane.
+template <int LOGW, int MODE, bool RAGGED>
 __global__ __launch_bounds__(512, 2) void wino44_conv_kernel(F44Args a) {
     using G = FGeo<LOGW, MODE>;
     constexpr int NT_ = 512;
@@ -128,8 +136,6 @@ __global__ __launch_bounds__(512, 2) void wino44_conv_kernel(F44Args a) {
     const int xcl = lane / G::Q, xq = lane % G::Q;
     const unsigned xgofs = (unsigned)(xcl * (4 * G::SH * G::SW) + (MODE == 0 ? 16 : 8) * xq);
     const int xlofs = xcl * G::PS + 4 * xq + 5;
-    const int lastc = a.CinP / FCK - 1;                  // the one chunk whose channels can reach beyond Cin
-    const bool cin_ragged = (a.Cin & (FCK - 1)) != 0;
 
     struct Tile {                                        // all workgroup-uniform
         const char* ubase;                               // U block of (co tile, first chunk)
@@ -151,32 +157,35 @@ __global__ __launch_bounds__(512, 2) void wino44_conv_kernel(F44Args a) {
         return t;
     };
     unsigned uoffb = 4u * (unsigned)(((wg_ * 9) * FCO + cw * 32 + li) * FCK + 4 * lh);
-    // slot I of this wave: patch row / channel group (scalar), validity for tile T (scalar)
-#define VF_SID(I) (wid + 8 * (I))
+    // slot I of this wave: patch row / channel group (scalar).  Every wave issues exactly three row loads and three row
+    // stores per chunk, UNCONDITIONALLY (a load or an LDS store inside a branch costs the compiler its count of what is
+    // in flight: every later s_waitcnt then waits for the youngest requests too -- measured: 670 cycles per chunk):
+    //   * a row outside the image is loaded from a zero-filled buffer (scalar select of the base) and stored like
+    //     any other row: no per-tile zeroing of such rows either;
+    //   * a wave without a third slot (sid >= NSLOT) repeats its second one (same bytes to the same place).
+#define VF_SID(I) (wid + 8 * (I) < NSLOT ? wid + 8 * (I) : wid + 8 * (I) - 8)
 #define VF_SROW(I) (VF_SID(I) % G::PH)
 #define VF_SCG(I) (VF_SID(I) / G::PH)
 #define VF_SUY(T, I) ((T).r0 + VF_SROW(I) - 1)
-#define VF_SOK(T, I) (VF_SID(I) < NSLOT && VF_SUY(T, I) >= 0 && VF_SUY(T, I) < G::H)
     // channels beyond Cin (last chunk of a Cin that is no multiple of 8) read the clamped last channel -- finite
     // values whose packed weights are zero
     auto fetch_x = [&](const Tile& t, int i, int c, f32x4& v) {
-        if (VF_SOK(t, i)) {
-            const int cg = c0 + c;
-            const int uy = VF_SUY(t, i);
-            const char* b_ = t.xbase + (size_t)(cg * FCK + VF_SCG(i) * CPS) * (4 * G::SH * G::SW)
-                             + 4 * (MODE == 0 ? uy * G::SW : (uy >> 1) * G::SW);
-            unsigned o_ = xgofs;
-            if (cin_ragged && cg == lastc) {
-                int lim = a.Cin - 1 - cg * FCK - VF_SCG(i) * CPS;             // last valid channel of this slot
-                if (lim < 0) { b_ += (long)lim * (4 * G::SH * G::SW); lim = 0; }   // none: every lane reads channel Cin - 1
-                o_ = (unsigned)(min(xcl, lim) * (4 * G::SH * G::SW) + (MODE == 0 ? 16 : 8) * xq);
-            }
-            asm("" : "+s"(b_), "+v"(o_));
-            if (MODE == 0) v = *(const __attribute__((address_space(1))) f32x4*)((const __attribute__((address_space(1))) char*)b_ + o_);
-            else {
-                const f32x2 h = *(const __attribute__((address_space(1))) f32x2*)((const __attribute__((address_space(1))) char*)b_ + o_);
-                v = (f32x4){h.x, h.x, h.y, h.y};
-            }
+        const int cg = c0 + c;
+        const int uy = VF_SUY(t, i);
+        const char* b_ = t.xbase + (size_t)(cg * FCK + VF_SCG(i) * CPS) * (4 * G::SH * G::SW)
+                         + 4 * (MODE == 0 ? uy * G::SW : (uy >> 1) * G::SW);
+        unsigned o_ = xgofs;
+        if (RAGGED) {                                    // (every chunk: in all but the last one lim >= CPS - 1)
+            int lim = a.Cin - 1 - cg * FCK - VF_SCG(i) * CPS;                 // last valid channel of this slot
+            if (lim < 0) { b_ += (long)lim * (4 * G::SH * G::SW); lim = 0; }  // none: every lane reads channel Cin - 1
+            o_ = (unsigned)(min(xcl, lim) * (4 * G::SH * G::SW) + (MODE == 0 ? 16 : 8) * xq);
+        }
+        if (uy < 0 || uy >= G::H) b_ = reinterpret_cast<const char*>(g_f44_zero);     // (scalar: s_cselect)
+        asm("" : "+s"(b_), "+v"(o_));
+        if (MODE == 0) v = *(const __attribute__((address_space(1))) f32x4*)((const __attribute__((address_space(1))) char*)b_ + o_);
+        else {
+            const f32x2 h = *(const __attribute__((address_space(1))) f32x2*)((const __attribute__((address_space(1))) char*)b_ + o_);
+            v = (f32x4){h.x, h.x, h.y, h.y};
         }
     };
 
@@ -199,22 +208,14 @@ __global__ __launch_bounds__(512, 2) void wino44_conv_kernel(F44Args a) {
       VF_ULOAD(T, 5, C); VF_ULOAD(T, 6, C); VF_ULOAD(T, 7, C); VF_ULOAD(T, 8, C); }
 #define VF_XLOAD(T, C, R0, R1, R2) { fetch_x((T), 0, (C), R0); fetch_x((T), 1, (C), R1); fetch_x((T), 2, (C), R2); }
     // (pixels sit at odd dword offsets, idx 5 + 4 q: four ds_write_b32, as two ds_write2_b32, per float4)
-#define VF_XST1(T, BUF, I, R)                                                                           \
-    if (VF_SOK(T, I)) {                                                                                 \
+#define VF_XST1(BUF, I, R)                                                                              \
+    {                                                                                                   \
         int so_ = (BUF) * PSZ + VF_SCG(I) * CPS * G::PS + VF_SROW(I) * G::PW;                           \
         asm("" : "+s"(so_));                                                                            \
         float* d_ = Pl + so_ + xlofs;                                                                   \
         d_[0] = R.x; d_[1] = R.y; d_[2] = R.z; d_[3] = R.w;                                             \
     }
-#define VF_XSTORE(T, BUF, R0, R1, R2) { VF_XST1(T, BUF, 0, R0); VF_XST1(T, BUF, 1, R1); VF_XST1(T, BUF, 2, R2); }
-    // rows of the tile that lie outside the image: zero in both raw-row buffers
-#define VF_XZ1(T, I)                                                                                    \
-    if (VF_SID(I) < NSLOT && !VF_SOK(T, I)) {                                                           \
-        float* d_ = Pl + VF_SCG(I) * CPS * G::PS + VF_SROW(I) * G::PW + xlofs;                          \
-        d_[0] = 0.f; d_[1] = 0.f; d_[2] = 0.f; d_[3] = 0.f;                                             \
-        d_[PSZ] = 0.f; d_[PSZ + 1] = 0.f; d_[PSZ + 2] = 0.f; d_[PSZ + 3] = 0.f;                         \
-    }
-#define VF_XZERO(T) { VF_XZ1(T, 0); VF_XZ1(T, 1); VF_XZ1(T, 2); }
+#define VF_XSTORE(T, BUF, R0, R1, R2) { VF_XST1(BUF, 0, R0); VF_XST1(BUF, 1, R1); VF_XST1(BUF, 2, R2); }
 
     // ---- input transform duty: channel tci, tile ttl, half th (wave-uniform): half 0 -> transformed rows 0-2 from
     // window rows 0-4, half 1 -> rows 3-5 from window rows 1-5.  The lanes of a ds_read_b128 lane group
@@ -243,8 +244,8 @@ __global__ __launch_bounds__(512, 2) void wino44_conv_kernel(F44Args a) {
         wr[J][0] = q_.xy; wr[J][1] = q_.zw;                                                             \
     }
 #define VF_WIN_READ2(BUF, J) { wr[J][2] = *reinterpret_cast<const f32x2*>(Pl + (BUF) * PSZ + wpo + (J) * G::PW + 4); }
-    auto win_rows1 = [&](int c) {
-        if (th == 0) {                                   // wr[j] = d_j
+    auto win_rows1 = [&](int c, int th_) {               // th_: the half, a compile-time constant at every call site
+        if (th_ == 0) {                                  // wr[j] = d_j
             const f32x2 P = pk_nmul4_add(wr[2][c], wr[4][c]);
             const f32x2 R = pk_nmul4_add(wr[1][c], wr[3][c]);
             tv[0][c] = pk_fmak<4>(wr[0][c], pk_sub(P, wr[2][c]));
@@ -280,7 +281,10 @@ __global__ __launch_bounds__(512, 2) void wino44_conv_kernel(F44Args a) {
         vo_[f44_p(R_, 0) * 64] = c05.x; vo_[f44_p(R_, 1) * 64] = c12.x; vo_[f44_p(R_, 2) * 64] = c12.y;  \
         vo_[f44_p(R_, 3) * 64] = c34.x; vo_[f44_p(R_, 4) * 64] = c34.y; vo_[f44_p(R_, 5) * 64] = c05.y;  \
     }
-    const int voff = (wg_ * 9) * 64 + lane;
+    // (one base per V buffer: every fragment is then base + a multiple of 64 dwords below 256 -- ds_read2st64_b32)
+    const float* const vb0 = Vl + (wg_ * 9) * 64 + lane;
+    const float* const vb1 = vb0 + VSZ;                  // (the compiler folds this back into offsets: an opaque second
+                                                         // base register was tried and tips the kernel into spills)
 
     // ---- first loads of the first tile: U(0), rows(0), rows(1) -- all issued together (one round trip)
     f32x4 yr0 = xr0, yr1 = xr0, yr2 = xr0;
@@ -290,13 +294,19 @@ __global__ __launch_bounds__(512, 2) void wino44_conv_kernel(F44Args a) {
     for (int i = tid; i < 2 * PSZ; i += NT_) Pl[i] = 0.f;    // halo columns stay zero in both buffers, for every tile
 
 #ifdef VF_STAMPS44F
-    unsigned long long st_loop = 0, st_epi = 0, st_tiles = 0, st_e[6] = {0, 0, 0, 0, 0, 0};
+    const unsigned long long rt_0 = __builtin_amdgcn_s_memrealtime(), ct_0 = __builtin_amdgcn_s_memtime();
+    unsigned long long st_loop = 0, st_epi = 0, st_tiles = 0, st_e[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_p[2][3];
 #define VF_STAMP(V) const unsigned long long V = __builtin_amdgcn_s_memtime()
 #else
 #define VF_STAMP(V)
 #endif
     // One slice = four MFMAs (K = 8) on accumulator B; side work goes BEHIND the slice's own MFMAs.  FIRST: the
     // accumulator starts from the literal 0.
+#ifdef VF_AB_NOU
+#define VF_ABU(...)
+#else
+#define VF_ABU(...) __VA_ARGS__
+#endif
 #define VF_SLICE(C, FIRST, B, BC, SIDE0, SIDE1, SIDE2)                                                   \
     {                                                                                                    \
         __builtin_amdgcn_sched_barrier(0);                                                               \
@@ -314,10 +324,10 @@ __global__ __launch_bounds__(512, 2) void wino44_conv_kernel(F44Args a) {
         __builtin_amdgcn_sched_barrier(0);                                                               \
         acc[B] = __builtin_amdgcn_mfma_f32_32x32x2f32(ur##B.w, BC[3], acc[B], 0, 0, 0);                  \
         __builtin_amdgcn_sched_barrier(0);                                                               \
-        VF_ULOAD(cur, B, min((C) + 1, clast));            /* this slice's U of the NEXT chunk, in place */ \
+        VF_ABU(VF_ULOAD(cur, B, min((C) + 1, clast)));    /* this slice's U of the NEXT chunk, in place */ \
     }
 #define VF_BFRAG(D, BUF_, S_)                                                                            \
-    { _Pragma("unroll") for (int e = 0; e < 4; ++e) D[e] = Vl[(BUF_) * VSZ + voff + ((S_) + e * FNS) * 64]; }
+    { _Pragma("unroll") for (int e = 0; e < 4; ++e) D[e] = ((BUF_) ? vb1 : vb0)[((S_) + e * FNS) * 64]; }
     // One chunk, PAR = chunk parity = its V buffer (compile time).  The B fragments alternate between two register
     // sets X, Y (nine slices: the NEXT chunk starts on the other set, which is why the sets are macro arguments);
     // slice 0's are loaded by the previous chunk.
@@ -329,27 +339,41 @@ __global__ __launch_bounds__(512, 2) void wino44_conv_kernel(F44Args a) {
     // Hazards: V[PAR] is rewritten in slices 2-4 of chunk C+1 (behind this barrier, all its reads are in front);
     // P[PAR^1] is rewritten in slice 6 of chunk C+1, read in slices 0-1 of C.  Staging indices beyond the last chunk
     // are clamped (the final iterations redo harmless loads / LDS writes that nobody reads).
-#define VF_CHUNK(C, PAR, FIRST, X, Y)                                                                    \
+#ifdef VF_AB_NOXFORM      /* diagnostic builds (tools/wino44f_ablate.sh): leave one kind of side work out of the chunk loop */
+#define VF_ABX(...)
+#else
+#define VF_ABX(...) __VA_ARGS__
+#endif
+#ifdef VF_AB_NOX
+#define VF_ABR(...)
+#else
+#define VF_ABR(...) __VA_ARGS__
+#endif
+#ifdef VF_AB_NOBF
+#define VF_ABB(...)
+#else
+#define VF_ABB(...) __VA_ARGS__
+#endif
+#define VF_CHUNK(C, PAR, FIRST, X, Y, TH)                                                                \
     {                                                                                                    \
-        VF_SLICE(C, FIRST, 0, X, { VF_BFRAG(Y, PAR, 1); VF_WIN_READ4((PAR) ^ 1, 0); VF_WIN_READ4((PAR) ^ 1, 1); }, \
-                 { VF_WIN_READ4((PAR) ^ 1, 2); VF_WIN_READ4((PAR) ^ 1, 3); }, VF_WIN_READ4((PAR) ^ 1, 4)); \
-        VF_SLICE(C, FIRST, 1, Y, { VF_BFRAG(X, PAR, 2); win_rows1(0); }, win_rows1(1),                   \
-                 { VF_WIN_READ2((PAR) ^ 1, 0); VF_WIN_READ2((PAR) ^ 1, 1); VF_WIN_READ2((PAR) ^ 1, 2);   \
-                   VF_WIN_READ2((PAR) ^ 1, 3); VF_WIN_READ2((PAR) ^ 1, 4); });                           \
-        VF_SLICE(C, FIRST, 2, X, { VF_BFRAG(Y, PAR, 3); win_rows1(2); }, win_col(0), VF_WIN_WRITE((PAR) ^ 1, 0)); \
-        VF_SLICE(C, FIRST, 3, Y, { VF_BFRAG(X, PAR, 4); win_col(1); }, VF_WIN_WRITE((PAR) ^ 1, 1), (void)0); \
-        VF_SLICE(C, FIRST, 4, X, { VF_BFRAG(Y, PAR, 5); win_col(2); }, VF_WIN_WRITE((PAR) ^ 1, 2), (void)0); \
-        VF_SLICE(C, FIRST, 5, Y, VF_BFRAG(X, PAR, 6), (void)0, (void)0);                                 \
-        VF_SLICE(C, FIRST, 6, X, VF_BFRAG(Y, PAR, 7), VF_XSTORE(cur, PAR, xr0, xr1, xr2), (void)0);      \
-        VF_SLICE(C, FIRST, 7, Y, VF_BFRAG(X, PAR, 8), (void)0, (void)0);                                 \
-        __syncthreads();                                                                                 \
-        VF_SLICE(C, FIRST, 8, X, VF_BFRAG(Y, (PAR) ^ 1, 0), VF_XLOAD(cur, min((C) + 3, clast), xr0, xr1, xr2), (void)0); \
+        VF_SLICE(C, FIRST, 0, X, { VF_ABB(VF_BFRAG(Y, PAR, 1)); VF_ABX(VF_WIN_READ4((PAR) ^ 1, 0); VF_WIN_READ4((PAR) ^ 1, 1)); }, \
+                 { VF_ABX(VF_WIN_READ4((PAR) ^ 1, 2); VF_WIN_READ4((PAR) ^ 1, 3)); }, VF_ABX(VF_WIN_READ4((PAR) ^ 1, 4))); \
+        VF_SLICE(C, FIRST, 1, Y, { VF_ABB(VF_BFRAG(X, PAR, 2)); VF_ABX(win_rows1(0, TH)); }, VF_ABX(win_rows1(1, TH)), \
+                 { VF_ABX(VF_WIN_READ2((PAR) ^ 1, 0); VF_WIN_READ2((PAR) ^ 1, 1); VF_WIN_READ2((PAR) ^ 1, 2); \
+                   VF_WIN_READ2((PAR) ^ 1, 3); VF_WIN_READ2((PAR) ^ 1, 4)); });                          \
+        VF_SLICE(C, FIRST, 2, X, { VF_ABB(VF_BFRAG(Y, PAR, 3)); VF_ABX(win_rows1(2, TH)); }, VF_ABX(win_col(0)), VF_ABX(VF_WIN_WRITE((PAR) ^ 1, 0))); \
+        VF_SLICE(C, FIRST, 3, Y, { VF_ABB(VF_BFRAG(X, PAR, 4)); VF_ABX(win_col(1)); }, VF_ABX(VF_WIN_WRITE((PAR) ^ 1, 1)), (void)0); \
+        VF_SLICE(C, FIRST, 4, X, { VF_ABB(VF_BFRAG(Y, PAR, 5)); VF_ABX(win_col(2)); }, VF_ABX(VF_WIN_WRITE((PAR) ^ 1, 2)), (void)0); \
+        VF_SLICE(C, FIRST, 5, Y, VF_ABB(VF_BFRAG(X, PAR, 6)), (void)0, (void)0);                         \
+        VF_SLICE(C, FIRST, 6, X, VF_ABB(VF_BFRAG(Y, PAR, 7)), VF_ABR(VF_XSTORE(cur, PAR, xr0, xr1, xr2)), (void)0); \
+        VF_SLICE(C, FIRST, 7, Y, VF_ABB(VF_BFRAG(X, PAR, 8)), (void)0, (void)0);                         \
+        VF_LDS_BARRIER();                                                                                \
+        VF_SLICE(C, FIRST, 8, X, VF_ABB(VF_BFRAG(Y, (PAR) ^ 1, 0)), VF_ABR(VF_XLOAD(cur, min((C) + 3, clast), xr0, xr1, xr2)), (void)0); \
     }
 
     // Staging of a tile's first chunks: rows(0), rows(1) -> P[0], P[1] (rows(2) requested), then V(0) from P[0].
 #define VF_STAGE_ROWS(T)                                                                                 \
     {                                                                                                    \
-        VF_XZERO(T);                                                                                     \
         VF_XSTORE(T, 0, xr0, xr1, xr2);                                                                  \
         VF_XSTORE(T, 1, yr0, yr1, yr2);                                                                  \
         VF_XLOAD(T, min(2, clast), xr0, xr1, xr2);                                                       \
@@ -358,7 +382,8 @@ __global__ __launch_bounds__(512, 2) void wino44_conv_kernel(F44Args a) {
     {                                                                                                    \
         VF_WIN_READ4(0, 0); VF_WIN_READ4(0, 1); VF_WIN_READ4(0, 2); VF_WIN_READ4(0, 3); VF_WIN_READ4(0, 4); \
         VF_WIN_READ2(0, 0); VF_WIN_READ2(0, 1); VF_WIN_READ2(0, 2); VF_WIN_READ2(0, 3); VF_WIN_READ2(0, 4); \
-        win_rows1(0); win_rows1(1); win_rows1(2);                                                        \
+        if (th == 0) { win_rows1(0, 0); win_rows1(1, 0); win_rows1(2, 0); }                              \
+        else { win_rows1(0, 1); win_rows1(1, 1); win_rows1(2, 1); }                                      \
         win_col(0); VF_WIN_WRITE(0, 0); win_col(1); VF_WIN_WRITE(0, 1); win_col(2); VF_WIN_WRITE(0, 2);  \
     }
     __syncthreads();                                      // zero fill done
@@ -373,20 +398,26 @@ __global__ __launch_bounds__(512, 2) void wino44_conv_kernel(F44Args a) {
         VF_BFRAG(bfA, 0, 0);
         VF_STAMP(t_1);
 
-        if (nch > 0) {
-            VF_CHUNK(0, 0, 1, bfA, bfB);
-        } else {
+        // (the two halves of the transform duty run their own copy of the loop: the half is a compile-time constant there)
+#define VF_LOOP(TH)                                                                                      \
+        {                                                                                                \
+            VF_CHUNK(0, 0, 1, bfA, bfB, TH);                                                             \
+            int c = 1;                                                                                   \
+            for (; c + 1 < nch; c += 2) {                                                                \
+                VF_CHUNK(c, 1, 0, bfB, bfA, TH);                                                         \
+                VF_CHUNK(c + 1, 0, 0, bfA, bfB, TH);                                                     \
+            }                                                                                            \
+            if (c < nch) VF_CHUNK(c, 1, 0, bfB, bfA, TH);                                                \
+        }
+        if (nch <= 0) {
 #pragma unroll
             for (int b = 0; b < 9; ++b) acc[b] = (f32x16){0};
+        } else if (th == 0) {
+            VF_LOOP(0);
+        } else {
+            VF_LOOP(1);
         }
-        {
-            int c = 1;
-            for (; c + 1 < nch; c += 2) {
-                VF_CHUNK(c, 1, 0, bfB, bfA);
-                VF_CHUNK(c + 1, 0, 0, bfA, bfB);
-            }
-            if (c < nch) VF_CHUNK(c, 1, 0, bfB, bfA);
-        }
+#undef VF_LOOP
 
         VF_STAMP(t_2);
         const unsigned lin_next = lin + F44_PERSIST;
@@ -403,7 +434,13 @@ __global__ __launch_bounds__(512, 2) void wino44_conv_kernel(F44Args a) {
         const int li_e = lane_e & 31, lh_e = lane_e >> 5;
         const int orow = r0 + 4 * G::t_row(li_e), ocol = 4 * G::t_col(li_e);
         float* const xch = Vl;
-        Tile nx = cur;
+        // the next whole tile's first loads go out FIRST (U fragments and raw-row registers are dead; issued
+        // unconditionally -- the last tile re-reads its own first chunks): every output store of this epilogue is then
+        // younger than they are, and no wait for them (in-order counter) has to sit out a store
+        const Tile nx = make_tile(has_next ? logical_of(lin_next) : logical_cur);
+        VF_ULOAD_ALL(nx, 0);
+        VF_XLOAD(nx, 0, xr0, xr1, xr2);
+        VF_XLOAD(nx, min(1, clast), yr0, yr1, yr2);
 
         // ---- output transform.  Columns (A4^T = [[1,1,1,1,1,0],[0,1,-1,2,-2,0],[0,1,1,4,4,0],[0,1,-1,8,-8,1]]) in
         // registers: the full row M[0..5] = acc[0..5] gives T[0..3]; the half row acc[6..8] gives the three values its
@@ -412,7 +449,7 @@ __global__ __launch_bounds__(512, 2) void wino44_conv_kernel(F44Args a) {
         const bool jh = wg_ & 1;                             // (uniform) which half of the shared row
 #pragma unroll
         for (int ps = 0; ps < 2; ++ps) {
-            if (ps == 1) __syncthreads();                    // pass 0's values have been read
+            if (ps == 1) VF_LDS_BARRIER();                   // pass 0's values have been read
             float* xo = xch + (size_t)(wid * 7) * (8 * 64) + lane_e;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {                    // register pairs (8 ps + 2 k, + 1)
@@ -427,9 +464,12 @@ __global__ __launch_bounds__(512, 2) void wino44_conv_kernel(F44Args a) {
                 const f32x2 T3 = pk_add(pk_fmak<8>(d34, d12), m5);
                 const f32x2 h0 = (f32x2){acc[6][r], acc[6][r + 1]}, h1 = (f32x2){acc[7][r], acc[7][r + 1]};
                 const f32x2 h2 = (f32x2){acc[8][r], acc[8][r + 1]};
-                const f32x2 hs = pk_add(h0, h1), hd = pk_sub(h0, h1);        // cols 3-5: (m3 + m4, m3 - m4, m5)
-                const f32x2 gs = pk_add(h1, h2), gd = pk_sub(h1, h2);        // cols 0-2: (m0 + (m1 + m2), m1 - m2, m1 + m2)
-                const f32x2 H0 = jh ? hs : pk_add(h0, gs), H1 = jh ? hd : gd, H2 = jh ? h2 : gs;
+                f32x2 H0, H1, H2;
+                if (jh) {                                    // cols 3-5: (m3 + m4, m3 - m4, m5)
+                    H0 = pk_add(h0, h1); H1 = pk_sub(h0, h1); H2 = h2;
+                } else {                                     // cols 0-2: (m0 + (m1 + m2), m1 - m2, m1 + m2)
+                    H2 = pk_add(h1, h2); H1 = pk_sub(h1, h2); H0 = pk_add(h0, H2);
+                }
                 xo[(0 * 8 + 2 * k) * 64] = T0.x; xo[(0 * 8 + 2 * k + 1) * 64] = T0.y;
                 xo[(1 * 8 + 2 * k) * 64] = T1.x; xo[(1 * 8 + 2 * k + 1) * 64] = T1.y;
                 xo[(2 * 8 + 2 * k) * 64] = T2.x; xo[(2 * 8 + 2 * k + 1) * 64] = T2.y;
@@ -438,15 +478,13 @@ __global__ __launch_bounds__(512, 2) void wino44_conv_kernel(F44Args a) {
                 xo[(5 * 8 + 2 * k) * 64] = H1.x; xo[(5 * 8 + 2 * k + 1) * 64] = H1.y;
                 xo[(6 * 8 + 2 * k) * 64] = H2.x; xo[(6 * 8 + 2 * k + 1) * 64] = H2.y;
             }
-            if (ps == 1) {
-                // the accumulators are dead: the next whole tile's first loads go out now and land under the rest of
-                // the epilogue (issued unconditionally -- the last tile re-reads its own first chunks)
-                nx = make_tile(has_next ? logical_of(lin_next) : logical_cur);
-                VF_ULOAD_ALL(nx, 0);
-                VF_XLOAD(nx, 0, xr0, xr1, xr2);
-                VF_XLOAD(nx, min(1, clast), yr0, yr1, yr2);
-            }
-            __syncthreads();
+#ifdef VF_STAMPS44F
+            t_p[ps][0] = __builtin_amdgcn_s_memtime();
+#endif
+            VF_LDS_BARRIER();
+#ifdef VF_STAMPS44F
+            t_p[ps][1] = __builtin_amdgcn_s_memtime();
+#endif
             // ---- this wave finishes accumulator registers 8 ps + 2 g + {0, 1} of its channel half
 #pragma unroll
             for (int rr = 0; rr < 2; ++rr) {
@@ -512,6 +550,10 @@ __global__ __launch_bounds__(512, 2) void wino44_conv_kernel(F44Args a) {
             }
         }
         VF_STAMP(t_3);
+#ifdef VF_STAMPS44F
+        st_e[2] += t_p[0][0] - t_2; st_e[3] += t_p[0][1] - t_p[0][0]; st_e[4] += t_p[1][0] - t_p[0][1];
+        st_e[5] += t_p[1][1] - t_p[1][0]; st_e[6] += t_3 - t_p[1][1];
+#endif
         if (!has_next) {
 #ifdef VF_STAMPS44F
             st_loop += t_2 - t_1; st_epi += t_3 - t_2; st_tiles += 1;
@@ -521,9 +563,9 @@ __global__ __launch_bounds__(512, 2) void wino44_conv_kernel(F44Args a) {
         // ---- next tile: raw rows now (P is outside the exchange area), V(0) once every wave has taken its values out
         // of the exchange area
         VF_STAGE_ROWS(nx);
-        __syncthreads();
+        VF_LDS_BARRIER();
         VF_STAGE_V0();
-        __syncthreads();                                  // V(0) of the next tile complete
+        VF_LDS_BARRIER();                                 // V(0) of the next tile complete
 #ifdef VF_STAMPS44F
         {
             const unsigned long long t_4 = __builtin_amdgcn_s_memtime();
@@ -536,7 +578,9 @@ __global__ __launch_bounds__(512, 2) void wino44_conv_kernel(F44Args a) {
 #ifdef VF_STAMPS44F
     if (tid == 0 && !partial) {
         atomicAdd(&g_stamps44f[0], st_loop); atomicAdd(&g_stamps44f[1], st_epi); atomicAdd(&g_stamps44f[2], st_tiles);
-        atomicAdd(&g_stamps44f[3], st_e[0]); atomicAdd(&g_stamps44f[4], st_e[1]);
+        for (int i = 0; i < 7; ++i) atomicAdd(&g_stamps44f[3 + i], st_e[i]);
+        atomicAdd(&g_stamps44f[10], __builtin_amdgcn_s_memtime() - ct_0);            // shader clocks ...
+        atomicAdd(&g_stamps44f[11], __builtin_amdgcn_s_memrealtime() - rt_0);        // ... per 100 MHz ticks
     }
 #endif
 #undef VF_STAMP
@@ -545,13 +589,10 @@ __global__ __launch_bounds__(512, 2) void wino44_conv_kernel(F44Args a) {
 #undef VF_XLOAD
 #undef VF_XST1
 #undef VF_XSTORE
-#undef VF_XZ1
-#undef VF_XZERO
 #undef VF_SID
 #undef VF_SROW
 #undef VF_SCG
 #undef VF_SUY
-#undef VF_SOK
 #undef VF_STAGE_ROWS
 #undef VF_STAGE_V0
 #undef VF_SLICE
@@ -684,8 +725,8 @@ __global__ __launch_bounds__(256) void wino44_fixup_kernel(F44Args a, int ntail)
 
 inline int f44_groups(int S, int H, int W) { return S * ((H / 4) * (W / 4) / FTT); }
 
-template <int LOGW, int MODE>
-int launch_f44(F44Args a, size_t ws_floats, hipStream_t st) {
+template <int LOGW, int MODE, bool RAGGED>
+int launch_f44r(F44Args a, size_t ws_floats, hipStream_t st) {
     using G = FGeo<LOGW, MODE>;
     const int T = G::groups(a.S) * (a.CoutP / FCO);
     wino_tail_plan(T, a.CinP / FCK, &a.nfull, &a.tail_split);
@@ -696,10 +737,15 @@ int launch_f44(F44Args a, size_t ws_floats, hipStream_t st) {
     }
     const int nt = T - a.nfull;
     a.npers = a.nfull < F44_PERSIST ? a.nfull : F44_PERSIST;
-    hipLaunchKernelGGL((wino44_conv_kernel<LOGW, MODE>), dim3(a.npers + nt * a.tail_split), dim3(512), 0, st, a);
+    hipLaunchKernelGGL((wino44_conv_kernel<LOGW, MODE, RAGGED>), dim3(a.npers + nt * a.tail_split), dim3(512), 0, st, a);
     if (nt > 0)
         hipLaunchKernelGGL((wino44_fixup_kernel<LOGW>), dim3((nt * FCO * FTT * 4 + 255) / 256), dim3(256), 0, st, a, nt);
     VF_RETURN_LAST_ERROR();
+}
+
+template <int LOGW, int MODE>
+int launch_f44(F44Args a, size_t ws_floats, hipStream_t st) {
+    return (a.Cin & (FCK - 1)) ? launch_f44r<LOGW, MODE, true>(a, ws_floats, st) : launch_f44r<LOGW, MODE, false>(a, ws_floats, st);
 }
 
 }  // namespace
