@@ -11,7 +11,7 @@ from view_fusion_amd import ops, train  # noqa: E402
 
 dev = torch.device("cuda:0")
 model = train.build_model(device="cuda:0")
-tr = train.Trainer(model)
+tr = train.Trainer(model, graph=False)
 import sys as _s
 B = int(_s.argv[1]) if len(_s.argv) > 1 else 16
 batch = train.synthetic_batch(B, 6, 64, dev)

@@ -43,6 +43,7 @@ for Cin, Cout, H in SHAPES:
     loop, epi, tiles = v[0], v[1], v[2]
     nch = (Cin + 7) // 8
     print(f"Cin {Cin:3d} Cout {Cout:3d} H {H:2d}: {e0.elapsed_time(e1) / 10 * 1e3:7.1f} us/launch | whole tiles/launch {tiles / 10:6.0f}"
-          f" | cycles per tile: loop {loop / tiles:6.0f} ({loop / tiles / nch:5.0f}/chunk, MFMA issue 4608)  epilogue+next-tile staging {epi / tiles:6.0f}"
-          f" = columns+publish 0 {v[5] / tiles:5.0f} | barrier {v[6] / tiles:5.0f} | finish 0 + columns+publish 1 {v[7] / tiles:5.0f} | loads+barrier {v[8] / tiles:5.0f}"
-          f" | finish 1 {v[9] / tiles:5.0f} | stage next tile {v[4] / tiles:5.0f} | in-kernel clock {v[10] / max(v[11], 1) * 0.1:.2f} GHz", flush=True)
+          f" | cycles per tile: loop {loop / tiles:6.0f} ({loop / tiles / nch:5.0f}/chunk, MFMA issue 4608)  epilogue incl. next-tile staging {epi / tiles:6.0f}"
+          f" = loads + publish 0 {v[5] / tiles:5.0f} | publish 1 + finish 0 {v[6] / tiles:5.0f} | publish 2 + finish 1 {v[7] / tiles:5.0f}"
+          f" | publish 3 + finish 2 + stage rows {v[8] / tiles:5.0f} | finish 3 + V(0) {v[9] / tiles:5.0f} (each up to its barrier)"
+          f" | in-kernel clock {v[10] / max(v[11], 1) * 0.1:.2f} GHz", flush=True)

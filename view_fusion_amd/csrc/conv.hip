@@ -83,10 +83,16 @@ struct ConvArgs {
 };
 
 // Global -> register load of one float4 of the input patch (zero outside the image / tensor).
-template <class G, int MODE>
+// SAFE (1x1 convs whose channel counts fill every 32-channel chunk and whose views fill every tile: the host checks):
+// every element of the patch exists, the load is UNCONDITIONAL.  A load behind a (per-lane) condition is a branch
+// around it, the compiler then no longer knows how many requests are in flight and its s_waitcnt before the LDS stores
+// of the chunk also waits for the youngest ones: 7 % on the 1x1 family (round 4, tools/conv1x1_table.py).
+template <class G, int MODE, bool SAFE = false>
 __device__ __forceinline__ float4 load_patch4(const float* __restrict__ x, int S, int Cin, int s, int ci,
                                               int r0, int pr, int q) {
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (SAFE && MODE == 0 && G::PAD == 0)
+        return *reinterpret_cast<const float4*>(x + ((size_t)s * Cin + ci) * (size_t)(G::SH * G::SW) + (r0 + pr) * G::SW + 4 * q);
     if (s >= S || ci >= Cin) return v;
     const size_t plane = ((size_t)s * Cin + ci) * (size_t)(G::SH * G::SW);
     if (MODE == 0) {
@@ -111,7 +117,7 @@ __device__ __forceinline__ float4 load_patch4(const float* __restrict__ x, int S
 // NCO > 1 (1x1 convs): the workgroup covers NCO consecutive 64-channel weight tiles, so the activation tile
 // is staged once for 64*NCO output channels -- a 64-channel workgroup of a 1x1 conv needs ~12 B/clk of
 // L2->LDS traffic per CU at full MFMA rate, which is the load path's limit.
-template <int KS, int LOGW, int MODE, int NPT, int NCO = 1>
+template <int KS, int LOGW, int MODE, int NPT, int NCO = 1, bool SAFE = false>
 __global__ __launch_bounds__(256, (KS == 1 && NPT == 1 && NCO == 1) ? 5 : 1) void conv_mfma_kernel(ConvArgs a) {
     constexpr int TPIX = 64 * NPT;            // each wave: 32 channels x (32*NPT) pixels
     using G = Geo<KS, LOGW, MODE, TPIX>;
@@ -179,10 +185,10 @@ __global__ __launch_bounds__(256, (KS == 1 && NPT == 1 && NCO == 1) ? 5 : 1) voi
         const int im = t2 % G::IM, ci = t2 / G::IM;
         if (KS == 1 && a.x2) {                                    // concatenated input: chunk-uniform source
             const bool second = c0 >= a.C1;
-            return load_patch4<G, MODE>(second ? a.x2 : a.x, a.S, second ? a.Cin - a.C1 : a.C1, s0 + im,
-                                        second ? c0 - a.C1 + ci : c0 + ci, r0, pr, q);
+            return load_patch4<G, MODE, SAFE>(second ? a.x2 : a.x, a.S, second ? a.Cin - a.C1 : a.C1, s0 + im,
+                                              second ? c0 - a.C1 + ci : c0 + ci, r0, pr, q);
         }
-        return load_patch4<G, MODE>(a.x, a.S, a.Cin, s0 + im, c0 + ci, r0, pr, q);
+        return load_patch4<G, MODE, SAFE>(a.x, a.S, a.Cin, s0 + im, c0 + ci, r0, pr, q);
     };
     auto store_x = [&](int e, const float4& v) {
         const int q = e % G::Q;
@@ -1029,7 +1035,13 @@ int launch_conv_npt(ConvArgs a, hipStream_t st, long ws_floats) {
     if (a.ws == nullptr) ks = 1;
     while (ks > 1 && (size_t)ks * out_floats > (size_t)ws_floats) --ks;
     a.ksplit = ks;
-    hipLaunchKernelGGL((conv_mfma_kernel<KS, LOGW, MODE, NPT, NCO>), dim3(nblk * ks), dim3(256), 0, st, a);
+    using G = Geo<KS, LOGW, MODE, 64 * NPT>;
+    // every patch element exists (see load_patch4): whole 32-channel chunks from either source, whole view groups
+    const bool safe = KS == 1 && a.Cin % 32 == 0 && (!a.x2 || a.C1 % 32 == 0) && (G::IM == 1 || a.S % G::IM == 0);
+    if (KS == 1 && safe)
+        hipLaunchKernelGGL((conv_mfma_kernel<KS, LOGW, MODE, NPT, NCO, KS == 1>), dim3(nblk * ks), dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL((conv_mfma_kernel<KS, LOGW, MODE, NPT, NCO, false>), dim3(nblk * ks), dim3(256), 0, st, a);
     bool gn_done = false;
     if (ks > 1) {
         const size_t n4 = out_floats / 4;

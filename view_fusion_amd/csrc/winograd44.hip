@@ -205,9 +205,16 @@ __global__ __launch_bounds__(512, 2) void wino44_wgrad_kernel(W44Args a) {
     };
     // (the opaque copies keep base and offset apart until instruction selection: SGPR base + zero-extended VGPR offset)
 #define VF_ROW_OUT(K, ROW) (((K).top && (ROW) == 0) || ((K).bot && (ROW) == NR - 1))      /* scalar */
+    // Every load of the chunk loop is issued UNCONDITIONALLY (round 4): a load inside a branch costs the compiler its
+    // count of the requests in flight, and every later s_waitcnt then also waits for the youngest ones (measured on the
+    // F(4x4) forward kernel: 670 cycles per chunk).  A strip row outside the image is read from its neighbour row inside
+    // (valid memory, scalar base shift) and replaced by zeros at the store; a halo pixel beyond the left / right image
+    // border is read one pixel further in (per-lane offset select) and zeroed at the store.
 #define VF_XLOAD1(K, I, R)                                                                                \
-    if (xrow[I] >= 0 && !VF_ROW_OUT(K, xrow[I])) {                                                        \
+    if (xrow[I] >= 0) {                                                                                   \
         const char* b_ = (K).xb;                                                                          \
+        if ((K).top && xrow[I] == 0) b_ += (MODE == 2 ? 4 * SW : 4 * W);                                  \
+        if ((K).bot && xrow[I] == NR - 1) b_ -= (MODE == 2 ? 4 * SW : 4 * W);                             \
         unsigned& o_ = xoffb[I];                                                                          \
         asm("" : "+s"(b_), "+v"(o_));                                                                     \
         if (MODE == 2) {                                                                                  \
@@ -217,15 +224,17 @@ __global__ __launch_bounds__(512, 2) void wino44_wgrad_kernel(W44Args a) {
             R = *(const VF_G1 f32x4*)((const VF_G1 char*)b_ + o_);                                        \
         }                                                                                                 \
     }
-    // (a left / right halo pixel at the image border is never requested: it may lie outside the tensor)
 #define VF_HLOAD1(K, I, R)                                                                                \
-    if (HALO && hrow[I] >= 0 && !VF_ROW_OUT(K, hrow[I])) {                                                \
-        if (VF_LANES((K).left ? ODD_LANES : ((K).right ? EVEN_LANES : ~0ull))) {                          \
-            const char* b_ = (K).xb - 4;                                                                  \
-            unsigned& o_ = hoffb[I];                                                                      \
-            asm("" : "+s"(b_), "+v"(o_));                                                                 \
-            R = *(const VF_G1 float*)((const VF_G1 char*)b_ + o_);                                        \
-        }                                                                                                 \
+    if (HALO && hrow[I] >= 0) {                                                                           \
+        const char* b_ = (K).xb - 4;                                                                      \
+        if ((K).top && hrow[I] == 0) b_ += (MODE == 2 ? 4 * SW : 4 * W);                                  \
+        if ((K).bot && hrow[I] == NR - 1) b_ -= (MODE == 2 ? 4 * SW : 4 * W);                             \
+        /* lanes whose pixel lies beyond the image border read their neighbour inside (+- one pixel) */    \
+        unsigned o_ = hoffb[I];                                                                           \
+        if ((K).left) o_ += VF_LANES(EVEN_LANES) ? 4u : 0u;                                               \
+        if ((K).right) o_ -= VF_LANES(ODD_LANES) ? 4u : 0u;                                               \
+        asm("" : "+s"(b_), "+v"(o_));                                                                     \
+        R = *(const VF_G1 float*)((const VF_G1 char*)b_ + o_);                                            \
     }
 #define VF_LOAD_X(K, SET)                                                                                 \
     {                                                                                                     \
@@ -246,11 +255,8 @@ __global__ __launch_bounds__(512, 2) void wino44_wgrad_kernel(W44Args a) {
 #define VF_HSTORE1(K, BUF, I, R)                                                                          \
     if (HALO && hrow[I] >= 0) {                                                                           \
         float* d_ = Xl + (BUF) * XSZ + hsl[I];                                                            \
-        if (VF_ROW_OUT(K, hrow[I])) d_[0] = 0.f;                                                          \
-        else {                                                                                            \
-            d_[0] = R;                                                                                    \
-            if (VF_LANES((K).left ? EVEN_LANES : ((K).right ? ODD_LANES : 0ull))) d_[0] = 0.f;            \
-        }                                                                                                 \
+        const mask_t zm_ = VF_ROW_OUT(K, hrow[I]) ? ~0ull : ((K).left ? EVEN_LANES : ((K).right ? ODD_LANES : 0ull)); \
+        d_[0] = VF_LANES(zm_) ? 0.f : R;                                                                  \
     }
 #define VF_STORE_X(K, BUF, SET)                       /* K: the chunk the registers hold */                  \
     {                                                                                                     \

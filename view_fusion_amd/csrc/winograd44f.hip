@@ -295,7 +295,7 @@ __global__ __launch_bounds__(512, 2) void wino44_conv_kernel(F44Args a) {
 
 #ifdef VF_STAMPS44F
     const unsigned long long rt_0 = __builtin_amdgcn_s_memrealtime(), ct_0 = __builtin_amdgcn_s_memtime();
-    unsigned long long st_loop = 0, st_epi = 0, st_tiles = 0, st_e[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_p[2][3];
+    unsigned long long st_loop = 0, st_epi = 0, st_tiles = 0, st_e[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_p[5];
 #define VF_STAMP(V) const unsigned long long V = __builtin_amdgcn_s_memtime()
 #else
 #define VF_STAMP(V)
@@ -445,55 +445,69 @@ __global__ __launch_bounds__(512, 2) void wino44_conv_kernel(F44Args a) {
         // ---- output transform.  Columns (A4^T = [[1,1,1,1,1,0],[0,1,-1,2,-2,0],[0,1,1,4,4,0],[0,1,-1,8,-8,1]]) in
         // registers: the full row M[0..5] = acc[0..5] gives T[0..3]; the half row acc[6..8] gives the three values its
         // partner needs: cols 0-2: (m0 + m1 + m2, m1 - m2, m1 + m2), cols 3-5: (m3 + m4, m3 - m4, m5).  Rows (the same
-        // A4^T) after the exchange.  Two passes of eight accumulator registers (the exchange area holds one).
+        // A4^T) after the exchange through LDS.  FOUR passes of four accumulator registers through TWO exchange buffers:
+        // while the waves publish pass k + 1 they finish pass k (LDS reads, row transform, operands, output stores), so
+        // LDS writes, LDS reads, arithmetic and stores of different waves overlap and every phase has ONE barrier:
+        //   publish 0 | publish 1, finish 0 | publish 2, finish 1 | publish 3, finish 2, stage the next tile's rows |
+        //   finish 3, V(0) of the next tile (its slot overlays exchange buffer 0 only, free since the previous barrier)
+        // Wave (cw, g) finishes register 4 k + g of its channel half in pass k: channel co0 + 32 cw + 8 k + 4 lh + g.
         const bool jh = wg_ & 1;                             // (uniform) which half of the shared row
+        constexpr int XB = 8 * 7 * 4 * 64;                   // floats of one exchange buffer: [wave 8][value 7][reg 4][lane 64]
+        static_assert(2 * XB <= XCH && VSZ <= XB, "exchange buffers");
+        // epilogue operands of this lane's four channels: requested now, used from the second phase on
+        const int cob = co0 + cw * 32 + 4 * lh_e + wg_;      // + 8 k
+        float ebias[4];
 #pragma unroll
-        for (int ps = 0; ps < 2; ++ps) {
-            if (ps == 1) VF_LDS_BARRIER();                   // pass 0's values have been read
-            float* xo = xch + (size_t)(wid * 7) * (8 * 64) + lane_e;
+        for (int k = 0; k < 4; ++k) ebias[k] = 0.f;
+        if (!partial) {
+            if (a.bias) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {                    // register pairs (8 ps + 2 k, + 1)
-                const int r = 8 * ps + 2 * k;
-                const f32x2 m0 = (f32x2){acc[0][r], acc[0][r + 1]}, m1 = (f32x2){acc[1][r], acc[1][r + 1]};
-                const f32x2 m2 = (f32x2){acc[2][r], acc[2][r + 1]}, m3 = (f32x2){acc[3][r], acc[3][r + 1]};
-                const f32x2 m4 = (f32x2){acc[4][r], acc[4][r + 1]}, m5 = (f32x2){acc[5][r], acc[5][r + 1]};
-                const f32x2 s12 = pk_add(m1, m2), d12 = pk_sub(m1, m2), s34 = pk_add(m3, m4), d34 = pk_sub(m3, m4);
-                const f32x2 T0 = pk_add(pk_add(m0, s12), s34);
-                const f32x2 T1 = pk_fmak<2>(d34, d12);
-                const f32x2 T2 = pk_fmak<4>(s34, s12);
-                const f32x2 T3 = pk_add(pk_fmak<8>(d34, d12), m5);
-                const f32x2 h0 = (f32x2){acc[6][r], acc[6][r + 1]}, h1 = (f32x2){acc[7][r], acc[7][r + 1]};
-                const f32x2 h2 = (f32x2){acc[8][r], acc[8][r + 1]};
-                f32x2 H0, H1, H2;
-                if (jh) {                                    // cols 3-5: (m3 + m4, m3 - m4, m5)
-                    H0 = pk_add(h0, h1); H1 = pk_sub(h0, h1); H2 = h2;
-                } else {                                     // cols 0-2: (m0 + (m1 + m2), m1 - m2, m1 + m2)
-                    H2 = pk_add(h1, h2); H1 = pk_sub(h1, h2); H0 = pk_add(h0, H2);
-                }
-                xo[(0 * 8 + 2 * k) * 64] = T0.x; xo[(0 * 8 + 2 * k + 1) * 64] = T0.y;
-                xo[(1 * 8 + 2 * k) * 64] = T1.x; xo[(1 * 8 + 2 * k + 1) * 64] = T1.y;
-                xo[(2 * 8 + 2 * k) * 64] = T2.x; xo[(2 * 8 + 2 * k + 1) * 64] = T2.y;
-                xo[(3 * 8 + 2 * k) * 64] = T3.x; xo[(3 * 8 + 2 * k + 1) * 64] = T3.y;
-                xo[(4 * 8 + 2 * k) * 64] = H0.x; xo[(4 * 8 + 2 * k + 1) * 64] = H0.y;
-                xo[(5 * 8 + 2 * k) * 64] = H1.x; xo[(5 * 8 + 2 * k + 1) * 64] = H1.y;
-                xo[(6 * 8 + 2 * k) * 64] = H2.x; xo[(6 * 8 + 2 * k + 1) * 64] = H2.y;
+                for (int k = 0; k < 4; ++k) ebias[k] = a.bias[min(cob + 8 * k, a.Cout - 1)];
             }
-#ifdef VF_STAMPS44F
-            t_p[ps][0] = __builtin_amdgcn_s_memtime();
-#endif
-            VF_LDS_BARRIER();
-#ifdef VF_STAMPS44F
-            t_p[ps][1] = __builtin_amdgcn_s_memtime();
-#endif
-            // ---- this wave finishes accumulator registers 8 ps + 2 g + {0, 1} of its channel half
+            if (a.vbias) {
 #pragma unroll
-            for (int rr = 0; rr < 2; ++rr) {
-                const int r8 = 2 * wg_ + rr;                                  // register of this pass
-                const int v16 = 8 * ps + r8;
-                const int co = co0 + cw * 32 + 8 * (v16 >> 2) + 4 * lh_e + (v16 & 3);
-                const float* xi = xch + (size_t)(cw * 7) * (8 * 64) + r8 * 64 + lane_e;
-                // wave (cw, g') sits at slot 2 g' + cw: stride 2 * 7 * 8 * 64 floats between slice groups
-                constexpr int GS = 2 * 7 * 8 * 64, VS = 8 * 64;
+                for (int k = 0; k < 4; ++k) ebias[k] += a.vbias[(size_t)s * a.Cout + min(cob + 8 * k, a.Cout - 1)];
+            }
+        }
+        float4 er[4];                                        // residual rows of the pass that is finished NEXT phase
+#pragma unroll
+        for (int y = 0; y < 4; ++y) er[y] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int ph = 0; ph < 5; ++ph) {
+            if (ph < 4) {                                    // ---- publish pass ph into buffer ph & 1
+                float* xo = xch + (ph & 1) * XB + (size_t)(wid * 7) * (4 * 64) + lane_e;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {                // register pairs (4 ph + 2 k, + 1)
+                    const int r = 4 * ph + 2 * k;
+                    const f32x2 m0 = (f32x2){acc[0][r], acc[0][r + 1]}, m1 = (f32x2){acc[1][r], acc[1][r + 1]};
+                    const f32x2 m2 = (f32x2){acc[2][r], acc[2][r + 1]}, m3 = (f32x2){acc[3][r], acc[3][r + 1]};
+                    const f32x2 m4 = (f32x2){acc[4][r], acc[4][r + 1]}, m5 = (f32x2){acc[5][r], acc[5][r + 1]};
+                    const f32x2 s12 = pk_add(m1, m2), d12 = pk_sub(m1, m2), s34 = pk_add(m3, m4), d34 = pk_sub(m3, m4);
+                    const f32x2 T0 = pk_add(pk_add(m0, s12), s34);
+                    const f32x2 T1 = pk_fmak<2>(d34, d12);
+                    const f32x2 T2 = pk_fmak<4>(s34, s12);
+                    const f32x2 T3 = pk_add(pk_fmak<8>(d34, d12), m5);
+                    const f32x2 h0 = (f32x2){acc[6][r], acc[6][r + 1]}, h1 = (f32x2){acc[7][r], acc[7][r + 1]};
+                    const f32x2 h2 = (f32x2){acc[8][r], acc[8][r + 1]};
+                    f32x2 H0, H1, H2;
+                    if (jh) {                                // cols 3-5: (m3 + m4, m3 - m4, m5)
+                        H0 = pk_add(h0, h1); H1 = pk_sub(h0, h1); H2 = h2;
+                    } else {                                 // cols 0-2: (m0 + (m1 + m2), m1 - m2, m1 + m2)
+                        H2 = pk_add(h1, h2); H1 = pk_sub(h1, h2); H0 = pk_add(h0, H2);
+                    }
+                    xo[(0 * 4 + 2 * k) * 64] = T0.x; xo[(0 * 4 + 2 * k + 1) * 64] = T0.y;
+                    xo[(1 * 4 + 2 * k) * 64] = T1.x; xo[(1 * 4 + 2 * k + 1) * 64] = T1.y;
+                    xo[(2 * 4 + 2 * k) * 64] = T2.x; xo[(2 * 4 + 2 * k + 1) * 64] = T2.y;
+                    xo[(3 * 4 + 2 * k) * 64] = T3.x; xo[(3 * 4 + 2 * k + 1) * 64] = T3.y;
+                    xo[(4 * 4 + 2 * k) * 64] = H0.x; xo[(4 * 4 + 2 * k + 1) * 64] = H0.y;
+                    xo[(5 * 4 + 2 * k) * 64] = H1.x; xo[(5 * 4 + 2 * k + 1) * 64] = H1.y;
+                    xo[(6 * 4 + 2 * k) * 64] = H2.x; xo[(6 * 4 + 2 * k + 1) * 64] = H2.y;
+                }
+            }
+            if (ph > 0) {                                    // ---- finish pass ph - 1 from buffer (ph - 1) & 1
+                constexpr int GS = 2 * 7 * 4 * 64, VS = 4 * 64;      // stride between slice groups (waves 2 g' + cw) / values
+                const int co = cob + 8 * (ph - 1);
+                const float* xi = xch + ((ph - 1) & 1) * XB + (size_t)(cw * 7) * (4 * 64) + wg_ * 64 + lane_e;
                 float T[6][4];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
@@ -524,23 +538,14 @@ __global__ __launch_bounds__(512, 2) void wino44_conv_kernel(F44Args a) {
                     Y[2][c] = __builtin_fmaf(4.f, S34, S12);
                     Y[3][c] = __builtin_fmaf(8.f, D34, D12) + T[5][c];
                 }
-                if (partial) {                                   // raw partial tile: ws[part][co 64][tile 32][4x4]
+                if (partial) {                               // raw partial tile: ws[part][co 64][tile 32][4x4]
                     float* w16 = a.ws + (((size_t)tail_id * FCO + (co - co0)) * FTT + li_e) * 16;
 #pragma unroll
                     for (int y = 0; y < 4; ++y)
                         *reinterpret_cast<float4*>(w16 + 4 * y) = make_float4(Y[y][0], Y[y][1], Y[y][2], Y[y][3]);
                 } else if (co < a.Cout) {
-                    float bb = 0.f;
-                    if (a.bias) bb += a.bias[co];
-                    if (a.vbias) bb += a.vbias[(size_t)s * a.Cout + co];
+                    const float bb = ebias[ph - 1];
                     const size_t o = ((size_t)s * a.Cout + co) * G::HW + (size_t)orow * G::W + ocol;
-                    float4 er[4];
-#pragma unroll
-                    for (int y = 0; y < 4; ++y) er[y] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (a.res) {
-#pragma unroll
-                        for (int y = 0; y < 4; ++y) er[y] = *reinterpret_cast<const float4*>(a.res + o + y * G::W);
-                    }
 #pragma unroll
                     for (int y = 0; y < 4; ++y)
                         *reinterpret_cast<float4*>(a.y + o + y * G::W) =
@@ -548,30 +553,26 @@ __global__ __launch_bounds__(512, 2) void wino44_conv_kernel(F44Args a) {
                                         Y[y][3] + bb + er[y].w);
                 }
             }
+            if (ph < 4 && !partial && a.res) {               // residual rows of pass ph: used in the next phase
+                const int co = min(cob + 8 * ph, a.Cout - 1);
+                const size_t o = ((size_t)s * a.Cout + co) * G::HW + (size_t)orow * G::W + ocol;
+#pragma unroll
+                for (int y = 0; y < 4; ++y) er[y] = *reinterpret_cast<const float4*>(a.res + o + y * G::W);
+            }
+            if (ph == 3 && has_next) VF_STAGE_ROWS(nx);      // (P is outside the exchange area)
+            if (ph == 4 && has_next) VF_STAGE_V0();
+#ifdef VF_STAMPS44F
+            t_p[ph] = __builtin_amdgcn_s_memtime();
+#endif
+            if (ph < 4 || has_next) VF_LDS_BARRIER();
         }
         VF_STAMP(t_3);
 #ifdef VF_STAMPS44F
-        st_e[2] += t_p[0][0] - t_2; st_e[3] += t_p[0][1] - t_p[0][0]; st_e[4] += t_p[1][0] - t_p[0][1];
-        st_e[5] += t_p[1][1] - t_p[1][0]; st_e[6] += t_3 - t_p[1][1];
+        st_e[2] += t_p[0] - t_2; st_e[3] += t_p[1] - t_p[0]; st_e[4] += t_p[2] - t_p[1];
+        st_e[5] += t_p[3] - t_p[2]; st_e[6] += t_p[4] - t_p[3];
+        st_loop += t_2 - t_1; st_epi += t_3 - t_2; st_tiles += 1; st_e[0] += t_3 - t_2;
 #endif
-        if (!has_next) {
-#ifdef VF_STAMPS44F
-            st_loop += t_2 - t_1; st_epi += t_3 - t_2; st_tiles += 1;
-#endif
-            break;
-        }
-        // ---- next tile: raw rows now (P is outside the exchange area), V(0) once every wave has taken its values out
-        // of the exchange area
-        VF_STAGE_ROWS(nx);
-        VF_LDS_BARRIER();
-        VF_STAGE_V0();
-        VF_LDS_BARRIER();                                 // V(0) of the next tile complete
-#ifdef VF_STAMPS44F
-        {
-            const unsigned long long t_4 = __builtin_amdgcn_s_memtime();
-            st_loop += t_2 - t_1; st_epi += t_4 - t_2; st_tiles += 1; st_e[0] += t_3 - t_2; st_e[1] += t_4 - t_3;
-        }
-#endif
+        if (!has_next) break;
         cur = nx;
         lin = lin_next;
     }

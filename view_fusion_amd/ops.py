@@ -491,44 +491,70 @@ WINOGRAD_WGRAD = True     # weight gradients of those layers (plain stride-1 one
 
 
 WINOGRAD44 = os.environ.get("VF_WINO44", "1") == "1"     # F(4x4,3x3) forward / dgrad kernel on the large maps
-WINO44_MIN_TILES = int(os.environ.get("VF_WINO44_MIN_TILES", 256))
 FORCE_WINOGRAD44 = False  # tests: F(4x4) wherever the kernel supports the map
 
 
-def wino_kind(S, Cin, Cout, H, W, KS, m):
+# Cost model behind the choice between the two Winograd forward / dgrad kernels (shader cycles, measured on S = 96 with
+# tools/wino44_table.py / tools/wino44f_stamps.py, round 4): a workgroup tile costs (chunks + F) x CH cycles,
+#   nested F(2,3)xF(4,3): CH = 3340 per 8-channel chunk of a 256-pixel tile,  F = 4.2 chunk-times of prologue + epilogue
+#   F(4x4,3x3)          : CH = 5390 per chunk of a 512-pixel tile,            F = 4.7
+# the tiles run in rounds of 256 (one workgroup per CU); K-split tail parts additionally write and re-read their raw
+# partial outputs (64 / 128 KB per part, priced at 4 TB/s = 2000 bytes per cycle) and pay the fix-up launch.
+_WINO_COST = {1: (3340.0, 4.2, 64 * 32 * 8), 2: (5390.0, 4.7, 64 * 32 * 16)}
+
+
+def _wino_cycles(kind, S, Cin, Cout, H, W):
+    lib = _lib.load()
+    ch, F, part_floats = _WINO_COST[kind]
+    tiles = ctypes.c_int(0)
+    getattr(lib, "vf_wino_conv_fill_pct" if kind == 1 else "vf_wino44_conv_fill_pct")(S, Cin, Cout, H, W, ctypes.byref(tiles))
+    T = tiles.value
+    parts = getattr(lib, _WINO_ABI[kind][4])(S, Cin, Cout, H, W) // part_floats     # K-split tail parts (0: plain grid)
+    nch = (Cin + 7) // 8
+    if parts == 0:
+        return -(-T // 256) * (nch + F) * ch
+    ntail = T % 256
+    split = max(1, parts // max(ntail, 1))
+    cyc = (T // 256) * (nch + F) * ch + -(-parts // 256) * (-(-nch // split) + F) * ch
+    return cyc + parts * part_floats * 4 * 2.5 / 2000.0 + 8000.0     # partials written + read (+ output), fix-up launch
+
+
+def wino_kind(S, Cin, Cout, H, W, KS, m, train=None):
     """Which kernel runs the forward AND the dgrad pass of a conv layer (they share one packed-weight format):
     0 direct (conv.hip), 1 nested Winograd F(2,3)xF(4,3) (winograd24.hip), 2 Winograd F(4x4,3x3) (winograd44f.hip).
 
     F(4x4) executes 25 % fewer multiplies than the nested kernel but its workgroup tile is 64 channels x 512 pixels:
-    taken on the 32x32 / 64x64 maps when BOTH passes have at least one full round of tiles (256, one workgroup per
-    CU) and the tail plan keeps >= 65 % of the CUs busy.  The nested kernel runs ONE 256-pixel workgroup per CU: taken
-    when its tile count (after the K-split of the tail tiles) keeps >= 65 % of the CUs busy; small batches (sampler)
-    stay on the direct kernel (+ split-K)."""
+    on the 32x32 / 64x64 maps it is taken when the cost model above prices forward + dgrad (`train`; forward alone
+    otherwise; default: whether autograd is recording) below the nested kernel's -- a grid of 1.5 rounds with a short K (128 -> 128 at 32x32, S = 96) is the case
+    it loses.  The nested kernel runs ONE 256-pixel workgroup per CU: taken when its tile count (after the K-split of
+    the tail tiles) keeps >= 65 % of the CUs busy; small batches (sampler) stay on the direct kernel (+ split-K)."""
     if not WINOGRAD or KS != 3 or m not in (0, 2):
         return 0
     lib = _lib.load()
+    nested = 0
+    if lib.vf_wino_supported(H, W, m):
+        if FORCE_WINOGRAD:
+            nested = 1
+        else:
+            tiles = ctypes.c_int(0)
+            fill = lib.vf_wino_conv_fill_pct(S, Cin, Cout, H, W, ctypes.byref(tiles))
+            nested = 1 if (tiles.value >= WINO_MIN_TILES and fill >= WINO_MIN_FILL) else 0
     if WINOGRAD44 and lib.vf_wino44_supported(H, W, m):
         if FORCE_WINOGRAD44:
             return 2
-        if not FORCE_WINOGRAD:
-            ok = True
-            for ci, co in ((Cin, Cout), (Cout, Cin)):
-                tiles = ctypes.c_int(0)
-                fill = lib.vf_wino44_conv_fill_pct(S, ci, co, H, W, ctypes.byref(tiles))
-                ok = ok and tiles.value >= WINO44_MIN_TILES and fill >= WINO_MIN_FILL
-            if ok:
+        if nested and not FORCE_WINOGRAD:
+            if train is None:
+                train = torch.is_grad_enabled()
+            dirs = ((Cin, Cout), (Cout, Cin)) if train else ((Cin, Cout),)
+            c1 = sum(_wino_cycles(1, S, ci, co, H, W) for ci, co in dirs)
+            c2 = sum(_wino_cycles(2, S, ci, co, H, W) for ci, co in dirs)
+            if c2 < c1:
                 return 2
-    if not lib.vf_wino_supported(H, W, m):
-        return 0
-    if FORCE_WINOGRAD:
-        return 1
-    tiles = ctypes.c_int(0)
-    fill = lib.vf_wino_conv_fill_pct(S, Cin, Cout, H, W, ctypes.byref(tiles))
-    return 1 if (tiles.value >= WINO_MIN_TILES and fill >= WINO_MIN_FILL) else 0
+    return nested
 
 
-def use_winograd(S, Cin, Cout, H, W, KS, m):
-    return wino_kind(S, Cin, Cout, H, W, KS, m) != 0
+def use_winograd(S, Cin, Cout, H, W, KS, m, train=None):
+    return wino_kind(S, Cin, Cout, H, W, KS, m, train) != 0
 
 
 def use_winograd_wgrad(S, Cin, Cout, H, W, KS, m):
@@ -585,7 +611,8 @@ def pack_all(root, S=None):
         geom = getattr(l, "_vf_geom", None)
         if geom is None or S is None:
             return 0
-        return wino_kind(S, l.weight.shape[1], l.weight.shape[0], geom[0], geom[0], l.weight.shape[2], _MODES[geom[1]])
+        return wino_kind(S, l.weight.shape[1], l.weight.shape[0], geom[0], geom[0], l.weight.shape[2], _MODES[geom[1]],
+                         train=True)
 
     key = tuple((l.weight.data_ptr(), kind_of(l)) for l in layers)
     if plan is None or plan[1] != key:
@@ -713,7 +740,7 @@ class _Conv2dFn(torch.autograd.Function):
         flops = 2.0 * S * Cout * Cin * KS * KS * H * W
         # algorithmic HBM bytes: input, output (+ residual) and the weights, each once
         nb = 4.0 * (x.numel() + y.numel() + weight.numel() + (residual.numel() if residual is not None else 0))
-        wino = wino_kind(S, Cin, Cout, H, W, KS, m)
+        wino = wino_kind(S, Cin, Cout, H, W, KS, m, train=bool(training))   # (grad mode is off inside Function.forward)
         ctx.b3 = _use_b3(KS, m, H * W)
         if ctx.b3:
             wf, wb = _packed_b3(layer, force=training)
@@ -943,7 +970,7 @@ def conv2d_gn(x, layer, gn, groups, silu, view_bias=None, residual=None, mode="s
     m = _MODES[mode]
     H, W = (Hi // 2, Wi // 2) if m == 1 else ((Hi * 2, Wi * 2) if m == 2 else (Hi, Wi))
     lib = _lib.load()
-    fused = (not torch.is_grad_enabled() and not use_winograd(S, Cin, Cout, H, W, KS, m) and not _use_b3(KS, m, H * W)
+    fused = (not torch.is_grad_enabled() and not use_winograd(S, Cin, Cout, H, W, KS, m, False) and not _use_b3(KS, m, H * W)
              and not use_small_conv(S, Cin, Cout, H, W, KS, m)      # (one conv launch + the GroupNorm launch instead)
              and lib.vf_conv_fwd_ws_floats(S, Cin, Cout, H, W, KS) > 0)
     if not fused:
