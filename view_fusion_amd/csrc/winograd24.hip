@@ -88,7 +88,10 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(WinoArgs a) {
     constexpr int NXR = (NX4 + NT_ - 1) / NT_;           // 1-2 per thread (tail predicated)
     constexpr int UCH = NSL * WTCO * WCK;                // floats of one (co tile, chunk) block of U
     constexpr int VSZ = NSL * WCK * WTT;
-    constexpr int PSZ = WCK * G::PS;
+    // (each raw-row buffer ends in a 512-byte scratch row: the LDS slot of an element that has no place in the patch -- a row
+    // outside the image, the unused tail of the per-thread element list -- so that every store of the loop is unconditional)
+    constexpr int PSZ = WCK * G::PS + 128;
+    constexpr int XDUMMY = WCK * G::PS;
     constexpr int XCH = 2 * 4 * 64 * 64;                 // epilogue exchange: [cw][row wave][value 64][lane 64]
     constexpr int LDSF = 2 * PSZ + (2 * VSZ > XCH ? 2 * VSZ : XCH);
     static_assert(NXR <= 2, "raw-row staging assumes at most two float4 per thread");
@@ -121,7 +124,7 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(WinoArgs a) {
     int xlo[2], xci[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const int e = tid + i * NT_;
+        const int e = min(tid + i * NT_, NX4 - 1);
         const int t1 = e / G::Q;
         xci[i] = t1 / G::PH;
         xlo[i] = xci[i] * G::PS + (t1 % G::PH) * G::PW + 4 * (e % G::Q) + 4;
@@ -130,7 +133,9 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(WinoArgs a) {
     struct Tile {                                        // what changes from tile to tile and the chunk loop needs
         const char* ubase;                               // workgroup-uniform: U block of (co tile, first chunk)
         const char* xbase;                               // workgroup-uniform: first view of the tile
-        int xgo0, xgo1;                                  // this thread's source byte offsets at channel xci (negative: outside the image)
+        int xgo0, xgo1;                                  // this thread's source byte offsets at channel xci (always a valid address)
+        int xl0, xl1;                                    // ... and their LDS slots (the scratch row for elements outside the image)
+        bool z0, z1;                                     // the element's own slot must hold zeros (row outside the image)
     };
     auto tile_pos = [&](unsigned logical, int& s_, int& r0_, int& cot_) {
         cot_ = logical % ncot;
@@ -144,17 +149,26 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(WinoArgs a) {
         tile_pos(logical, ts, tr0, cot);
         t.ubase = reinterpret_cast<const char*>(a.u + ((size_t)cot * (a.CinP / WCK) + c0) * UCH);
         t.xbase = reinterpret_cast<const char*>(a.x + (size_t)ts * a.Cin * (G::SH * G::SW));
-        int go[2];
+        // Round 4: every load and LDS store of the chunk loop is UNCONDITIONAL (a load or store inside a branch costs the
+        // compiler its count of the requests in flight; measured on the F(4x4) kernel).  An element outside the
+        // image (or past the last view / the element list) reads the clamped row inside and lands in the scratch row.
+        int go[2], xl[2];
+        bool zz[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int e = tid + i * NT_;
+            const int e = min(tid + i * NT_, NX4 - 1);
             const int q = e % G::Q, t1 = e / G::Q;
             const int pr = t1 % G::PH;
             const int img = pr / G::RPI;
             const int uy = tr0 + pr % G::RPI - 1;
-            const bool ok = i < NXR && e < NX4 && ts + img < a.S && uy >= 0 && uy < G::H;
-            go[i] = ok ? 4 * ((img * a.Cin + xci[i]) * (G::SH * G::SW) + (MODE == 0 ? uy * G::SW + 4 * q : (uy >> 1) * G::SW + 2 * q)) : -1;
+            const bool in_list = i < NXR && tid + i * NT_ < NX4;
+            const bool ok = in_list && ts + img < a.S && uy >= 0 && uy < G::H;
+            const int uyc = min(max(uy, 0), G::H - 1), imgc = min(img, max(a.S - 1 - ts, 0));
+            go[i] = 4 * ((imgc * a.Cin + xci[i]) * (G::SH * G::SW) + (MODE == 0 ? uyc * G::SW + 4 * q : (uyc >> 1) * G::SW + 2 * q));
+            xl[i] = ok ? xlo[i] : XDUMMY + 4 * (tid & 31);
+            zz[i] = in_list && !ok;
         }
+        t.xl0 = xl[0]; t.xl1 = xl[1]; t.z0 = zz[0]; t.z1 = zz[1];
         t.xgo0 = go[0]; t.xgo1 = go[1];
         return t;
     };
@@ -170,12 +184,10 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(WinoArgs a) {
                                                                           // slices 6 wa .., rows cw*32 + li, k half lh
     auto fetch_x = [&](const Tile& t, int i, int c, float4& v) {
         const int go = i == 0 ? t.xgo0 : t.xgo1;
-        if (go >= 0) {
-            const unsigned off = (unsigned)(min((c0 + c) * WCK, xlim[i]) * (4 * G::SH * G::SW) + go);
-            const char* p = t.xbase + off;
-            if (MODE == 0) v = *reinterpret_cast<const float4*>(p);
-            else { const float2 h = *reinterpret_cast<const float2*>(p); v = make_float4(h.x, h.x, h.y, h.y); }
-        }
+        const unsigned off = (unsigned)(min((c0 + c) * WCK, xlim[i]) * (4 * G::SH * G::SW) + go);
+        const char* p = t.xbase + off;
+        if (MODE == 0) v = *reinterpret_cast<const float4*>(p);
+        else { const float2 h = *reinterpret_cast<const float2*>(p); v = make_float4(h.x, h.x, h.y, h.y); }
     };
 
     unsigned lin = partial ? 0u : blockIdx.x;           // linear id of the current whole tile
@@ -199,17 +211,17 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(WinoArgs a) {
 #define VF_XLOAD(T, C, R0, R1) { fetch_x((T), 0, (C), R0); if (NXR > 1) fetch_x((T), 1, (C), R1); }
 #define VF_XSTORE(T, BUF, R0, R1)                                                                       \
     {                                                                                                   \
-        if ((T).xgo0 >= 0) *reinterpret_cast<float4*>(Pl + (BUF) * PSZ + xlo[0]) = R0;                   \
-        if (NXR > 1 && (T).xgo1 >= 0) *reinterpret_cast<float4*>(Pl + (BUF) * PSZ + xlo[1]) = R1;        \
+        *reinterpret_cast<float4*>(Pl + (BUF) * PSZ + (T).xl0) = R0;                                     \
+        if (NXR > 1) *reinterpret_cast<float4*>(Pl + (BUF) * PSZ + (T).xl1) = R1;                        \
     }
     // rows of the tile that lie outside the image (or past the last view): zero in both raw-row buffers
 #define VF_XZERO(T)                                                                                     \
     {                                                                                                   \
         const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);                                              \
-        if ((T).xgo0 < 0 && tid < NX4) {                                                                \
+        if ((T).z0) {                                                                                   \
             *reinterpret_cast<float4*>(Pl + xlo[0]) = z4; *reinterpret_cast<float4*>(Pl + PSZ + xlo[0]) = z4; \
         }                                                                                               \
-        if (NXR > 1 && (T).xgo1 < 0 && tid + NT_ < NX4) {                                               \
+        if (NXR > 1 && (T).z1) {                                                                        \
             *reinterpret_cast<float4*>(Pl + xlo[1]) = z4; *reinterpret_cast<float4*>(Pl + PSZ + xlo[1]) = z4; \
         }                                                                                               \
     }
