@@ -6,6 +6,7 @@ Tolerance: fp32.  `rel` = max|a-b| / max|b|.  Contractions: 2e-5 forward / dgrad
 norm kernels 1e-5.
 """
 import math
+import os
 
 import numpy as np
 import pytest
@@ -98,6 +99,29 @@ def test_conv_fwd_bwd(dev, Cin, Cout, Hin, KS, mode, S, tol=2e-5):
     assert rel(layer.bias.grad, bgc) < 2e-5
     assert rel(vbg.grad, vbc.grad) < 2e-5
     assert rel(rg.grad, rc.grad) < 1e-6
+
+
+C11_CASES = [(192, 576, 16, 40), (576, 192, 16, 48), (128, 64, 64, 20), (64, 128, 64, 16), (320, 128, 32, 64),
+             (192, 192, 16, 96), (96, 160, 8, 600), (32, 64, 32, 70), (640, 320, 8, 351)]
+
+
+def test_conv1x1_training_size_kernel():
+    """The dedicated 1x1 kernel of csrc/conv1x1.hip (weights straight from global memory, 128 x 128 tiles) -- forward with
+    bias + per-view bias + residual and dgrad, incl. an odd number of 64-channel tiles (576 = 9, 160 -> 3, 320 = 5), a
+    Cout below one tile, 8x8 maps (a 128-pixel tile spans two views) and a pixel count that is no multiple of 128 (351
+    views of 8x8), plus the concatenated-input / split-output forms.  Its natural policy (deep K, even tile count, two
+    workgroups per CU) is what the full-size model tests run; here VF_CONV1X1_FORCE=1 routes every legal shape to it --
+    the library reads that variable once, so the cases run in a child process of their own."""
+    import subprocess
+    import sys
+    code = ("import sys, torch; sys.path.insert(0, %r); sys.path.insert(0, %r);"
+            "import test_gpu_kernels as t; dev = torch.device('cuda:0');"
+            "[t.test_conv_fwd_bwd(dev, ci, co, h, 1, 'same', s) for ci, co, h, s in t.C11_CASES];"
+            "[t.test_cat_free_decoder_ops(dev, *c) for c in [(64, 64, 64, 64, 12), (192, 128, 32, 128, 40), (128, 64, 16, 192, 80)]];"
+            "print('C11_OK')") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, VF_CONV1X1_FORCE="1"), capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and "C11_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
 @pytest.mark.parametrize("S", [1, 2, 5])

@@ -15,7 +15,8 @@ sys.path.insert(0, ROOT)
 so = os.path.join(ROOT, "build", "libvf_hip_stamps.so")
 if not os.path.exists(so):   # built here (no GPU needed) or on the box
     subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-DVF_CONV_STAMPS", "-I",
-                    os.path.join(ROOT, "include"), os.path.join(ROOT, "view_fusion_amd/csrc/conv.hip"), "-o", so],
+                    os.path.join(ROOT, "include"), os.path.join(ROOT, "view_fusion_amd/csrc/conv.hip"),
+                    os.path.join(ROOT, "view_fusion_amd/csrc/norm.hip"), "-o", so],
                    check=True)
 if len(sys.argv) < 5:
     sys.exit(0)

@@ -21,6 +21,7 @@
 //
 // Bound: fp32 matrix rate (157.3 TF), not HBM: AI of these layers is 144-960 flop/B.
 #include "common.h"
+#include "conv1x1.h"
 #include <cstdlib>
 
 namespace {
@@ -1208,6 +1209,14 @@ static int conv_fwd_impl(const float* x, const float* x2, int C1, const float* w
         a.gn_groups = gn->groups; a.gn_silu = gn->silu; a.gn_store_y = gn->store_y; a.gn_eps = gn->eps;
     }
     hipStream_t st = (hipStream_t)stream;
+    if (KS == 1 && !gn) {          // training-size grids: the dedicated 1x1 kernel (conv1x1.hip)
+        C11Args c;
+        c.x = x; c.x2 = x2; c.w = w_packed; c.bias = bias; c.vbias = view_bias; c.res = residual; c.y = y; c.y2 = y2;
+        c.S = S; c.Cin = Cin; c.Cout = Cout; c.C1 = C1; c.C1o = C1o; c.HW = H * W; c.hwsh = 2 * lw; c.npx = S * H * W;
+        c.nct = a.CoutP / TCO;
+        static const bool off = getenv("VF_CONV1X1_OLD") != nullptr;       // (tuning aid: the generic kernel)
+        if (!off && vfi_conv1x1_supported(c)) return vfi_conv1x1_launch(c, st);
+    }
 #define VF_CASE(KS_, LW_, M_) \
     if (KS == KS_ && lw == LW_ && mode == M_) return launch_conv<KS_, LW_, M_>(a, st, ws_floats);
     VF_CASE(3, 3, 0) VF_CASE(3, 4, 0) VF_CASE(3, 5, 0) VF_CASE(3, 6, 0) VF_CASE(3, 7, 0)
