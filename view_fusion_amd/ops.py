@@ -519,7 +519,25 @@ def _wino_cycles(kind, S, Cin, Cout, H, W):
     return cyc + parts * part_floats * 4 * 2.5 / 2000.0 + 8000.0     # partials written + read (+ output), fix-up launch
 
 
+_WINO_KIND_CACHE = {}
+
+
 def wino_kind(S, Cin, Cout, H, W, KS, m, train=None):
+    """Cached front of _wino_kind (the decision costs up to a dozen host calls into the library; an eager iteration asks
+    it twice per conv layer)."""
+    if train is None:
+        train = torch.is_grad_enabled()
+    key = (S, Cin, Cout, H, W, KS, m, bool(train), WINOGRAD, WINOGRAD44, FORCE_WINOGRAD, FORCE_WINOGRAD44, WINO_MIN_TILES,
+           WINO_MIN_FILL)
+    k = _WINO_KIND_CACHE.get(key)
+    if k is None:
+        if len(_WINO_KIND_CACHE) > 4096:
+            _WINO_KIND_CACHE.clear()
+        k = _WINO_KIND_CACHE[key] = _wino_kind(S, Cin, Cout, H, W, KS, m, train)
+    return k
+
+
+def _wino_kind(S, Cin, Cout, H, W, KS, m, train):
     """Which kernel runs the forward AND the dgrad pass of a conv layer (they share one packed-weight format):
     0 direct (conv.hip), 1 nested Winograd F(2,3)xF(4,3) (winograd24.hip), 2 Winograd F(4x4,3x3) (winograd44f.hip).
 
@@ -543,8 +561,6 @@ def wino_kind(S, Cin, Cout, H, W, KS, m, train=None):
         if FORCE_WINOGRAD44:
             return 2
         if nested and not FORCE_WINOGRAD:
-            if train is None:
-                train = torch.is_grad_enabled()
             dirs = ((Cin, Cout), (Cout, Cin)) if train else ((Cin, Cout),)
             c1 = sum(_wino_cycles(1, S, ci, co, H, W) for ci, co in dirs)
             c2 = sum(_wino_cycles(2, S, ci, co, H, W) for ci, co in dirs)
