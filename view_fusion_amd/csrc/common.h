@@ -120,6 +120,12 @@ __device__ __forceinline__ f32x2 pk_lo_pm_hi(f32x2 a, f32x2 b) {         // [a.x
     return d;
 }
 
+// An LDS-only workgroup barrier.  __syncthreads() is a workgroup-scope fence + barrier: the compiler drains the wave's
+// outstanding GLOBAL stores in front of it (s_waitcnt vmcnt(0); loads and stores retire through one in-order counter, so
+// younger loads wait too).  Where only LDS traffic has to be ordered -- the chunk loops and the LDS exchanges of the
+// epilogues, whose output stores are never read back by the workgroup -- that wait is thousands of cycles per tile.
+#define VF_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
 // A pointer the program knows to be wave-uniform, as an SGPR pair (for the saddr form of global loads).
 __device__ __forceinline__ const char* uniform_ptr(const void* p) {
     const unsigned long long v = (unsigned long long)p;

@@ -23,7 +23,6 @@ namespace {
 
 constexpr int XPS = 132;                 // LDS row stride of the activation image (128 pixels + 4: 16-byte aligned rows)
 constexpr int XSZ = 32 * XPS;            // floats of one activation buffer
-#define VF_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #define VF_G1 __attribute__((address_space(1)))
 
 __global__ __launch_bounds__(512, 4) void conv1x1_kernel(C11Args a) {

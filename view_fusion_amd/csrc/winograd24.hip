@@ -349,7 +349,7 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(WinoArgs a) {
                  { win_write(4, (PAR) ^ 1); win_write(5, (PAR) ^ 1); });                                 \
         VF_SLICE(C, FIRST, 3, bfB, { VF_BFRAG(bfA, PAR, 4); VF_BFRAG(bfC, PAR, 5); },                    \
                  VF_XSTORE(cur, PAR, xr0, xr1), (void)0);                                                \
-        __syncthreads();                                                                                 \
+        VF_LDS_BARRIER();                                                                                 \
         VF_SLICE(C, FIRST, 4, bfA, VF_XLOAD(cur, min((C) + 3, clast), xr0, xr1), (void)0, (void)0);      \
         VF_SLICE(C, FIRST, 5, bfC, VF_BFRAG(bfA, (PAR) ^ 1, 0), (void)0, (void)0);                       \
     }
@@ -445,7 +445,7 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(WinoArgs a) {
         for (int r = 0; r < 16; ++r)
 #pragma unroll
             for (int j = 0; j < 4; ++j) xch[(size_t)wa * (64 * 64) + (r * 4 + j) * 64 + lane_e] = part[r >> 1][j][r & 1];
-        __syncthreads();
+        VF_LDS_BARRIER();
         VF_STAMP(t_b);
         float o0[4][4], o1[4][4];                        // [rr][column]: output rows 0 / 1 of the 2x4 tile
 #pragma unroll
@@ -498,7 +498,7 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(WinoArgs a) {
         VF_STAMP(t_d);
         if (has_next) VF_STAGE_ROWS(nx);
         VF_STAMP(t_e);
-        __syncthreads();
+        VF_LDS_BARRIER();
         VF_STAMP(t_f);
         if (partial) {                                       // raw partial tile: ws[tail_id][co 64][tile 32][2x4]
 #pragma unroll
@@ -532,7 +532,7 @@ __global__ __launch_bounds__(512, 2) void wino_conv_kernel(WinoArgs a) {
         VF_STAMP(t_g);
         VF_STAGE_V0();
         VF_STAMP(t_h);
-        __syncthreads();                                  // V(0) of the next tile complete
+        VF_LDS_BARRIER();                                  // V(0) of the next tile complete
 #ifdef VF_STAMPS
         {
             const unsigned long long t_i = __builtin_amdgcn_s_memtime();

@@ -90,7 +90,6 @@ __device__ float g_f44_zero[16384];
 
 // An LDS-only workgroup barrier: __syncthreads() also drains the wave's outstanding GLOBAL stores (vmcnt), which in the
 // epilogue are the output rows just issued -- thousands of cycles; the exchange only needs the LDS traffic ordered.
-#define VF_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
 // RAGGED: Cin is no multiple of 8 (stem, dgrad of the head): the last chunk's channel offsets are clamped per lane.
 template <int LOGW, int MODE, bool RAGGED>
