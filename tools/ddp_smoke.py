@@ -21,15 +21,18 @@ def child(kind):
     sys.path.insert(0, ROOT)
     from view_fusion_amd import train
     torch.cuda.set_device(0)
+    eager = kind.endswith("-eager")
+    kind = kind.replace("-eager", "")
     if kind != "none":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ["VF_REDUCER"] = kind
         train.init_rccl_group(0, rank=0, world_size=1)
     model = train.build_model(device="cuda:0")
-    tr = train.Trainer(model, world=2 if kind != "none" else 1, local_rank=0)   # world=2 only selects the reducer
+    tr = train.Trainer(model, world=2 if kind != "none" else 1, local_rank=0,      # world=2 only selects the reducer
+                       graph=False if eager else None)
     batch = train.synthetic_batch(16, 6, 64, torch.device("cuda:0"))
-    for _ in range(3):
+    for _ in range(6):
         tr.step(batch)
     if tr.arena is not None:
         tr.arena.copied = 0
@@ -44,7 +47,8 @@ def child(kind):
     if tr.arena is not None:
         a = tr.arena
         extra = f" copied/step {a.copied / n:.0f} of {len(a.params)} segments {[(hi - lo) * 4 >> 20 for lo, hi in a.seg_range]} MiB"
-    print(f"reducer={kind:5s} {ms:.2f} ms/step loss {loss.item():.6f} param-checksum {chk:.9e}{extra}", flush=True)
+    kind = kind + ("-eager" if eager else "")
+    print(f"reducer={kind:11s} graph replays {tr.graph_steps:2d}  {ms:.2f} ms/step loss {loss.item():.6f} param-checksum {chk:.9e}{extra}", flush=True)
     if kind != "none":
         dist.destroy_process_group()
 
@@ -53,5 +57,5 @@ if __name__ == "__main__":
     if len(sys.argv) > 1:
         child(sys.argv[1])
     else:
-        for kind in ("none", "ddp", "arena"):
+        for kind in ("none-eager", "none", "ddp", "arena-eager", "arena"):
             subprocess.run([sys.executable, os.path.abspath(__file__), kind], check=False)

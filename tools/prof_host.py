@@ -3,14 +3,21 @@ import cProfile, os, pstats, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from view_fusion_amd import train
 dev = "cuda:0"
+ARENA = os.environ.get("VF_PROF_ARENA") == "1"      # the N > 1 launch path on one GPU: gradient arena over a world-1 RCCL group
+if ARENA:
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29541")
+    torch.cuda.set_device(0)
+    train.init_rccl_group(0, rank=0, world_size=1)
 model = train.build_model(device=dev, phase="train")
-GRAPH = os.environ.get("VF_STEP_GRAPH") == "1"
-tr = train.Trainer(model, graph=GRAPH)
-print("whole-step HIP graph:", "on" if GRAPH else "off")
+GRAPH = os.environ.get("VF_STEP_GRAPH", "1") == "1"
+tr = train.Trainer(model, graph=GRAPH, world=2 if ARENA else 1)     # (world=2 only selects the reducer)
+print("whole-step HIP graph:", "on" if GRAPH else "off", "| gradient arena over RCCL (world 1):", "on" if ARENA else "off")
 batch = train.synthetic_batch(16, 6, 64, device=dev, seed=0)
-for _ in range(3):
+for _ in range(6):           # (arena: layout iteration + two sightings + the capture)
     tr.step(batch)
 torch.cuda.synchronize()
+print("iterations replayed from a graph so far:", tr.graph_steps)
 import time
 t0 = time.perf_counter()
 for _ in range(5):
