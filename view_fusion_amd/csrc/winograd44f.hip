@@ -18,15 +18,18 @@
 //     (slices are stored in that "wave order" p = 9 g + j everywhere: packed weights, LDS image);
 //   * U = G4 g G4^T arrives pre-transformed + packed  U[co tile][chunk][p 36][co 64][ci 8]  and goes STRAIGHT from
 //     global memory into the MFMA A registers (one float4 per lane and slice, reloaded in place one chunk ahead);
-//   * per 8-channel chunk the raw haloed rows are staged in LDS; two threads per (channel, tile) transform the 6x6 window
-//     (B4^T d B4: three transformed rows each, 42 packed-fp32 instructions; a window row = one ds_read_b128 + one
-//     ds_read_b64) into V[ci & 3][p][ci >> 2][tile];
-//   * rows and V are double buffered: ONE barrier per chunk; all side work sits behind MFMAs (fp32 MFMA and VALU do not
-//     overlap on a SIMD, tools/mfma_valu.hip);
+//   * per 8-channel chunk the raw haloed rows are staged in LDS, one ROW per wave-slot (row / channel group are scalars),
+//     every load and store unconditional (rows outside the image come from a zero buffer); two threads per
+//     (channel, tile) transform the 6x6 window (B4^T d B4: three transformed rows each, 42 packed-fp32 instructions; a
+//     window row = one ds_read_b128 + one ds_read_b64) into V[ci & 3][p][ci >> 2][tile]; the two halves of that duty run
+//     their own copy of the chunk loop;
+//   * rows and V are double buffered: ONE (LDS-only) barrier per chunk; all side work sits behind MFMAs (fp32 MFMA and
+//     VALU do not overlap on a SIMD, tools/mfma_valu.hip);
 //   * epilogue: A4^T along the columns in registers (full row: 4 values, half row: 3 values per accumulator register),
-//     exchange through LDS in two passes of eight accumulator registers, every wave finishes 2 x 2 channel rows
-//     (A4^T along the rows, bias + per-view bias + residual, float4 row stores); the next tile's first loads and raw
-//     rows are staged under it.
+//     exchange through LDS in FOUR passes of four accumulator registers through two buffers (publish k+1 while finishing
+//     k: one barrier per phase), every wave finishes one channel row of its half per pass (A4^T along the rows, bias +
+//     per-view bias + residual, float4 row stores); the next tile's first loads go out before any store, its raw rows and
+//     V(0) are staged in the last two phases.
 // MODE 0: plain input; MODE 2: nearest-x2-upsampled input (Upsample conv), as in conv.hip.
 #include "common.h"
 #include "wino_plan.h"
@@ -96,14 +99,11 @@ template <int LOGW, int MODE, bool RAGGED>
 __global__ __launch_bounds__(512, 2) void wino44_conv_kernel(F44Args a) {
     using G = FGeo<LOGW, MODE>;
     constexpr int NT_ = 512;
-    constexpr int NX4 = FCK * G::PH * G::Q;
-    constexpr int NXR = (NX4 + NT_ - 1) / NT_;
     constexpr int UCH = FNS * FCO * FCK;                 // floats of one (co tile, chunk) block of U
     constexpr int VSZ = FNS * FCK * FTT;
     constexpr int PSZ = FCK * G::PS;
-    constexpr int XCH = 8 * 7 * 8 * 64;                  // epilogue exchange of one pass: [wave 8][value 7][reg 8][lane 64]
+    constexpr int XCH = 2 * 8 * 7 * 4 * 64;              // epilogue exchange: two buffers of [wave 8][value 7][reg 4][lane 64]
     constexpr int LDSF = 2 * PSZ + (2 * VSZ > XCH ? 2 * VSZ : XCH);
-    static_assert(NXR == 3, "raw-row staging assumes three float4 per thread");
     static_assert(LDSF * 4 <= 160 * 1024, "LDS budget");
 
     __shared__ __attribute__((aligned(16))) float lds[LDSF];
