@@ -198,7 +198,9 @@ __global__ __launch_bounds__(512) void attn_fwd_kh_kernel(const float* __restric
         } else {
             oprev = o;
         }
-        __syncthreads();
+        // (LDS-only barrier: __syncthreads() would also drain this wave's global stores -- the P rows written above and
+        // the output rows of the previous tile -- at every one of the C / 32 iterations)
+        VF_LDS_BARRIER();
     }
     if (kh == 0) {                                       // last tile (its oex slot is (C / 32 - 1) & 1)
         const int last = (C / 32 - 1) & 1;
