@@ -212,3 +212,31 @@ def test_trainer_step_graph_gating_is_host_logic():
     kt, _ = tr._graph_key(dict(gb, view_count=[1, 2, 3, 3]), {"t": f(torch.zeros(4))})
     assert kt != k1 and kt[-1] == 9
     assert tr._graph_key(dict(bt, view_count=[1, 2, 3, 3]), {}) is None          # CPU images
+
+
+def test_winograd_kernel_choice_is_host_logic():
+    """ops.wino_kind (round 4): which of the three conv paths a stride-1 3x3 layer takes is decided on the host from the
+    library's tile plans and a cost model -- no GPU involved.  At the bench geometry (S = 96) the 64x64 layers and the
+    deep 32x32 layers take the F(4x4,3x3) kernel, 128 -> 128 at 32x32 (1.5 rounds of tiles with a short K) and the
+    16x16 / 8x8 maps stay on the nested kernel, one or two views (the sampler) on the direct kernel; the decision is the
+    same for the pack (made outside autograd.Function) and the launch (made inside, where grad mode is off) because
+    both pass `train` explicitly; forcing flags override it."""
+    from view_fusion_amd import ops
+    k = lambda S, ci, co, h, train=True, m=0: ops.wino_kind(S, ci, co, h, h, 3, m, train)
+    assert [k(96, 64, 64, 64), k(96, 128, 64, 64), k(96, 192, 64, 64), k(96, 6, 64, 64), k(96, 64, 6, 64)] == [2] * 5
+    assert [k(96, 256, 128, 32), k(96, 320, 128, 32), k(96, 128, 128, 64, m=2), k(96, 192, 192, 32, m=2)] == [2] * 4
+    assert k(96, 128, 128, 32) == 1 and k(96, 192, 192, 16) == 1 and k(96, 320, 320, 8) == 1 and k(96, 640, 320, 8) == 1
+    assert k(1, 64, 64, 64) == 0 and k(2, 320, 320, 8) == 0
+    assert ops.wino_kind(96, 64, 64, 64, 64, 1, 0, True) == 0 and ops.wino_kind(96, 64, 64, 64, 64, 3, 1, True) == 0
+    assert k(96, 64, 64, 64, train=False) == 2               # forward alone (the sampler at B = 16)
+    import torch
+    with torch.no_grad():                                   # default `train` = whether autograd records
+        assert ops.wino_kind(96, 64, 64, 64, 64, 3, 0) == ops.wino_kind(96, 64, 64, 64, 64, 3, 0, False)
+    ops.FORCE_WINOGRAD = True
+    try:
+        assert k(2, 64, 64, 64) == 1 and k(96, 64, 64, 64) == 1
+        ops.FORCE_WINOGRAD44 = True
+        assert k(2, 64, 64, 64) == 2 and k(2, 192, 192, 16) == 1          # (no F(4x4) kernel for 16x16 maps)
+    finally:
+        ops.FORCE_WINOGRAD = ops.FORCE_WINOGRAD44 = False
+    assert ops.use_winograd(96, 64, 64, 64, 64, 3, 0, True) and not ops.use_winograd(1, 64, 64, 64, 64, 3, 0, False)
