@@ -9,7 +9,7 @@ import os, sys, ctypes, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from view_fusion_amd import _lib, ops
 dev = torch.device("cuda:0")
-S = 96
+S = int(os.environ.get("VF_STAMP_S", "96"))
 lib = _lib.load()
 st = ops._stream()
 raw = ctypes.CDLL(_lib.LIB_PATH)
