@@ -434,6 +434,14 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     loss_val = float(loss.item())
+    # what the job looked like from every rank: the driver can see that N processes on N devices took part, over which
+    # backend / RCCL version, and which launch mode each ended in (train.Trainer.mode)
+    info = trainer.dist_info()
+    info["device"] = torch.cuda.get_device_name(dev) + f" #{local_rank}"
+    ranks = [info]
+    if world > 1:
+        ranks = [None] * world
+        dist.all_gather_object(ranks, info)
 
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -451,7 +459,12 @@ def main():
                                                                                      ", ragged view_count" if args.ragged else ""),
                        "global_batch": args.batch * world, "views": args.views,
                        "parallelism": "dp%d" % world,
-                       "launch": "HIP-graph replay of the whole iteration" if trainer.graph_steps else "eager launches"},
+                       "launch": {"graph": "HIP-graph replay of the whole iteration",
+                                  "captured": "HIP-graph replay of the whole iteration, RCCL all-reduces inside the graph",
+                                  "split": "HIP-graph replay of forward + backward, then six eager RCCL all-reduces + Adam",
+                                  "eager": "eager launches"}[trainer.mode if trainer.graph_steps else "eager"]},
+            "dist": {"world_size": dist.get_world_size() if world > 1 else 1, "backend": info.get("backend"),
+                     "rccl_version": info.get("rccl_version"), "reducer": info["reducer"], "ranks": ranks},
             "iters_per_sec": args.steps / dt, "loss": loss_val,
             "achieved_tflops_total": 62.98e9 * S * world * args.steps / dt / 1e12,
         }

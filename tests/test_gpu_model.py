@@ -270,19 +270,32 @@ def test_gradient_arena_matches_plain_training(dev):
     plain, _, _ = run(1, False)
     train.init_rccl_group(0, rank=0, world_size=1)            # the harness' own group setup (high-priority RCCL streams)
     try:
-        for graph in (False, True):
-            vf, tr, copied = run(2, graph)               # world=2 only selects the reducer; the group has one rank
+        # eager | captured (collectives inside the graph: the default for a group of one) | split on RCCL (what a real
+        # multi-rank run defaults to: forward + backward replayed, collectives + Adam eager) | a capture that fails in
+        # captured mode: the failure flag rides the all-reduce, the agreement point steps down to split, which captures
+        for graph, env, mode in ((False, {}, "eager"), (True, {}, "captured"),
+                                 (True, {"VF_CAPTURE_COLLECTIVES": "0"}, "split"),
+                                 (True, {"VF_TEST_FAIL_CAPTURE": "0:captured"}, "split")):
+            os.environ.update(env)
+            try:
+                vf, tr, copied = run(2, graph)           # world=2 only selects the reducer; the group has one rank
+            finally:
+                for k in env:
+                    os.environ.pop(k)
             a = tr.arena
-            assert a is not None and reducer.ACTIVE is a
+            assert a is not None and reducer.ACTIVE is a and tr.mode == mode, (tr.mode, mode)
             assert copied[1:] == [0] * (STEPS - 1), copied   # zero-copy from the second iteration on (capture included)
             assert all(p.grad.data_ptr() == a.base + 4 * a.off[i] for i, p in enumerate(a.params))
             assert len(a.seg_range) >= 2 and a.seg_range[-1][1] == a.flat.numel()
-            if graph:                                    # iterations 0-2 eager (layout, two sightings), then replays
-                assert a.capturable and tr.graph_steps == STEPS - 1 - train.Trainer.GRAPH_AFTER, tr.graph_steps
+            if "VF_TEST_FAIL_CAPTURE" in env:            # it = 4 fails, read at it = 6, sightings 6-7, replay at it = 8
+                assert tr.demotions == 1 and tr.graph_steps == 1, (tr.demotions, tr.graph_steps)
+            elif graph:                                  # iterations 0-2 eager (layout, two sightings), then replays
+                assert a.capturable == (mode == "captured")
+                assert tr.graph_steps == STEPS - 1 - train.Trainer.GRAPH_AFTER, tr.graph_steps
             else:
                 assert tr.graph_steps == 0
             for (k, p), q in zip(vf.state_dict().items(), plain.state_dict().values()):
-                assert torch.equal(p, q), (graph, k)
+                assert torch.equal(p, q), (mode, env, k)
             reducer.ACTIVE = None
     finally:
         reducer.ACTIVE = None
@@ -333,13 +346,16 @@ def test_full_size_train_step_vs_oracle(dev, B, N, ragged):
     loss = vf(y_cond=y_cond.to(dev), view_count=vc, angle=angle.to(dev), y_0=y_0.to(dev), noise=noise.to(dev),
               t=t.to(dev), u=u.to(dev))
     loss.backward()
-    sd = cpu_sd(vf.denoise_fn)
-    sched = vfr.schedule_buffers(vfr.beta_schedule(**SCHED_TRAIN))
-    lref = oracle_train_chunked(sd, SMALL, sched, y_cond, vc, angle, y_0, t, u, noise)
+    import oracle_pool
+    sd0 = {k: v.detach().cpu() for k, v in vf.denoise_fn.state_dict().items()}
+    try:                        # the oracle, sample-parallel (tests/oracle_pool.py: samples are independent)
+        lref, gref = oracle_pool.train(sd0, SMALL, SCHED_TRAIN, y_cond, vc, angle, y_0, t, u, noise)
+    finally:
+        oracle_pool.close()
     assert abs(loss.item() - lref) <= 1e-5 * abs(lref), (loss.item(), lref)
     worst, wk = 0.0, None
     for k, p in vf.denoise_fn.named_parameters():
-        a, b = p.grad.detach().cpu().double(), sd[k].grad.double()
+        a, b = p.grad.detach().cpu().double(), gref[k].double()
         if float(b.norm()) > 1e-4:
             err = float((a - b).norm() / b.norm())
             if err > worst:
@@ -361,7 +377,7 @@ def test_full_size_train_step_vs_oracle(dev, B, N, ragged):
     assert abs(lg.item() - lref) <= 1e-5 * abs(lref), (lg.item(), lref)
     worst, wk = 0.0, None
     for k, p in vf.denoise_fn.named_parameters():
-        a, b = p.grad.detach().cpu().double(), sd[k].grad.double()
+        a, b = p.grad.detach().cpu().double(), gref[k].double()
         if float(b.norm()) > 1e-4:
             err = float((a - b).norm() / b.norm())
             if err > worst:
@@ -418,6 +434,111 @@ def test_small_unet_sampler_vs_oracle(dev, N, use_graph):
                                            angle, y_T, z_seq)
     np.testing.assert_allclose(y.cpu().numpy(), yr.numpy(), rtol=1e-4, atol=5e-5)
     np.testing.assert_allclose(ret.cpu().numpy(), retr.numpy(), rtol=1e-4, atol=5e-5)
+    np.testing.assert_allclose(logit_arr.cpu().numpy(), lr.numpy(), rtol=1e-4, atol=5e-5)
+    np.testing.assert_allclose(weight_arr.cpu().numpy(), wr.numpy(), rtol=1e-4, atol=1e-5)
+
+
+def _kernel_names(fn):
+    """C-ABI entry points a call goes through (ops.KERNEL_LOG), in launch order."""
+    from view_fusion_amd import ops
+    ops.KERNEL_LOG = []
+    try:
+        fn()
+        torch.cuda.synchronize()
+        return [e[5] for e in ops.KERNEL_LOG]
+    finally:
+        ops.KERNEL_LOG = None
+
+
+def test_small_unet_sampler_b16_vs_oracle(dev):
+    """The path bench.py times as `sampler.B16_N6` (reference view_fusion.py:179-214 at B=16, N=6: S = 96 stacked views,
+    eager -- S > 16 -- under the no-grad kernel policy: F(4x4) + nested Winograd forward, conv -> GroupNorm un-fused,
+    attn_fwd_kh without the P write): three reverse steps of generate() against the oracle, tolerances as the B=1
+    sampler tests; and the two Winograd forward kernels really are what ran."""
+    import oracle_pool
+    sched_kw = dict(schedule="linear", num_timesteps=3, linear_start=1e-4, linear_end=0.09)
+    vf = make_vf(SMALL, sched_kw, dev, True)
+    B, N = 16, 6
+    g = torch.Generator().manual_seed(216)
+    y_cond = torch.rand(B, N, 3, 64, 64, generator=g)
+    angle = 2 * np.pi / 24 * torch.randint(0, 24, (B, 1), generator=g).float()
+    y_T = torch.randn(B, 3, 64, 64, generator=g)
+    z_seq = torch.randn(3, B, 3, 64, 64, generator=g)
+    vc = torch.full((B,), N)
+    args = (y_cond.to(dev), vc, angle.to(dev))
+    y, ret, logit_arr, weight_arr, samples = vf.generate(*args, y_t=y_T.to(dev), z_seq=z_seq.to(dev), sample_num=2)
+    names = _kernel_names(lambda: vf.p_sample(y_T.to(dev), *args, torch.full((B,), 2, device=dev), z=z_seq[2].to(dev)))
+    assert "vf_wino44_conv_fwd" in names and "vf_wino_conv_fwd" in names, sorted(set(names))
+    sd = {k: v.detach().cpu() for k, v in vf.denoise_fn.state_dict().items()}
+    try:
+        yr, retr, lr, wr, _ = oracle_pool.generate(sd, SMALL, sched_kw, y_cond, vc, angle, y_T, z_seq, sample_num=2)
+    finally:
+        oracle_pool.close()
+    np.testing.assert_allclose(y.cpu().numpy(), yr.numpy(), rtol=1e-4, atol=5e-5)
+    np.testing.assert_allclose(ret.cpu().numpy(), retr.numpy(), rtol=1e-4, atol=5e-5)
+    np.testing.assert_allclose(logit_arr.cpu().numpy(), lr.numpy(), rtol=1e-4, atol=5e-5)
+    np.testing.assert_allclose(weight_arr.cpu().numpy(), wr.numpy(), rtol=1e-4, atol=1e-5)
+
+
+def test_long_chain_through_winograd_kernels(dev):
+    """A long reverse chain THROUGH the Winograd kernels: small UNet, B=8 N=6 (S = 48: F(4x4) on the 64x64 / 32x32 maps,
+    nested kernel below), the last 100 steps (t = 99 .. 0) of the T=1000 sampler schedule with injected z, every step's
+    output fed to the next.  Stated max-abs 1e-3; the measured value is printed and asserted with 10x
+    margin.  One forward of the F(4x4) kernel alone carries 1e-5 (profiles/r04_parity_margin.txt): this is the test
+    that shows it does not accumulate."""
+    import oracle_pool
+    vf = make_vf(SMALL, SCHED_TEST, dev, True)
+    B, N, steps = 8, 6, 100
+    g = torch.Generator().manual_seed(301)
+    y_cond = torch.rand(B, N, 3, 64, 64, generator=g)
+    angle = 2 * np.pi / 24 * torch.randint(0, 24, (B, 1), generator=g).float()
+    # start where the chain would be at t = 99: a lightly noised image
+    y_start = (0.8 * (2 * torch.rand(B, 3, 64, 64, generator=g) - 1) + 0.6 * torch.randn(B, 3, 64, 64, generator=g))
+    z_seq = torch.randn(steps, B, 3, 64, 64, generator=g)
+    vc = torch.full((B,), N)
+    args = (y_cond.to(dev), vc, angle.to(dev))
+    names = _kernel_names(lambda: vf.p_sample(y_start.to(dev), *args, torch.full((B,), 99, device=dev),
+                                              z=z_seq[0].to(dev)))
+    assert "vf_wino44_conv_fwd" in names and "vf_wino_conv_fwd" in names, sorted(set(names))
+    y, kept = y_start.to(dev), []
+    for n, i in enumerate(range(steps - 1, -1, -1)):
+        y, _, w = vf.p_sample(y, *args, torch.full((B,), i, device=dev), z=z_seq[n].to(dev))
+        if (n + 1) % 10 == 0:
+            kept.append(y)
+    sd = {k: v.detach().cpu() for k, v in vf.denoise_fn.state_dict().items()}
+    try:
+        yr, keptr, wr = oracle_pool.chain(sd, SMALL, SCHED_TEST, y_cond, vc, angle, y_start, z_seq, steps - 1, 0,
+                                          keep_every=10)
+    finally:
+        oracle_pool.close()
+    err = float((y.cpu() - yr).abs().max())
+    err_mid = float((torch.stack(kept).cpu() - keptr).abs().max())
+    err_w = float((w.cpu() - wr).abs().max())
+    print(f"100-step chain through the Winograd kernels (S=48): final max-abs {err:.3e}, over every 10th step "
+          f"{err_mid:.3e}, weights {err_w:.3e}")
+    assert err < 1e-3 and err_mid < 1e-3          # the stated long-chain tolerance
+    assert err < 1e-4 and err_mid < 1e-4, (err, err_mid)
+
+
+def test_extrapolate_real_unet_n23(dev):
+    """SURVEY 8(f2) on the REAL UNet: drivers.extrapolate (experiment.py:472-488) with up to 23 conditioning views,
+    B=2 (S = 40 stacked views, ragged), ten reverse steps, against the oracle."""
+    import oracle_pool
+    from view_fusion_amd import drivers
+    vf = make_vf(SMALL, SCHED_C1, dev, True)
+    g = torch.Generator().manual_seed(423)
+    cond, angle = torch.rand(2, 23, 3, 64, 64, generator=g), torch.rand(2, 1, generator=g) * 6
+    vc = torch.tensor([23, 17])
+    y_T, z_seq = torch.randn(2, 3, 64, 64, generator=g), torch.randn(10, 2, 3, 64, 64, generator=g)
+    ret, logit_arr, weight_arr, _ = drivers.extrapolate(vf, cond.to(dev), angle.to(dev), view_count=vc,
+                                                        y_t=y_T.to(dev), z_seq=z_seq.to(dev))
+    sd = {k: v.detach().cpu() for k, v in vf.denoise_fn.state_dict().items()}
+    try:
+        _, retr, lr, wr, _ = oracle_pool.generate(sd, SMALL, SCHED_C1, cond, vc, angle, y_T, z_seq)
+    finally:
+        oracle_pool.close()
+    assert weight_arr.shape == (2, 8, 23, 3, 64, 64)
+    np.testing.assert_allclose(ret.cpu().numpy(), retr.clamp(0, 1).numpy(), rtol=1e-4, atol=5e-5)
     np.testing.assert_allclose(logit_arr.cpu().numpy(), lr.numpy(), rtol=1e-4, atol=5e-5)
     np.testing.assert_allclose(weight_arr.cpu().numpy(), wr.numpy(), rtol=1e-4, atol=1e-5)
 

@@ -59,10 +59,10 @@ def _run(tr, vf, batches, dev):
     return grads
 
 
-def _worker(rank, world, port, out, lr, kind, graph, steps):
+def _worker(rank, world, port, out, lr, kind, graph, steps, env=None):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      VF_REDUCER=kind)
+                      VF_REDUCER=kind, **(env or {}))
     import torch.distributed as dist
     from view_fusion_amd import train
     dev = torch.device("cuda:0")
@@ -78,7 +78,7 @@ def _worker(rank, world, port, out, lr, kind, graph, steps):
         grads += _run(tr, vf, [_batch(s, rank, ragged=not graph)], dev)
         copied.append(tr.arena.copied if tr.arena is not None else 0)
     out[rank] = dict(grads=grads, copied=copied, params=[p.detach().cpu().clone() for p in vf.parameters()],
-                     graph_steps=tr.graph_steps)
+                     graph_steps=tr.graph_steps, mode=tr.mode, demotions=tr.demotions, info=tr.dist_info())
     dist.destroy_process_group()
 
 
@@ -90,11 +90,30 @@ def _free_port():
     return p
 
 
-def _spawn(lr, kind="arena", graph=False, steps=3):
+def _spawn(lr, kind="arena", graph=False, steps=3, env=None):
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_worker, args=(2, _free_port(), out, lr, kind, graph, steps), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), out, lr, kind, graph, steps, env), nprocs=2, join=True)
     return out[0], out[1]
+
+
+def _check_against_global_batch(r0, r1, STEPS, ragged):
+    from view_fusion_amd import train
+    dev = torch.device("cuda:0")
+    vf = _model(dev)
+    tr = train.Trainer(vf, world=1, lr_warmup=1, graph=False)
+    tr.it, tr.sched.peak_lr = 0, 0.0
+    glob = []
+    for s in range(STEPS):
+        a, b = _batch(s, 0, ragged), _batch(s, 1, ragged)
+        glob.append({k: torch.cat([a[k], b[k]]) for k in a})
+    ref = _run(tr, vf, glob, dev)
+    names = [k for k, _ in vf.named_parameters()]
+    for s in range(STEPS):
+        for k, g0, g1, gr in zip(names, r0["grads"][s], r1["grads"][s], ref[s]):
+            assert torch.equal(g0, g1), (s, k)                       # both ranks hold the same average
+            err = float((g0.double() - gr.double()).norm())
+            assert err <= 2e-5 * float(gr.double().norm()) + 1e-7 * gr.numel() ** 0.5, (s, k, err)
 
 
 # arena: eager launches / the iteration replayed as a HIP graph (gloo cannot be captured: the graph ends with the
@@ -107,21 +126,25 @@ def test_two_rank_arena_gradients_match_the_global_batch(kind, graph, STEPS):
     assert r0["copied"][1:] == [0] * (STEPS - 1) and r1["copied"][1:] == [0] * (STEPS - 1), (r0["copied"], r1["copied"])
     want = STEPS - 1 - train.Trainer.GRAPH_AFTER if graph else 0
     assert r0["graph_steps"] == r1["graph_steps"] == want, (r0["graph_steps"], r1["graph_steps"])
-    dev = torch.device("cuda:0")
-    vf = _model(dev)
-    tr = train.Trainer(vf, world=1, lr_warmup=1, graph=False)
-    tr.it, tr.sched.peak_lr = 0, 0.0
-    glob = []
-    for s in range(STEPS):
-        a, b = _batch(s, 0, not graph), _batch(s, 1, not graph)
-        glob.append({k: torch.cat([a[k], b[k]]) for k in a})
-    ref = _run(tr, vf, glob, dev)
-    names = [k for k, _ in vf.named_parameters()]
-    for s in range(STEPS):
-        for k, g0, g1, gr in zip(names, r0["grads"][s], r1["grads"][s], ref[s]):
-            assert torch.equal(g0, g1), (s, k)                       # both ranks hold the same average
-            err = float((g0.double() - gr.double()).norm())
-            assert err <= 2e-5 * float(gr.double().norm()) + 1e-7 * gr.numel() ** 0.5, (s, k, err)
+    assert r0["mode"] == r1["mode"] == ("split" if graph else "eager") and r0["info"]["world_size"] == 2
+    _check_against_global_batch(r0, r1, STEPS, not graph)
+
+
+def test_capture_failure_on_one_rank_steps_every_rank_down():
+    """Rank 1's training-step capture fails (injected) while rank 0's succeeds.  Until the next agreement point the
+    ranks run different launch modes -- rank 0 replays, rank 1 enqueues eagerly: same collectives in the same order --
+    then BOTH step down to the eager mode together; the averaged gradients of every iteration, before, during and
+    after, equal single-process gradients on the concatenated batch, and the replicas end bit-identical."""
+    STEPS = 9
+    r0, r1 = _spawn(0.0, "arena", True, STEPS, env=dict(VF_TEST_FAIL_CAPTURE="1:split"))
+    # iterations it = 1..9: layout, two eager sightings, capture at it = 4 (rank 1 fails and raises the flag), rank 0
+    # replays it = 4, 5; the flag is read at it = 6 (= 2 + 4): everybody eager from there on
+    assert r0["graph_steps"] == 2 and r1["graph_steps"] == 0, (r0["graph_steps"], r1["graph_steps"])
+    assert r0["mode"] == r1["mode"] == "eager" and r0["demotions"] == r1["demotions"] == 1
+    _check_against_global_batch(r0, r1, STEPS, False)
+    r0, r1 = _spawn(1e-4, "arena", True, STEPS, env=dict(VF_TEST_FAIL_CAPTURE="1:split"))
+    for a, b in zip(r0["params"], r1["params"]):
+        assert torch.equal(a, b)
 
 
 @pytest.mark.parametrize("kind,graph,STEPS", [("arena", False, 3), ("arena", True, 6), ("ddp", False, 3)])

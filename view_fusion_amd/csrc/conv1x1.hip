@@ -209,6 +209,10 @@ bool vfi_conv1x1_supported(const C11Args& a) {
     if (a.Cin % 32 != 0 || a.HW < 64 || (a.HW & (a.HW - 1)) != 0 || a.npx < 128 || a.npx % 4 != 0) return false;
     if (a.x2 && (a.C1 <= 0 || a.C1 >= a.Cin || a.C1 % 32 != 0)) return false;
     if (a.y2 && (a.C1o <= 0 || a.C1o >= a.Cout || a.C1o % 64 != 0)) return false;
+    // the kernel carries per-lane BYTE offsets into x / x2 as 32-bit values: a source tensor must stay below 4 GiB
+    // (S = 96 views of 320 channels at 64x64 are 0.5 GiB; larger view batches fall back to the generic kernel)
+    const size_t widest = (size_t)(a.x2 ? (a.C1 > a.Cin - a.C1 ? a.C1 : a.Cin - a.C1) : a.Cin);
+    if ((size_t)a.S * widest * (size_t)a.HW * 4 >= (1ull << 32)) return false;
     static const bool force = getenv("VF_CONV1X1_FORCE") != nullptr;     // tests / tuning: wherever the shape is legal
     const long tiles = (long)((a.npx + 127) / 128) * ((a.nct + 1) / 2);
     if (force) return tiles >= 64;

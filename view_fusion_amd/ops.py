@@ -161,13 +161,17 @@ def _gout(p, *shape, like):
 # before the flush:
 #   * both parameters' .grad is None (AccumulateGrad then adopts the tensor without reading it; zero_grad(set_to_none=
 #     True), what Trainer.step does);
-#   * no tensor hook / post-accumulate-grad hook sits on the parameters (the arena's own hook is the one exception: it
-#     flushes before it lets a segment go);
-#   * nobody has switched COLSUM_DEFER off: torch's DistributedDataParallel copies a gradient into its bucket from a
-#     hook on the AccumulateGrad NODE (invisible from the tensor) while the backward pass is still running, so Trainer
-#     sets COLSUM_DEFER = False when it wraps the model in DDP (VF_REDUCER=ddp).
-# A backward pass that raises never runs its engine callbacks: the entries it left behind are recognised by their
-# autograd graph-task id and dropped by the next pass (their destinations belong to a pass that produced no step).
+#   * no tensor hook / post-accumulate-grad hook sits on the parameters (the arena's own hooks are the exception -- the
+#     post-accumulate hook of the eager step and the tensor hook on a leaf alias of the captured step: both flush before
+#     they let a segment go);
+#   * the parameter is not marked `_vf_no_defer`: torch's DistributedDataParallel copies a gradient into its bucket from
+#     a hook on the AccumulateGrad NODE (invisible from the tensor) while the backward pass is still running, so Trainer
+#     marks the parameters of a model it wraps in DDP (VF_REDUCER=ddp); COLSUM_DEFER = False switches deferral off
+#     for the whole process (nothing in the package sets it).
+# A backward pass that raises never runs its engine callbacks, and a re-entrant backward pass (torch.utils.checkpoint)
+# starts a new graph task while the outer one still has entries pending: entries of another task are recognised by their
+# graph-task id and FLUSHED by the next pass (filling a destination nobody will read is harmless; dropping one autograd
+# still hands out is not).  A capture that aborts drops them explicitly (drop_pending_colsums).
 COLSUM_DEFER = True
 _PENDING_COLSUMS = []
 _PENDING_TASK = None      # torch._C._current_graph_task_id() of the backward pass the pending entries belong to
@@ -273,12 +277,16 @@ def _flush_colsums():
 
 def _defer_ok(params):
     a = reducer.ACTIVE
+    flushes = a is not None and getattr(a, "flushes_colsums", False)
     for p in params:
-        if p is None or p.grad is not None or getattr(p, "_backward_hooks", None):
+        if p is None or p.grad is not None or getattr(p, "_vf_no_defer", False):
             return False
+        if getattr(p, "_backward_hooks", None) and not (flushes and id(p) in a._alias):
+            return False        # a foreign tensor hook would read the gradient before the flush; the arena's own hook
+                                # on a leaf alias (captured iteration) flushes before it lets the segment go
         if a is None and getattr(p, "_post_accumulate_grad_hooks", None):
             return False
-    return a is None or getattr(a, "flushes_colsums", False)
+    return a is None or flushes
 
 
 def _colsum(parts, dgb, batch, S, C, params):
@@ -288,7 +296,14 @@ def _colsum(parts, dgb, batch, S, C, params):
     if (COLSUM_DEFER and task != -1 and _defer_ok(params)
             and (_CAPTURE_TABLE is not None or not torch.cuda.is_current_stream_capturing())):
         if _PENDING_COLSUMS and _PENDING_TASK != task:
-            _PENDING_COLSUMS.clear()          # left behind by a backward pass that failed (its callback never ran)
+            # entries of another graph task: a backward pass that failed (its callback never ran) -- or the OUTER pass
+            # of a re-entrant backward (torch.utils.checkpoint, autograd.grad inside a backward), whose destinations
+            # autograd will still hand out.  Outside a capture filling them now is always right (the entries keep
+            # their tensors alive); inside a capture the abort path has already dropped them (drop_pending_colsums).
+            if torch.cuda.is_current_stream_capturing():
+                _PENDING_COLSUMS.clear()
+            else:
+                _flush_colsums()
         if not _PENDING_COLSUMS:
             _PENDING_TASK = task
             torch.autograd.Variable._execution_engine.queue_callback(_flush_colsums)

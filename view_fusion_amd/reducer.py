@@ -23,6 +23,17 @@ reference never does it, experiment.py:286-293) and raises.
 
 Single-process training (world 1) never constructs an arena.
 
+Order of the collectives: segment k's all-reduce is issued only when segments 0..k-1 have been issued, on every rank and
+in every launch mode (eager hooks, captured graph, replay + reduce_all()).  Ranks may therefore run different launch
+modes in the same iteration (one rank replays a graph while another meets a new batch geometry and runs eagerly) and
+still present RCCL with the same sequence of six collectives.
+
+Failure flag: the last segment carries one extra float that every rank fills before the segment goes -- 0, or 1 when
+this rank's training-step capture has failed -- and the averaged value is added to a device accumulator after the join.
+train.Trainer reads the accumulator at iteration numbers every rank computes alike and, when it is non-zero, ALL ranks
+step down together (captured collectives -> split replay -> eager): agreement about the launch mode without an extra
+collective and without a per-step host sync.
+
 Deferred GroupNorm column sums (ops._colsum): with the arena the ~70 per-layer launches of a backward pass collapse into
 one multi-tensor launch per SEGMENT -- `_ready` flushes what is pending right before it lets a segment's all-reduce go.
 
@@ -63,7 +74,14 @@ class GradArena:
                     self.owner[i] = m_ord
         self.avg = dist.get_backend(group) == "nccl"          # RCCL has ncclAvg; gloo only SUM
         # RCCL collectives are stream work and can be recorded into a HIP graph; gloo's run on the host
-        self.capturable = self.avg and os.environ.get("VF_CAPTURE_COLLECTIVES", "1") == "1"
+        # Default: inside the graph only for a group of ONE (nothing to wait for).  With real peers the captured-collective
+        # path has never run on hardware (one-GPU pool), and a mismatch there is a hang no except-clause can catch: a
+        # multi-rank run replays forward + backward and issues the six collectives + Adam eagerly after each replay
+        # unless VF_CAPTURE_COLLECTIVES=1 asks for the fully captured iteration.
+        want = os.environ.get("VF_CAPTURE_COLLECTIVES", "1" if self.world == 1 else "0")
+        self.capturable = self.avg and want == "1"
+        self.flag_value = 0.0                                 # this rank's entry of the failure flag (see module doc)
+        self.flag_acc = None
         self._alias = {}                                      # id(leaf alias of a parameter) -> index (captured step)
         self._hooks = []
         self.flat = None                                      # laid out at the end of the first iteration
@@ -99,13 +117,15 @@ class GradArena:
             self.off[i], prev = off, self.owner[i]
             off += self.params[i].numel()
         off = (off + _ALIGN - 1) // _ALIGN * _ALIGN
-        self.flat = torch.zeros(off, device=self.params[0].device, dtype=torch.float32)
+        self.flag_off = off                                   # the failure flag: one float behind the last slot,
+        self.flat = torch.zeros(off + _ALIGN, device=self.params[0].device, dtype=torch.float32)   # inside the last segment
+        self.flag_acc = torch.zeros(1, device=self.params[0].device, dtype=torch.float32)
         self.base = self.flat.data_ptr()
         self.seg_of, self.seg_range, k, lo = [0] * n, [], 0, 0
         for pos, i in enumerate(seq):
             self.seg_of[i] = k
-            end = self.off[seq[pos + 1]] if pos + 1 < n else off
-            if end * self.nseg >= off * (k + 1):
+            end = self.off[seq[pos + 1]] if pos + 1 < n else off + _ALIGN
+            if end * self.nseg >= off * (k + 1) or pos + 1 == n:
                 self.seg_range.append((lo, end))
                 lo, k = end, k + 1
         self.seg_count = [self.seg_of.count(s) for s in range(len(self.seg_range))]
@@ -114,6 +134,7 @@ class GradArena:
     def _reset(self):
         self.pending = list(self.seg_count)
         self.launched = [False] * len(self.seg_range)
+        self.next_seg = 0
         self.got = [False] * len(self.params)
         self.handed = set()                                   # slots given to a backward kernel this iteration
 
@@ -172,11 +193,18 @@ class GradArena:
             s.copy_(g)
             g = s
             self.copied += 1
-        k = self.seg_of[i]
-        self.pending[k] -= 1
-        if self.pending[k] == 0 and self._may_launch():
-            self._launch(k)
+        self.pending[self.seg_of[i]] -= 1
+        self._launch_complete()
         return g
+
+    def _launch_complete(self):
+        """Issue, in index order, every segment whose gradients have all arrived (never segment k before k-1)."""
+        if not self._may_launch():
+            return
+        k = self.next_seg
+        while k < len(self.pending) and self.pending[k] == 0:
+            self._launch(k)
+            k += 1
 
     def _may_launch(self):
         return self.capturable or not (self.flat.is_cuda and torch.cuda.is_current_stream_capturing())
@@ -184,11 +212,15 @@ class GradArena:
     def _launch(self, k):
         from . import ops
         ops.flush_colsums()                                   # deferred GroupNorm sums of this (and earlier) segments
+        assert k == self.next_seg, (k, self.next_seg)       # the order every rank relies on
         lo, hi = self.seg_range[k]
+        if k == len(self.seg_range) - 1:
+            self.flat[self.flag_off:self.flag_off + 1].fill_(self.flag_value)
         t = self.flat[lo:hi]
         op = dist.ReduceOp.AVG if self.avg else dist.ReduceOp.SUM
         self.works.append((dist.all_reduce(t, op=op, group=self.group, async_op=True), t))
         self.launched[k] = True
+        self.next_seg = k + 1
 
     # -- main thread, after loss.backward() ---------------------------------------------------------------------
     def finish(self):
@@ -216,6 +248,8 @@ class GradArena:
             w.wait()
             if not self.avg:
                 t.mul_(1.0 / self.world)
+        if self.works:
+            self.flag_acc.add_(self.flat[self.flag_off:self.flag_off + 1])
         self.works = []
         self._reset()
 

@@ -107,7 +107,7 @@ class _StepGraph:
 class Trainer:
     """The reference's iteration (experiment.py:265-293) around `model`.
 
-    graph (default: the VF_STEP_GRAPH environment variable, off unless "1"): single-process GPU runs replay the WHOLE
+    graph (default: on; the VF_STEP_GRAPH=0 environment variable or graph=False turn it off): GPU runs replay the WHOLE
     iteration -- weight packs, forward, backward, the multi-tensor Adam launch: ~1000 kernels -- as one HIP graph per
     batch geometry instead of enqueueing it launch by launch.  The geometry is the tensor shapes plus the stacked-view
     count S = sum(view_count): which sample owns which views is the offsets table the kernels read from device memory,
@@ -117,7 +117,13 @@ class Trainer:
     state then exist and are only re-used); up to `GRAPH_MAX` graphs share one memory pool (each keeps its own
     gradient tensors, 136 MB for the small UNet).  Eager as before: injected arguments other than the draws t / u /
     noise (which are graph inputs), a device-resident view_count (reading it back would be a sync per step), a
-    kernel log, world > 1.  The captured step is the same launches on the same data: with the same random draws its
+    kernel log, torch DDP as the reducer (VF_REDUCER=ddp).  world > 1 with the gradient arena has three launch modes
+    (`self.mode`): "split" (the default: forward + backward replayed, the six segment all-reduces and the Adam launch
+    issued eagerly after each replay), "captured" (VF_CAPTURE_COLLECTIVES=1: the collectives recorded into the graph on
+    RCCL's stream, Adam included; the default only for a group of one) and "eager".  A rank whose capture fails raises
+    the arena's failure flag, which rides the gradient all-reduce; at iteration numbers all ranks compute alike
+    (`_agree`) every rank reads the accumulated flag and, if any rank failed, ALL step down one mode together
+    (captured -> split -> eager) and drop their graphs -- never a lasting mix of modes.  The captured step is the same launches on the same data: with the same random draws its
     parameters match the eager step's bit for bit (tests/test_gpu_step_graph.py).  Learning rate and Adam bias
     corrections are read from device memory refreshed before each replay; torch's device RNG advances per replay
     exactly as it does per eager step.  The capture runs the forward on fresh leaf aliases of the parameters and takes
@@ -148,8 +154,8 @@ class Trainer:
             self.model = DistributedDataParallel(model, **kw)
             # DDP copies a gradient into its bucket from a hook on the AccumulateGrad node, during the backward pass:
             # a GroupNorm gradient whose column sum is deferred to the end of the pass would be read before it exists
-            from . import ops
-            ops.COLSUM_DEFER = False
+            for p in model.parameters():        # (per parameter, not a process-wide switch: other models keep deferring)
+                p._vf_no_defer = True
         # modules whose behaviour depends on train/eval mode (see step()): the blocks that carry a Dropout
         self._mode_modules = [m for m in model.modules() if getattr(m, "dropout", 0) and hasattr(m, "_drop")]
         self.sched = LrScheduler(peak_lr=1e-4, peak_it=lr_warmup, decay_it=decay_it, decay_rate=0.16)
@@ -165,12 +171,69 @@ class Trainer:
             graph = os.environ.get("VF_STEP_GRAPH", "1") == "1"
         # (with torch DDP the iteration stays eager: its reducer is driven by autograd hooks on the host)
         self.use_graph = bool(graph) and params[0].is_cuda and (world == 1 or self.arena is not None)
+        self._graph_wanted = self.use_graph     # what the run was configured for (a local capture failure clears use_graph)
         self._graphs = {}           # geometry key -> _StepGraph
         self._pool = None           # the graphs' shared private memory pool
         self._scal = None           # device {lr, 1-b1^t, 1-b2^t}
         self._last_graph = None
         self._graph_epoch = None    # FusedAdam.graph_epoch the kept graphs were captured under (None: none captured)
         self.graph_steps = 0        # iterations that ran as a replay (diagnostics / tests)
+        self.world = world
+        self._check_base = self.GRAPH_AFTER     # multi-rank agreement: flag read at _check_base + 1, 2, 4, 8, ...
+        self.demotions = 0
+
+    @property
+    def mode(self):
+        """Launch mode of the iteration: "eager", "graph" (single process), "split" / "captured" (gradient arena)."""
+        if not self.use_graph:
+            return "eager"
+        if self.arena is None:
+            return "graph"
+        return "captured" if self.arena.capturable else "split"
+
+    def dist_info(self):
+        """What a multi-rank run looks like from this rank (bench.py prints it)."""
+        info = dict(world_size=self.world, reducer="none" if self.world == 1 else ("arena" if self.arena else "ddp"),
+                    launch_mode=self.mode, graph_steps=self.graph_steps, mode_demotions=self.demotions)
+        if dist.is_available() and dist.is_initialized():
+            info.update(world_size=dist.get_world_size(), rank=dist.get_rank(), backend=dist.get_backend())
+            if info["backend"] == "nccl":
+                try:
+                    info["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+                except Exception:           # noqa: BLE001
+                    info["rccl_version"] = None
+        if self.arena is not None:
+            info["gradients_copied_last_step"] = self.arena.copied
+        return info
+
+    def _drop_graphs(self):
+        self._graphs, self._last_graph, self._pool, self._graph_epoch = {}, None, None, None
+
+    def _agree(self):
+        """Multi-rank agreement on the launch mode (see the class doc).  Called at the top of every step; reads the
+        arena's accumulated failure flag (one host sync) only at iterations _check_base + 2^j."""
+        a = self.arena
+        if a is None or a.flag_acc is None:
+            return
+        d = self.it - self._check_base
+        if d < 1 or (d & (d - 1)) != 0:
+            return
+        if float(a.flag_acc.item()) == 0.0:        # the same averaged value on every rank
+            return
+        was = "captured" if a.capturable and self._graph_wanted else ("split" if self._graph_wanted else "eager")
+        if was == "captured":
+            a.capturable = False
+            self.use_graph = True
+        else:
+            self.use_graph = self._graph_wanted = False
+        import sys
+        print(f"[view_fusion_amd] rank {dist.get_rank() if dist.is_initialized() else 0}: a training-step capture failed "
+              f"on some rank; all ranks step down from '{was}' to '{self.mode}' at iteration {self.it}", file=sys.stderr)
+        self._drop_graphs()
+        a.flag_value = 0.0
+        a.flag_acc.zero_()
+        self._check_base = self.it
+        self.demotions += 1
 
     # -- whole-step HIP graph ---------------------------------------------------------------------------------------
     def _graph_key(self, batch, extra):
@@ -202,6 +265,9 @@ class Trainer:
         from . import ops
         dev = batch["y_0"].device
         arena = self.arena
+        inj = os.environ.get("VF_TEST_FAIL_CAPTURE")         # tests: "<rank>:<mode>" fails that rank's captures in that mode
+        if inj and dist.is_initialized() and inj == f"{dist.get_rank()}:{self.mode}":
+            raise RuntimeError("injected capture failure (VF_TEST_FAIL_CAPTURE)")
         # With a host-driven transport (gloo) the graph ends with the backward pass; the exchange and the Adam launch
         # follow each replay eagerly.  On RCCL the segment all-reduces and Adam are part of the graph.
         split = arena is not None and not arena.capturable
@@ -293,11 +359,12 @@ class Trainer:
         # The residual blocks' Dropout is the only such layer; the root flag alone would miss `vf.denoise_fn.eval()`.
         if not self.model.training or any(not m.training for m in self._mode_modules):
             self.model.train()
+        self._agree()
         key, vc = self._graph_key(batch, extra) or (None, None)
         if key is not None and self._graph_epoch is not None and self.opt.graph_epoch != self._graph_epoch:
             # the optimizer state was replaced (load_state_dict, a changed parameter set): the captured steps still
             # address the old moment tensors -- drop them; every geometry is captured again after its eager sightings
-            self._graphs, self._last_graph, self._pool, self._graph_epoch = {}, None, None, None
+            self._drop_graphs()
         if key is not None:
             e = self._graphs.get(key)
             if e is None and len(self._graphs) < self.GRAPH_MAX:
@@ -310,8 +377,11 @@ class Trainer:
                     except Exception as err:           # leave the run on the eager path, loudly
                         import sys
                         print(f"[view_fusion_amd] training-step graph capture failed ({type(err).__name__}: {err}); "
-                              "continuing eagerly", file=sys.stderr)
+                              "continuing eagerly" + ("" if self.arena is None else
+                                                      " and telling the other ranks (failure flag)"), file=sys.stderr)
                         self.use_graph, e.graph = False, None
+                        if self.arena is not None:     # rides the next gradient all-reduce; every rank steps down at
+                            self.arena.flag_value = 1.0    # the next agreement point (_agree)
                         self.opt.zero_grad()
                 if e.graph is not None:
                     return self._graph_step(e, vc, batch, extra)
