@@ -537,7 +537,7 @@ def test_extrapolate_real_unet_n23(dev):
         _, retr, lr, wr, _ = oracle_pool.generate(sd, SMALL, SCHED_C1, cond, vc, angle, y_T, z_seq)
     finally:
         oracle_pool.close()
-    assert weight_arr.shape == (2, 8, 23, 3, 64, 64)
+    assert weight_arr.shape == (2, 10, 23, 3, 64, 64)      # T = 10, sample_num = 8: every step is stashed
     np.testing.assert_allclose(ret.cpu().numpy(), retr.clamp(0, 1).numpy(), rtol=1e-4, atol=5e-5)
     np.testing.assert_allclose(logit_arr.cpu().numpy(), lr.numpy(), rtol=1e-4, atol=5e-5)
     np.testing.assert_allclose(weight_arr.cpu().numpy(), wr.numpy(), rtol=1e-4, atol=1e-5)
@@ -556,11 +556,12 @@ def test_long_chain_T1000_tolerance(dev):
     z_seq = torch.randn(1000, B, 3, 16, 16, generator=g)
     vc = torch.tensor([3, 2])
     y, ret, *_ = vf.generate(y_cond.to(dev), vc, angle.to(dev), y_t=y_T.to(dev), z_seq=z_seq.to(dev), use_graph=True)
+    import oracle_pool
     sd = {k: v.detach().cpu() for k, v in vf.denoise_fn.state_dict().items()}
-    sched = vfr.schedule_buffers(vfr.beta_schedule(**SCHED_TEST))
-    with torch.no_grad():
-        yr, retr, *_ = vfr.generate(lambda x, a, l: unet_ref.unet_forward(sd, TINY, x, a, l), sched, y_cond, vc, angle,
-                                    y_T, z_seq)
+    try:                                            # one worker per sample (the chain is 1000 sequential tiny forwards)
+        yr, retr, *_ = oracle_pool.generate(sd, TINY, SCHED_TEST, y_cond, vc, angle, y_T, z_seq)
+    finally:
+        oracle_pool.close()
     err = float((y.cpu() - yr).abs().max())
     err_mid = float((ret.cpu() - retr).abs().max())
     print(f"T=1000 chain: final max-abs {err:.3e}, over all stashed steps {err_mid:.3e}")

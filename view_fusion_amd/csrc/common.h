@@ -120,6 +120,14 @@ __device__ __forceinline__ f32x2 pk_lo_pm_hi(f32x2 a, f32x2 b) {         // [a.x
     return d;
 }
 
+// Value of the lane one below within its 16-lane DPP row; lane 0 of a row gets 0 (bound_ctrl).  Through the builtin, so
+// that the compiler's hazard recognizer sees a DPP instruction (a VALU write of its source needs two wait states in
+// front of it).  NOT __builtin_bit_cast(int, v.w): on an ext-vector element that hands the builtin element 0
+// (clang 19 / ROCm 7.2); take the element into a scalar first.
+__device__ __forceinline__ float dpp_row_shr1(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xf, 0xf, true));
+}
+
 // An LDS-only workgroup barrier.  __syncthreads() is a workgroup-scope fence + barrier: the compiler drains the wave's
 // outstanding GLOBAL stores in front of it (s_waitcnt vmcnt(0); loads and stores retire through one in-order counter, so
 // younger loads wait too).  Where only LDS traffic has to be ordered -- the chunk loops and the LDS exchanges of the

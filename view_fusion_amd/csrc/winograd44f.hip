@@ -134,7 +134,11 @@ __global__ __launch_bounds__(512, 2) void wino44_conv_kernel(F44Args a) {
     static_assert(NSLOT > 16 && NSLOT <= 24, "three slots per wave");
     const int xcl = lane / G::Q, xq = lane % G::Q;
     const unsigned xgofs = (unsigned)(xcl * (4 * G::SH * G::SW) + (MODE == 0 ? 16 : 8) * xq);
-    const int xlofs = xcl * G::PS + 4 * xq + 5;
+    // LDS position of this lane's store: the ALIGNED float4 at idx 4 xq + 4 = pixels 4 xq - 1 .. 4 xq + 2 (see VF_XST1)
+    const int xlofs = xcl * G::PS + 4 * xq;              // (+ 4: an immediate offset of the stores)
+    // lanes that own the last float4 of a row (their .w = pixel W - 1 goes to idx W + 4 with a store of its own)
+    constexpr unsigned long long XLAST = G::Q == 16 ? 0x8000800080008000ull : 0x8080808080808080ull;
+    static_assert(G::Q == 16 || G::Q == 8, "row = 16 or 8 lanes");
 
     struct Tile {                                        // all workgroup-uniform
         const char* ubase;                               // U block of (co tile, first chunk)
@@ -206,13 +210,26 @@ __global__ __launch_bounds__(512, 2) void wino44_conv_kernel(F44Args a) {
     { VF_ULOAD(T, 0, C); VF_ULOAD(T, 1, C); VF_ULOAD(T, 2, C); VF_ULOAD(T, 3, C); VF_ULOAD(T, 4, C);    \
       VF_ULOAD(T, 5, C); VF_ULOAD(T, 6, C); VF_ULOAD(T, 7, C); VF_ULOAD(T, 8, C); }
 #define VF_XLOAD(T, C, R0, R1, R2) { fetch_x((T), 0, (C), R0); fetch_x((T), 1, (C), R1); fetch_x((T), 2, (C), R2); }
-    // (pixels sit at odd dword offsets, idx 5 + 4 q: four ds_write_b32, as two ds_write2_b32, per float4)
+    // A window starts at pixel 4 t - 1, so pixel x sits at idx x + 5 (window = aligned b128 + b64) and a lane's four
+    // pixels 4 q .. 4 q + 3 straddle two 16-byte slots.  Stored as four ds_write_b32 they hit 8 of the 32 store banks
+    // (stride 4 dwords, channel planes 720 = 16 mod 32 apart): 4-way conflicts, 2/3 of this kernel's conflict cycles
+    // (SQ_LDS_BANK_CONFLICT, round 4).  Instead every lane takes its LEFT neighbour's last pixel (DPP row_shr:1 -- the
+    // first lane of a 16-lane row gets 0 = the left halo pixel; on 32-wide maps a DPP row holds two image rows and
+    // lane 8 is zeroed by a select) and stores ONE aligned float4 (pixels 4 q - 1 .. 4 q + 2 at idx 4 q + 4: eight
+    // consecutive lanes = 32 consecutive banks); the row's last pixel is one more ds_write_b32 from the row's last
+    // lane only (EXEC set inside the asm statement: no branch for the compiler to lose its request count over).
 #define VF_XST1(BUF, I, R)                                                                              \
     {                                                                                                   \
         int so_ = (BUF) * PSZ + VF_SCG(I) * CPS * G::PS + VF_SROW(I) * G::PW;                           \
         asm("" : "+s"(so_));                                                                            \
         float* d_ = Pl + so_ + xlofs;                                                                   \
-        d_[0] = R.x; d_[1] = R.y; d_[2] = R.z; d_[3] = R.w;                                             \
+        float pw_ = dpp_row_shr1(R.w);                                                                  \
+        if (G::Q == 8) pw_ = xq == 0 ? 0.f : pw_;                                                       \
+        *reinterpret_cast<f32x4*>(d_ + 4) = (f32x4){pw_, R.x, R.y, R.z};                                \
+        /* (s_nop 4: an EXEC write needs five wait states before a DPP instruction -- the next slot's --, and the   \
+           compiler cannot see this one) */                                                             \
+        asm volatile("s_mov_b64 exec, %2\n\tds_write_b32 %0, %1 offset:32\n\ts_mov_b64 exec, -1\n\ts_nop 4" \
+                     :: "v"((unsigned)(size_t)(__attribute__((address_space(3))) float*)d_), "v"(R.w), "s"(XLAST) : "memory"); \
     }
 #define VF_XSTORE(T, BUF, R0, R1, R2) { VF_XST1(BUF, 0, R0); VF_XST1(BUF, 1, R1); VF_XST1(BUF, 2, R2); }
 
