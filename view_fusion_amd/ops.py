@@ -108,6 +108,50 @@ def _workspace(device, nfloats):
 
 
 # ---------------------------------------------------------------------------------------------
+# Side branches of a captured graph.  A single-stream capture records a CHAIN: every kernel waits for its predecessor,
+# also where the dataflow does not ask for it.  In the sampler's reverse step at a few stacked views every node costs its
+# ~5 us launch-to-launch latency, so the residual 1x1 convolution of a block (needed only by the block's LAST conv) and
+# the time-embedding MLP (needed only by the first block's first conv) are put on a second stream between a fork and a
+# join: in the graph they become siblings of the main chain instead of links of it.  Outside a capture the branch body
+# simply runs inline on the current stream (eager launches are host-bound at these sizes; a second stream would add
+# host calls, not remove latency).
+# MEASURED (round 5, profiles/r05_sampler.md): OFF by default -- on this runtime a fork / join pair costs more than the
+# 5 us node it takes off the chain (B=1 N=1: 1.50 -> 1.85 ms per reverse step with the 19 residual convs + the embedding
+# chain on a second stream; N=6: 2.30 -> 2.53; N=12: 2.88 -> 3.04): a linear chain is the cheapest graph there is.
+BRANCHES = os.environ.get("VF_GRAPH_BRANCHES", "0") == "1"
+_SIDE_STREAMS = {}
+
+
+class side_branch:
+    def __enter__(self):
+        self.side = None
+        if BRANCHES and torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            self.main = torch.cuda.current_stream()
+            dev = self.main.device
+            self.side = _SIDE_STREAMS.get(dev)
+            if self.side is None:
+                self.side = _SIDE_STREAMS[dev] = torch.cuda.Stream(device=dev)
+            self.side.wait_stream(self.main)                 # fork: the branch joins the capture here
+            self._ctx = torch.cuda.stream(self.side)
+            self._ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.side is not None:
+            self._ctx.__exit__(*exc)
+        return False
+
+    def join(self, *tensors):
+        """Make the main stream wait for the branch; `tensors` = what the branch produced (allocated on its stream)."""
+        if self.side is not None:
+            self.main.wait_stream(self.side)
+            for t in tensors:
+                if t is not None:
+                    t.record_stream(self.main)
+            self.side = None
+
+
+# ---------------------------------------------------------------------------------------------
 def _gn_forward(x, gamma, beta, groups, silu):
     _check(x, gamma, beta)
     S, C, H, W = x.shape

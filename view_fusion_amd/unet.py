@@ -63,13 +63,21 @@ class _ResBlock(nn.Module):
             C1, C = x.shape[1], x.shape[1] + skip.shape[1]
             if not (isinstance(self.res_conv, nn.Conv2d) and ops.cat_fusable(C1, C, x.shape[2] * x.shape[3], self.groups)):
                 x, skip = ops.concat_channels(x, skip), None
+        # the residual 1x1 conv is needed by the block's LAST conv only: a side branch of the captured step (ops.side_branch)
         if skip is not None:
-            a, x1, x2 = ops.group_norm_cat_skip(x, skip, b1["0"].weight, b1["0"].bias, self.groups, silu=True)
-            res = ops.conv1x1_cat(x1, x2, self.res_conv)
-        else:
+            with ops.side_branch() as br:
+                res = ops.conv1x1_cat(x, skip, self.res_conv)
+            a, _, _ = ops.group_norm_cat_skip(x, skip, b1["0"].weight, b1["0"].bias, self.groups, silu=True)
+        elif isinstance(self.res_conv, nn.Identity):
+            br, res = None, x
             a = a_in if a_in is not None else ops.group_norm(x, b1["0"].weight, b1["0"].bias, self.groups, silu=True)
-            res = x if isinstance(self.res_conv, nn.Identity) else ops.conv2d(x, self.res_conv)
+        else:
+            with ops.side_branch() as br:
+                res = ops.conv2d(x, self.res_conv)
+            a = a_in if a_in is not None else ops.group_norm(x, b1["0"].weight, b1["0"].bias, self.groups, silu=True)
         _, a2 = ops.conv2d_gn(a, b1["3"], b2["0"], self.groups, True, view_bias=e)
+        if br is not None:
+            br.join(res)
         if next_gn is None:
             return ops.conv2d(a2, b2["3"], residual=res), None
         return ops.conv2d_gn(a2, b2["3"], next_gn[0], self.groups, next_gn[1], residual=res, want_y=True)
@@ -255,10 +263,11 @@ class UNet(nn.Module):
     def _has_dropout(self):
         return any(isinstance(m, _ResBlock) and m.dropout > 0 for m in self.modules())
 
-    def _forward_inference(self, x, es):
+    def _forward_inference(self, x, es, embed_branch=None):
         """The no-grad forward (sampler): same dataflow as below without the autograd handles; a residual block whose
         output goes straight into another residual block's first GroupNorm (or into the final one) lets its last conv
-        evaluate that GroupNorm too."""
+        evaluate that GroupNorm too.  embed_branch = (ops.side_branch, its tensors): the time-embedding launches, to be
+        joined in front of the first residual block."""
         from . import ops
 
         def gn1_of(layer):            # first GroupNorm of a residual block that consumes its input un-concatenated
@@ -268,6 +277,9 @@ class UNet(nn.Module):
         downs = list(self.downs)
         for i, layer in enumerate(downs):
             if isinstance(layer, _ResAttnBlock):
+                if embed_branch is not None:      # the time-embedding chain ran beside the stem conv: join it here
+                    embed_branch[0].join(*embed_branch[1])
+                    embed_branch = None
                 nxt = downs[i + 1] if i + 1 < len(downs) else self.mid[0]
                 x, a_next = layer.forward_inference(x, next(es), a_in=a_next, next_gn=gn1_of(nxt))
             elif isinstance(layer, _Resample):
@@ -297,14 +309,20 @@ class UNet(nn.Module):
         if torch.is_grad_enabled() and self.final_conv["block"]["3"].weight.requires_grad:
             ops.pack_all(self, x.shape[0])   # training: all 103 conv layers re-packed (one launch per format)
         mlp = self.noise_level_mlp
-        pe = ops.sincos_embedding(time, angle, self.inner_channel)                  # (S,inner)
-        emb = ops.linear(pe, mlp["0"].weight, mlp["0"].bias)
-        emb = ops.linear(ops.swish(emb), mlp["2"].weight, mlp["2"].bias)            # (S,inner)
-        # FeatureWiseAffine of every residual block (unet.py:160-177) in one grouped launch
-        es = iter(ops.time_affine_all(emb, self._affine_layers()))
+        inference = not torch.is_grad_enabled() and not (self.training and self._has_dropout())
 
-        if not torch.is_grad_enabled() and not (self.training and self._has_dropout()):
-            return self._forward_inference(x, es)       # (Dropout active: the general path below applies it)
+        def embed():
+            pe = ops.sincos_embedding(time, angle, self.inner_channel)                  # (S,inner)
+            emb = ops.linear(pe, mlp["0"].weight, mlp["0"].bias)
+            emb = ops.linear(ops.swish(emb), mlp["2"].weight, mlp["2"].bias)            # (S,inner)
+            # FeatureWiseAffine of every residual block (unet.py:160-177) in one grouped launch
+            return ops.time_affine_all(emb, self._affine_layers())
+
+        if inference:                                   # (Dropout active: the general path below applies it)
+            with ops.side_branch() as br:               # five small launches beside the stem conv (captured step)
+                es = list(embed())
+            return self._forward_inference(x, iter(es), (br, es))
+        es = iter(embed())
 
         # feats[i] feeds the next encoder layer AND the decoder: where that next layer is a residual block or a
         # Downsample conv, the decoder takes that layer's handle on its input instead (see _ResBlock.forward, tap):
