@@ -81,6 +81,24 @@ int vf_conv_small_supported(int Cin, int Cout, int H, int W, int KS, int mode);
 int vf_conv_small(const float* x, const float* x2 /*|NULL*/, int C1, const float* w_oihw, const float* bias /*|NULL*/,
                   const float* view_bias /*|NULL*/, const float* residual /*|NULL*/, float* y, int S, int Cin, int Cout,
                   int H, int W, int KS, int mode, void* stream);
+/* The same 3x3 launch with the residual block's 1x1 convolution folded in as extra K (unet.py:238,245:
+ * block2(h) + res_conv(x)):  y = conv3x3(x, w) + bias + view_bias + conv1x1([rx | rx2], rw_oihw) + rbias.
+ * rC = channels of [rx | rx2] (a multiple of 4), the first rC1 of them from rx; rx2 == NULL: all from rx. */
+int vf_conv_small_res(const float* x, const float* w_oihw, const float* bias /*|NULL*/, const float* view_bias /*|NULL*/,
+                      float* y, int S, int Cin, int Cout, int H, int W, const float* rx, const float* rx2 /*|NULL*/,
+                      int rC1, int rC, const float* rw_oihw, const float* rbias /*|NULL*/, void* stream);
+/* The general one-launch form (round 5): GroupNorm(+Swish) around the conv without a GroupNorm launch (unet.py:207-218,
+ * 254: GroupNorm -> Swish -> conv).  in_stats != NULL: x is the RAW GroupNorm input and in_stats the [S][Cin][2] 64-bit
+ * integer sums (x, x^2 in 2^-24 units) left by the launch that produced x; the normalisation is applied while x is
+ * staged (not with x2).  out_stats != NULL ([S][Cout][2] uint64, ZERO before the launch): the launch adds the sums of
+ * y and y^2 per (view, channel) with integer atomics -- order-independent, bit-reproducible.  rx != NULL: as
+ * vf_conv_small_res.  mode 0 only. */
+int vf_conv_small_gn(const float* x, const float* x2 /*|NULL*/, int C1, const float* w_oihw, const float* bias /*|NULL*/,
+                     const float* view_bias /*|NULL*/, const float* residual /*|NULL*/, float* y, int S, int Cin,
+                     int Cout, int H, int W, int KS, const unsigned long long* in_stats /*|NULL*/,
+                     const float* in_gamma, const float* in_beta, int in_groups, float eps, int silu,
+                     unsigned long long* out_stats /*|NULL*/, const float* rx /*|NULL*/, const float* rx2 /*|NULL*/,
+                     int rC1, int rC, const float* rw_oihw, const float* rbias /*|NULL*/, void* stream);
 /* split-K workspace the call above wants at this shape (0 when the natural grid fills the chip) */
 long vf_conv_fwd_ws_floats(int S, int Cin, int Cout, int H, int W, int KS);
 /* 1x1 conv on the channel concatenation [x1 (C1 channels, multiple of 64) | x2] (residual conv of the decoder

@@ -195,6 +195,99 @@ def test_conv_small_sampler_kernel(dev, Cin, Cout, Hin, KS, mode, S):
     assert rel(y0, ref - vb.double()[:, :, None, None] - res.double()) < 2e-6
 
 
+@pytest.mark.parametrize("S", [1, 2])
+@pytest.mark.parametrize("C,H,rC1,rC2", [(64, 64, 64, 64), (64, 64, 128, 64), (128, 32, 64, 0), (128, 32, 192, 128),
+                                         (192, 16, 128, 0), (192, 16, 192, 192), (100, 8, 36, 0), (32, 4, 20, 12)])
+def test_conv_small_with_folded_residual_conv(dev, C, H, rC1, rC2, S):
+    """Round 5: a residual block's last 3x3 conv with the block's residual 1x1 conv folded in as extra K
+    (vf_conv_small_res; reference unet.py:238,245: block2(h) + res_conv(x), x possibly the decoder's never-materialised
+    concatenation) against fp64, through the ops.conv2d(..., res_fold=) call of the no-grad UNet forward."""
+    from view_fusion_amd import ops
+    Cin = C if C % 32 == 0 else 96          # (3x3 small kernel: Cin a multiple of 32; Cout free)
+    conv, resc = torch.nn.Conv2d(Cin, C, 3, padding=1), torch.nn.Conv2d(rC1 + rC2, C, 1)
+    with torch.no_grad():
+        conv.weight.copy_(rnd(C, Cin, 3, 3, seed=5) / math.sqrt(Cin * 9))
+        conv.bias.copy_(rnd(C, seed=6) * 0.1)
+        resc.weight.copy_(rnd(C, rC1 + rC2, 1, 1, seed=15) / math.sqrt(rC1 + rC2))
+        resc.bias.copy_(rnd(C, seed=16) * 0.1)
+    a2, vb = rnd(S, Cin, H, H, seed=7), rnd(S, C, seed=8) * 0.3
+    x1 = rnd(S, rC1, H, H, seed=9)
+    x2 = rnd(S, rC2, H, H, seed=10) if rC2 else None
+    xin = torch.cat([x1, x2], 1) if rC2 else x1
+    ref = (F.conv2d(a2.double(), conv.weight.double(), conv.bias.double(), padding=1) + vb.double()[:, :, None, None]
+           + F.conv2d(xin.double(), resc.weight.double(), resc.bias.double()))
+    conv, resc = conv.to(dev), resc.to(dev)
+    saved = ops.SMALL_CONV_MAX_WGS, ops.SMALL_CONV_MAX_CIN3, ops.SMALL_CONV_MAX_S3
+    ops.SMALL_CONV_MAX_WGS, ops.SMALL_CONV_MAX_CIN3, ops.SMALL_CONV_MAX_S3 = (1 << 30, 1 << 30), 1 << 30, 1 << 30
+    ops.KERNEL_LOG = []
+    try:
+        with torch.no_grad():
+            fold = (resc, x1.to(dev), None if x2 is None else x2.to(dev))
+            y = ops.conv2d(a2.to(dev), conv, view_bias=vb.to(dev), res_fold=fold)
+            y_nb = ops.conv2d(a2.to(dev), conv, res_fold=fold)
+        torch.cuda.synchronize()
+        assert [e[5] for e in ops.KERNEL_LOG] == ["vf_conv_small_res", "vf_conv_small_res"]
+    finally:
+        ops.KERNEL_LOG = None
+        ops.SMALL_CONV_MAX_WGS, ops.SMALL_CONV_MAX_CIN3, ops.SMALL_CONV_MAX_S3 = saved
+    assert rel(y, ref) < 2e-6
+    assert rel(y_nb, ref - vb.double()[:, :, None, None]) < 2e-6
+
+
+@pytest.mark.parametrize("S", [1, 3])
+@pytest.mark.parametrize("C0,C1,C2,H,KS2", [(64, 64, 64, 64, 3), (128, 128, 64, 32, 3), (192, 192, 576, 16, 1),
+                                            (64, 192, 192, 16, 3), (96, 320, 100, 8, 1), (32, 32, 40, 4, 3)])
+def test_conv_small_groupnorm_without_a_launch(dev, C0, C1, C2, H, KS2, S):
+    """Round 5: conv -> GroupNorm(32)+Swish -> conv with NO GroupNorm launch (vf_conv_small_gn): the first conv's
+    epilogue accumulates per-(view, channel) integer sums of its output, the second conv normalises while staging --
+    against fp64 of the reference's Block chain (unet.py:207-218); the sums themselves against fp64 to 2^-24-unit
+    fixed-point accuracy; bit-reproducible across launches (integer atomics)."""
+    from view_fusion_amd import ops
+    conv1, conv2 = torch.nn.Conv2d(C0, C1, 3, padding=1), torch.nn.Conv2d(C1, C2, KS2, padding=KS2 // 2)
+    gn = torch.nn.GroupNorm(32, C1)
+    with torch.no_grad():
+        conv1.weight.copy_(rnd(C1, C0, 3, 3, seed=5) / math.sqrt(C0 * 9))
+        conv1.bias.copy_(rnd(C1, seed=6) * 0.5 + 0.7)               # (a mean well away from zero)
+        conv2.weight.copy_(rnd(C2, C1, KS2, KS2, seed=7) / math.sqrt(C1 * KS2 * KS2))
+        conv2.bias.copy_(rnd(C2, seed=8) * 0.1)
+        gn.weight.copy_(1 + 0.3 * rnd(C1, seed=9))
+        gn.bias.copy_(0.2 * rnd(C1, seed=10))
+    x, vb = rnd(S, C0, H, H, seed=11), rnd(S, C1, seed=12) * 0.3
+    silu = KS2 == 3
+    h_ref = F.conv2d(x.double(), conv1.weight.double(), conv1.bias.double(), padding=1) + vb.double()[:, :, None, None]
+    n_ref = F.group_norm(h_ref, 32, gn.weight.double(), gn.bias.double(), 1e-5)
+    if silu:
+        n_ref = n_ref * torch.sigmoid(n_ref)
+    y_ref = F.conv2d(n_ref, conv2.weight.double(), conv2.bias.double(), padding=KS2 // 2)
+    conv1, conv2, gn = conv1.to(dev), conv2.to(dev), gn.to(dev)
+    saved = ops.SMALL_CONV_MAX_WGS, ops.SMALL_CONV_MAX_CIN3, ops.SMALL_CONV_MAX_S3
+    ops.SMALL_CONV_MAX_WGS, ops.SMALL_CONV_MAX_CIN3, ops.SMALL_CONV_MAX_S3 = (1 << 30, 1 << 30), 1 << 30, 1 << 30
+    ops.STATS = ops.StatsArena(dev, S)
+    ops.KERNEL_LOG = []
+    lazy_default, ops.GN_LAZY = ops.GN_LAZY, True        # (gated experiment, off by default: profiles/r05_sampler.md)
+    try:
+        with torch.no_grad():
+            assert ops.can_apply_gn_on_load(S, conv1, H, H) and ops.can_apply_gn_on_load(S, conv2, H, H)
+            outs = []
+            for _ in range(2):
+                h, st = ops.conv2d(x.to(dev), conv1, view_bias=vb.to(dev), want_stats=True)
+                y = ops.conv2d(ops.LazyGN(h, st, gn, 32, silu), conv2)
+                outs.append((h.clone(), st.clone(), y.clone()))
+        torch.cuda.synchronize()
+        assert [e[5] for e in ops.KERNEL_LOG] == ["vf_conv_small_gn"] * 4
+    finally:
+        ops.KERNEL_LOG, ops.STATS, ops.GN_LAZY = None, None, lazy_default
+        ops.SMALL_CONV_MAX_WGS, ops.SMALL_CONV_MAX_CIN3, ops.SMALL_CONV_MAX_S3 = saved
+    (h, st, y), (h2, st2, y2) = outs
+    assert torch.equal(st, st2) and torch.equal(y, y2)                # order-independent sums: bit-reproducible
+    assert rel(h, h_ref) < 2e-6
+    sums = st.view(S, C1, 2).double().cpu() / 2.0 ** 24
+    hd = h.double().cpu()
+    np.testing.assert_allclose(sums[..., 0].numpy(), hd.sum(dim=(2, 3)).numpy(), rtol=1e-6, atol=2e-4)
+    np.testing.assert_allclose(sums[..., 1].numpy(), (hd * hd).sum(dim=(2, 3)).numpy(), rtol=1e-6, atol=2e-4)
+    assert rel(y, y_ref) < 5e-6, rel(y, y_ref)
+
+
 @pytest.mark.parametrize("S", [1, 4])
 def test_conv_small_cat_and_gn(dev, S):
     """The decoder's 1x1 conv on the never-materialised concatenation, and conv + GroupNorm(+Swish) of the inference

@@ -82,6 +82,9 @@ SIGNATURES = {
     "vf_adam_multi": [_P, _I, _L, _F, _F, _F, _F, _F, _F, _P],
     "vf_conv_small_supported": [_I, _I, _I, _I, _I, _I],
     "vf_conv_small": [_P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "vf_conv_small_res": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _I, _P, _P, _P],
+    "vf_conv_small_gn": [_P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _F, _I, _P, _P, _P, _I, _I,
+                         _P, _P, _P],
     "vf_adam_multi_dev": [_P, _I, _L, _P, _F, _F, _F, _P],
     "vf_adam_set_scalars": [_P, _F, _F, _F, _P],
     "vf_psnr": [_P, _P, _P, _I, _I, _P],

@@ -28,7 +28,47 @@ struct SmallArgs {
     const float* res;
     float* y;
     int S, Cin, C1, Cout, logW, n;     // output map W = H = 1 << logW; 1x1: n = products per wave (multiple of 16)
+    // 3x3 only: the residual 1x1 convolution of the block folded in as extra K (vf_conv_small_res), or rx = null:
+    //   y += rw[co][:] . [rx | rx2][:, pixel] + rbias[co]        (rC channels in all, the first rC1 from rx)
+    const float* rx;
+    const float* rx2;
+    const float* rw;
+    const float* rbias;
+    int rC, rC1, rn;                   // rn = folded products per wave (multiple of 16)
+    // GroupNorm around the conv without a GroupNorm launch (round 5, vf_conv_small_gn):
+    //   ost != null: the launch also accumulates per-(view, output channel) sums of y and y^2 -- what the GroupNorm
+    //                BEHIND this conv needs -- as 64-bit fixed-point integers (2^-24 units) with integer atomics: integer
+    //                addition is associative, so the result does not depend on the order the workgroups arrive in
+    //                (bit-reproducible, unlike float atomics);
+    //   ist != null: x is the RAW input of a GroupNorm(+Swish) whose statistics the producer of x left in ist: the
+    //                staging applies (x - mean_g) * rstd_g * gamma_c + beta_c [, Swish] on the way in.
+    unsigned long long* ost;           // [S][Cout][2], zero before the launch
+    const unsigned long long* ist;     // [S][Cin][2]
+    const float* ig;                   // gamma, beta of the input GroupNorm
+    const float* ib;
+    int icpg, isilu;                   // channels per group
+    float iinv, ieps;                  // 1 / (2^24 * icpg * H * W)
 };
+
+constexpr float SM_FIX = 16777216.f;   // 2^24: fixed-point unit of the statistics
+
+// mean, rstd * gamma, beta of channel c of view s from the producer's integer sums (biased variance, eps inside the
+// square root, like nn.GroupNorm; E[x^2] - mean^2 in fp32 on exactly accumulated sums)
+__device__ __forceinline__ void small_gn_coef(const SmallArgs& a, int s, int c, float& mean, float& scale, float& beta) {
+    const int g0 = (c / a.icpg) * a.icpg;
+    const unsigned long long* p = a.ist + ((size_t)s * a.Cin + g0) * 2;
+    long long s1 = 0, s2 = 0;
+    for (int i = 0; i < a.icpg; ++i) { s1 += (long long)p[2 * i]; s2 += (long long)p[2 * i + 1]; }
+    mean = (float)((double)s1 * (double)a.iinv);
+    const float ex2 = (float)((double)s2 * (double)a.iinv);
+    const float var = fmaxf(ex2 - mean * mean, 0.f);
+    scale = a.ig[c] / sqrtf(var + a.ieps);
+    beta = a.ib[c];
+}
+__device__ __forceinline__ float small_gn_apply(float x, float mean, float scale, float beta, int silu) {
+    const float t = fmaf(x - mean, scale, beta);
+    return silu ? silu_f(t) : t;
+}
 
 constexpr int SM_PX = 16;
 
@@ -47,7 +87,7 @@ struct SmallEpi {
         if (tid < TCO * SM_PX && co < a.Cout) {
             o = ((size_t)s * a.Cout + co) * HW + op;
             float b0 = a.bias ? a.bias[co] : 0.f, b1 = a.vbias ? a.vbias[(size_t)s * a.Cout + co] : 0.f;
-            float r = a.res ? a.res[o] : 0.f;
+            float r = a.res ? a.res[o] : (a.rbias ? a.rbias[co] : 0.f);
             add = (b0 + b1) + r;
         }
     }
@@ -64,11 +104,24 @@ __device__ __forceinline__ void small_epilogue(const SmallArgs& a, float* red, c
 #pragma unroll
         for (int r = 0; r < 4; ++r) rw[(16 * rs + 4 * kk + r) * SM_PX + j] = acc[rs][r];      // lane holds D[4 kk + r][j]
     __syncthreads();
+    float v = 0.f;
     if (ep.o != ~(size_t)0) {
-        float v = red[tid];
+        v = red[tid];
 #pragma unroll
         for (int i = 1; i < 8; ++i) v += red[i * (TCO * SM_PX) + tid];
-        a.y[ep.o] = v + ep.add;
+        v += ep.add;
+        a.y[ep.o] = v;
+    }
+    if (a.ost && tid < TCO * SM_PX) {              // (whole waves: TCO * 16 is a multiple of 64)
+        // sums of this tile's 16 pixels per channel (16 consecutive lanes), then two integer atomics per channel
+        float s1 = v, s2 = v * v;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+        if ((tid & 15) == 0 && ep.o != ~(size_t)0) {
+            unsigned long long* d = a.ost + (ep.o >> (2 * a.logW)) * 2;      // ep.o / HW = s * Cout + co
+            atomicAdd(d, (unsigned long long)__float2ll_rn(s1 * SM_FIX));
+            atomicAdd(d + 1, (unsigned long long)__float2ll_rn(s2 * SM_FIX));
+        }
     }
 }
 
@@ -76,9 +129,11 @@ __device__ __forceinline__ void small_epilogue(const SmallArgs& a, float* red, c
 // quarter kk holds the channels 16 q + 4 kk + (0..3): one 16-byte weight load per lane, the four quarters of a weight
 // row 64 contiguous bytes; B = the lane's pixel of those four channel planes
 constexpr int SM_NB = 8;
+constexpr int SM_GN_MAXC = 1024;       // most input channels of a 1x1 conv with the GroupNorm applied on load
 template <bool CAT>
 __global__ __launch_bounds__(512) void conv1_small_kernel(SmallArgs a) {
     __shared__ float red[8 * 32 * SM_PX];
+    __shared__ float gtab[3 * SM_GN_MAXC];         // input GroupNorm: mean | rstd gamma | beta per channel
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 15, kk = lane >> 4;
     const int HW = 1 << (2 * a.logW);
     const int ptiles = HW / SM_PX, ncot = (a.Cout + 31) / 32;
@@ -89,6 +144,11 @@ __global__ __launch_bounds__(512) void conv1_small_kernel(SmallArgs a) {
     SmallEpi<2> ep;
     ep.fetch(a, s, cot, pt);
     const int K = a.Cin;
+    const bool gn = !CAT && a.ist != nullptr;      // (kernel-uniform)
+    if (gn) {
+        for (int c = tid; c < K; c += 512) small_gn_coef(a, s, c, gtab[c], gtab[SM_GN_MAXC + c], gtab[2 * SM_GN_MAXC + c]);
+        __syncthreads();
+    }
     const int kw = w * a.n + 4 * kk;
     // A rows of this lane (rows past Cout read the last row; their results are never stored)
     const float* wa0 = a.w + (size_t)min(cot * 32 + j, a.Cout - 1) * K;
@@ -112,6 +172,18 @@ __global__ __launch_bounds__(512) void conv1_small_kernel(SmallArgs a) {
                 float v = 0.f;
                 if (ok) v = (CAT && ci >= a.C1) ? xs2[(size_t)(ci - a.C1) * HW] : xs[(size_t)ci * HW];
                 B[4 * q + e] = v;
+            }
+        }
+        if (gn) {
+#pragma unroll
+            for (int q = 0; q < SM_NB; ++q) {
+                const int k = kw + mb + 16 * q;
+                if (mb + 16 * q < a.n && k < K) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        B[4 * q + e] = small_gn_apply(B[4 * q + e], gtab[k + e], gtab[SM_GN_MAXC + k + e],
+                                                      gtab[2 * SM_GN_MAXC + k + e], a.isilu);
+                }
             }
         }
 #pragma unroll
@@ -189,6 +261,11 @@ __global__ __launch_bounds__(512) void conv3_small_kernel(SmallArgs a) {
     f32x4 acc[RS];
 #pragma unroll
     for (int rs = 0; rs < RS; ++rs) acc[rs] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // input GroupNorm applied on load: lane l < cw works out the coefficients of the wave's channel c0 + l once
+    // (cw = Cin / 8 <= 64 channels per wave); the staging below fetches them with v_readlane (the channel is wave-uniform)
+    const bool gn = a.ist != nullptr;              // (kernel-uniform)
+    float gmean = 0.f, gscale = 1.f, gbeta = 0.f;
+    if (gn && lane < cw) small_gn_coef(a, s, c0 + lane, gmean, gscale, gbeta);
     const int nr = (cw + RND - 1) / RND;
     for (int r = 0; r < nr; ++r) {
         const int np = 9 * min(RND, cw - r * RND);     // products of this round (72 or 36)
@@ -198,6 +275,16 @@ __global__ __launch_bounds__(512) void conv3_small_kernel(SmallArgs a) {
         for (int i = 0; i < RND; ++i) {
             const int c = r * RND + i;
             P[i] = (pin && c < cw) ? xp[(size_t)c * HW] : 0.f;
+        }
+        if (gn) {                                  // (the zero padding is padding of the NORMALISED map: stays zero)
+#pragma unroll
+            for (int i = 0; i < RND; ++i) {
+                const int c = min(r * RND + i, cw - 1);
+                const float m_ = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gmean), c));
+                const float s_ = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gscale), c));
+                const float b_ = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gbeta), c));
+                P[i] = (pin && r * RND + i < cw) ? small_gn_apply(P[i], m_, s_, b_, a.isilu) : 0.f;
+            }
         }
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
@@ -227,6 +314,48 @@ __global__ __launch_bounds__(512) void conv3_small_kernel(SmallArgs a) {
             }
         }
         __builtin_amdgcn_wave_barrier();           // the next round's patch overwrites what this round read
+    }
+    // ---- the block's residual 1x1 convolution as extra K (reference unet.py:238,245: block2(...) + res_conv(x)): the
+    // wave's share of the rC residual-input channels, products dealt as in conv1_small_kernel (one 16-byte weight load
+    // per lane and 16 products, B = the lane's pixel of four channel planes, straight from global memory -- a tile's 16
+    // pixels are consecutive in every map geometry this kernel takes).  One graph node less per residual block.
+    if (a.rx) {
+        constexpr int NBR = 4;
+        const float* wr[RS];
+#pragma unroll
+        for (int rs = 0; rs < RS; ++rs) wr[rs] = a.rw + (size_t)min(cot * TCO + 16 * rs + j, a.Cout - 1) * a.rC;
+        const float* xs = a.rx + (size_t)s * a.rC1 * HW + p0 + j;
+        const float* xs2 = a.rx2 ? a.rx2 + (size_t)s * (a.rC - a.rC1) * HW + p0 + j : xs;
+        const int kw = w * a.rn + 4 * kk;
+        for (int mb = 0; mb < a.rn; mb += 16 * NBR) {
+            f32x4 A[RS][NBR];
+            float B[4 * NBR];
+#pragma unroll
+            for (int q = 0; q < NBR; ++q) {
+                const int k = kw + mb + 16 * q;
+                const bool ok = mb + 16 * q < a.rn && k < a.rC;
+#pragma unroll
+                for (int rs = 0; rs < RS; ++rs)
+                    A[rs][q] = ok ? *reinterpret_cast<const f32x4*>(wr[rs] + k) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int ci = k + e;
+                    float v = 0.f;
+                    if (ok) v = ci >= a.rC1 ? xs2[(size_t)(ci - a.rC1) * HW] : xs[(size_t)ci * HW];
+                    B[4 * q + e] = v;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < NBR; ++q) {
+                if (mb + 16 * q < a.rn) {          // (wave-uniform)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int rs = 0; rs < RS; ++rs)
+                            acc[rs] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[rs][q][e], B[4 * q + e], acc[rs], 0, 0, 0);
+                }
+            }
+        }
     }
     __syncthreads();                               // the reduction buffer overlays the patches
     small_epilogue<RS>(a, lds, acc, ep);
@@ -260,15 +389,36 @@ int vf_conv_small_supported(int Cin, int Cout, int H, int W, int KS, int mode) {
 
 // y = conv(x [| x2 on channels C1..], w) + bias + view_bias + residual at the sampler's sizes (stride 1, H = W).
 // w: the unpacked OIHW parameter.  One launch, no workspace.
-int vf_conv_small(const float* x, const float* x2, int C1, const float* w, const float* bias, const float* view_bias,
-                  const float* residual, float* y, int S, int Cin, int Cout, int H, int W, int KS, int mode, void* stream) {
+struct SmallGn {                       // GroupNorm on the input (applied on load) / statistics of the output
+    const unsigned long long* ist = nullptr;
+    const float* ig = nullptr;
+    const float* ib = nullptr;
+    int groups = 0, silu = 0;
+    float eps = 0.f;
+    unsigned long long* ost = nullptr;
+};
+
+static int conv_small_launch(const float* x, const float* x2, int C1, const float* w, const float* bias,
+                             const float* view_bias, const float* residual, float* y, int S, int Cin, int Cout, int H,
+                             int W, int KS, int mode, const float* rx, const float* rx2, int rC1, int rC,
+                             const float* rw, const float* rbias, void* stream, const SmallGn& gn = SmallGn()) {
     if (!vf_conv_small_supported(Cin, Cout, H, W, KS, mode) || (x2 && (KS != 1 || C1 <= 0 || C1 >= Cin)))
+        return (int)hipErrorInvalidValue;
+    if (gn.ist && (x2 || !gn.ig || !gn.ib || gn.groups <= 0 || Cin % gn.groups != 0 || (KS == 1 && Cin > SM_GN_MAXC)
+                   || (KS == 3 && Cin / 8 > 64)))
+        return (int)hipErrorInvalidValue;
+    if (rx && (KS != 3 || residual || !rw || rC < 4 || rC % 4 != 0 || (rx2 ? (rC1 <= 0 || rC1 >= rC) : rC1 != rC)))
         return (int)hipErrorInvalidValue;
     if (S <= 0) return 0;
     SmallArgs a;
     a.x = x; a.x2 = x2; a.w = w; a.bias = bias; a.vbias = view_bias; a.res = residual; a.y = y;
     a.S = S; a.Cin = Cin; a.C1 = x2 ? C1 : Cin; a.Cout = Cout; a.logW = ilog2(W);
     a.n = (((Cin + 7) / 8) + 15) & ~15;
+    a.rx = rx; a.rx2 = rx2; a.rw = rw; a.rbias = rbias; a.rC = rC; a.rC1 = rC1;
+    a.rn = rx ? ((((rC + 7) / 8) + 15) & ~15) : 0;
+    a.ost = gn.ost; a.ist = gn.ist; a.ig = gn.ig; a.ib = gn.ib;
+    a.icpg = gn.ist ? Cin / gn.groups : 1; a.isilu = gn.silu; a.ieps = gn.eps;
+    a.iinv = gn.ist ? (float)(1.0 / (16777216.0 * (double)a.icpg * (double)H * (double)W)) : 0.f;
     hipStream_t st = (hipStream_t)stream;
     if (KS == 1) {
         const long grid = (long)S * ((Cout + 31) / 32) * (H * W / SM_PX);
@@ -279,6 +429,42 @@ int vf_conv_small(const float* x, const float* x2, int C1, const float* w, const
     // 32-channel tiles when they alone fill the chip, 16-channel tiles (twice the workgroups) otherwise
     const long wgs32 = (long)S * ((Cout + 31) / 32) * (H * W / SM_PX);
     return wgs32 >= 256 ? launch_conv3<2>(a, st) : launch_conv3<1>(a, st);
+}
+
+int vf_conv_small(const float* x, const float* x2, int C1, const float* w, const float* bias, const float* view_bias,
+                  const float* residual, float* y, int S, int Cin, int Cout, int H, int W, int KS, int mode, void* stream) {
+    return conv_small_launch(x, x2, C1, w, bias, view_bias, residual, y, S, Cin, Cout, H, W, KS, mode, nullptr, nullptr, 0,
+                             0, nullptr, nullptr, stream);
+}
+
+// A residual block's LAST convolution and its residual 1x1 convolution in one launch (3x3, stride 1):
+//   y = conv3x3(x, w) + bias + view_bias + conv1x1([rx | rx2], rw) + rbias
+// rw: the unpacked (Cout, rC, 1, 1) parameter, rC % 4 == 0; rx2 == NULL: all rC channels from rx (rC1 = rC).
+int vf_conv_small_res(const float* x, const float* w, const float* bias, const float* view_bias, float* y, int S, int Cin,
+                      int Cout, int H, int W, const float* rx, const float* rx2, int rC1, int rC, const float* rw,
+                      const float* rbias, void* stream) {
+    if (!rx) return (int)hipErrorInvalidValue;
+    return conv_small_launch(x, nullptr, 0, w, bias, view_bias, nullptr, y, S, Cin, Cout, H, W, 3, 0, rx, rx2,
+                             rx2 ? rC1 : rC, rC, rw, rbias, stream);
+}
+
+// The general form (round 5): the two calls above plus GroupNorm without a GroupNorm launch on either side.
+//   in_stats  != NULL: x is the raw input of GroupNorm(in_groups, eps)[+Swish]; in_stats = the [S][Cin][2] integer sums
+//                      (y, y^2 in 2^-24 units) that the launch which produced x accumulated; (x - mean) rstd gamma + beta
+//                      [, Swish] is applied while x is staged.  Not with x2.
+//   out_stats != NULL: [S][Cout][2] 64-bit integers, ZERO before the launch; the launch adds the sums of y and y^2 of
+//                      every (view, channel) with integer atomics (order-independent: bit-reproducible).
+//   rx != NULL (3x3): the residual 1x1 conv folded in, as vf_conv_small_res.
+int vf_conv_small_gn(const float* x, const float* x2, int C1, const float* w, const float* bias, const float* view_bias,
+                     const float* residual, float* y, int S, int Cin, int Cout, int H, int W, int KS,
+                     const unsigned long long* in_stats, const float* in_gamma, const float* in_beta, int in_groups,
+                     float eps, int silu, unsigned long long* out_stats, const float* rx, const float* rx2, int rC1,
+                     int rC, const float* rw, const float* rbias, void* stream) {
+    SmallGn gn;
+    gn.ist = in_stats; gn.ig = in_gamma; gn.ib = in_beta; gn.groups = in_groups; gn.silu = silu; gn.eps = eps;
+    gn.ost = out_stats;
+    return conv_small_launch(x, x2, C1, w, bias, view_bias, residual, y, S, Cin, Cout, H, W, KS, 0, rx, rx2,
+                             rx ? (rx2 ? rC1 : rC) : 0, rx ? rC : 0, rw, rbias, stream, gn);
 }
 
 }  // extern "C"

@@ -796,6 +796,117 @@ def _conv_small(x, x2, weight, bias, view_bias, residual, S, Cin, Cout, H, W, KS
     return y
 
 
+RES_FOLD = os.environ.get("VF_RES_FOLD", "1") == "1"
+# Round 5, sampler: GroupNorm without a GroupNorm launch between two one-launch convs -- the producer's epilogue leaves
+# per-(view, channel) integer sums of its output, the consumer normalises while it stages its input (vf_conv_small_gn).
+# MEASURED (profiles/r05_sampler.md): 171 -> 127 launcher calls per reverse step at B=1 N=1, parity green -- and the step
+# gets SLOWER, 1.50 -> 1.56 ms: inside a replayed chain a GroupNorm launch costs 2.7-4 us, the statistics + apply-on-load
+# cost the two convs 2.4-5.5 us on the 32x32 / 16x16 / 8x8 maps and 14.7 us on the 64x64 maps (256 workgroups per
+# channel hammer the same atomics).  OFF by default; VF_GN_LAZY=1 turns it on.
+GN_LAZY = os.environ.get("VF_GN_LAZY", "0") == "1"
+
+
+class LazyGN:
+    """GroupNorm(+Swish) that has not been evaluated: the raw input `x`, the integer channel sums `stats` ([S][C][2]
+    int64) its producer accumulated, and the norm (`gn` holder, `groups`, `silu`).  Only a conv that
+    can_apply_gn_on_load() may consume it; anybody else calls materialize()."""
+    __slots__ = ("x", "stats", "gn", "groups", "silu")
+
+    def __init__(self, x, stats, gn, groups, silu):
+        self.x, self.stats, self.gn, self.groups, self.silu = x, stats, gn, groups, bool(silu)
+
+    @property
+    def shape(self):
+        return self.x.shape
+
+    def materialize(self):
+        return group_norm(self.x, self.gn.weight, self.gn.bias, self.groups, self.silu)
+
+
+class StatsArena:
+    """One zeroed int64 buffer per UNet forward (ONE fill launch) from which the producers' statistics are carved."""
+
+    def __init__(self, device, S, channels=24576):
+        self.device, self.cap, self.buf, self.used = device, S * channels * 2, None, 0
+
+    def take(self, S, C):
+        n = S * C * 2
+        if self.buf is None:          # (first use: a forward whose convs all run the large kernels never pays for it)
+            self.buf = torch.zeros(self.cap, dtype=torch.int64, device=self.device)
+        if self.used + n > self.cap:
+            return None
+        v = self.buf[self.used:self.used + n]
+        self.used += n
+        return v
+
+
+STATS = None          # the arena of the running no-grad UNet forward (set by UNet._forward_inference)
+
+
+def can_apply_gn_on_load(S, layer, H, W):
+    """May `layer` (an nn.Conv2d holder, stride 1, output map H x W) take a LazyGN input?  (also: can it leave statistics)"""
+    if not (GN_LAZY and STATS is not None and not torch.is_grad_enabled() and isinstance(layer, torch.nn.Conv2d)):
+        return False
+    Cout, Cin, KS, _ = layer.weight.shape
+    if layer.stride != (1, 1) or not use_small_conv(S, Cin, Cout, H, W, KS, 0):
+        return False
+    return Cin <= 1024 if KS == 1 else Cin // 8 <= 64
+
+
+def _conv_small_gn(x, layer, view_bias=None, residual=None, res_fold=None, want_stats=False):
+    """The general one-launch conv of the sampler: x a tensor or a LazyGN, optional folded residual conv, optional
+    statistics of the output.  -> y, or (y, stats) with want_stats (stats None if the arena is full)."""
+    lazy = x if isinstance(x, LazyGN) else None
+    xt = lazy.x if lazy is not None else x
+    S, Cin, H, W = xt.shape
+    Cout, _, KS, _ = layer.weight.shape
+    wd = layer.weight.detach()
+    _check(xt, wd, layer.bias, view_bias, residual)
+    y = torch.empty(S, Cout, H, W, device=xt.device, dtype=torch.float32)
+    stats = STATS.take(S, Cout) if (want_stats and STATS is not None) else None
+    rl = rx = rx2 = rwd = None
+    rC = rC1 = 0
+    if res_fold is not None:
+        rl, rx, rx2 = res_fold
+        rwd = rl.weight.detach()
+        rC, rC1 = rl.weight.shape[1], rx.shape[1]
+        assert residual is None and KS == 3 and rC1 + (rx2.shape[1] if rx2 is not None else 0) == rC
+        _check(rx, rx2, rwd, rl.bias)
+    if lazy is not None:
+        _check(lazy.gn.weight, lazy.gn.bias)
+        assert lazy.stats is not None and lazy.stats.numel() == S * Cin * 2
+    _launch("conv_fwd", 2.0 * S * Cout * (Cin * KS * KS + rC) * H * W, "vf_conv_small_gn", _ptr(xt), None, 0, _ptr(wd),
+            _ptr(layer.bias), _ptr(view_bias), _ptr(residual), _ptr(y), S, Cin, Cout, H, W, KS,
+            ctypes.c_void_p(lazy.stats.data_ptr()) if lazy is not None else None,
+            _ptr(lazy.gn.weight) if lazy is not None else None, _ptr(lazy.gn.bias) if lazy is not None else None,
+            lazy.groups if lazy is not None else 0, 1e-5, int(lazy.silu) if lazy is not None else 0,
+            ctypes.c_void_p(stats.data_ptr()) if stats is not None else None, _ptr(rx), _ptr(rx2), rC1, rC, _ptr(rwd),
+            _ptr(rl.bias) if rl is not None else None, _stream(), tag=(Cin, Cout, H, KS, 0))
+    return (y, stats) if want_stats else y
+
+
+def can_fold_residual(S, C, H, W, res_layer):
+    """Inference: may a residual block's last 3x3 conv (C -> C on an H x W map) take its residual 1x1 conv `res_layer`
+    along as extra K (vf_conv_small_res: one launch instead of two)?  Only where that conv runs the one-launch kernel."""
+    return (RES_FOLD and not torch.is_grad_enabled() and isinstance(res_layer, torch.nn.Conv2d)
+            and res_layer.weight.shape[1] % 4 == 0 and use_small_conv(S, C, C, H, W, 3, 0))
+
+
+def _conv_small_res(x, layer, view_bias, res_layer, rx, rx2):
+    S, Cin, H, W = x.shape
+    Cout = layer.weight.shape[0]
+    rC = res_layer.weight.shape[1]
+    rC1 = rx.shape[1]
+    assert rC1 + (rx2.shape[1] if rx2 is not None else 0) == rC and res_layer.weight.shape[0] == Cout
+    wd, rwd = layer.weight.detach(), res_layer.weight.detach()
+    _check(x, wd, rwd, layer.bias, view_bias, rx, rx2, res_layer.bias)
+    y = torch.empty(S, Cout, H, W, device=x.device, dtype=torch.float32)
+    _launch("conv_fwd", 2.0 * S * Cout * (Cin * 9 + rC) * H * W, "vf_conv_small_res", _ptr(x), _ptr(wd), _ptr(layer.bias),
+            _ptr(view_bias), _ptr(y), S, Cin, Cout, H, W, _ptr(rx), _ptr(rx2), rC1, rC, _ptr(rwd), _ptr(res_layer.bias),
+            _stream(), tag=(Cin, Cout, H, 3, 0))
+    return y
+
+
 class _Conv2dFn(torch.autograd.Function):
     """tap (stride-2 convs of the encoder): also return a handle on the INPUT x for the decoder's skip connection,
     whose gradient is then added in the dgrad kernel's epilogue instead of by an autograd add (as _GroupNormSkipFn
@@ -1011,7 +1122,7 @@ def conv1x1_cat(x1, x2, layer):
     return _Conv1x1CatFn.apply(x1, x2, layer.weight, layer.bias, layer, training)
 
 
-def conv2d(x, layer, view_bias=None, residual=None, mode="same", twin=None, tap=False):
+def conv2d(x, layer, view_bias=None, residual=None, mode="same", twin=None, tap=False, res_fold=None, want_stats=False):
     """3x3 (pad 1) or 1x1 convolution with the parameters of `layer` (an nn.Conv2d holder).
     tap=True: returns (y, x') with x' a handle on x for a second consumer (see _Conv2dFn).
 
@@ -1024,10 +1135,17 @@ def conv2d(x, layer, view_bias=None, residual=None, mode="same", twin=None, tap=
         Cout, _, KS, _ = layer.weight.shape
         m = _MODES[mode]
         H, W = (Hi // 2, Wi // 2) if m == 1 else ((Hi * 2, Wi * 2) if m == 2 else (Hi, Wi))
+        if isinstance(x, LazyGN) or want_stats:      # (only offered where can_apply_gn_on_load() said so)
+            assert m == 0 and not tap
+            return _conv_small_gn(x, layer, view_bias, residual, res_fold, want_stats)
+        if res_fold is not None:          # (res_layer, rx, rx2 | None): only offered where can_fold_residual() said so
+            assert residual is None and not tap
+            return _conv_small_res(x, layer, view_bias, *res_fold)
         if use_small_conv(S, Cin, Cout, H, W, KS, m):
             _check(x, layer.bias, view_bias, residual)
             y = _conv_small(x, None, layer.weight, layer.bias, view_bias, residual, S, Cin, Cout, H, W, KS, m)
             return (y, x) if tap else y
+    assert res_fold is None and not want_stats and not isinstance(x, LazyGN)
     training = torch.is_grad_enabled() and layer.weight.requires_grad
     if tap and torch.is_grad_enabled():
         return _Conv2dFn.apply(x, layer.weight, layer.bias, view_bias, residual, layer, mode, training, twin, True)
@@ -1035,7 +1153,7 @@ def conv2d(x, layer, view_bias=None, residual=None, mode="same", twin=None, tap=
     return (y, x) if tap else y
 
 
-def conv2d_gn(x, layer, gn, groups, silu, view_bias=None, residual=None, mode="same", want_y=False):
+def conv2d_gn(x, layer, gn, groups, silu, view_bias=None, residual=None, mode="same", want_y=False, res_fold=None):
     """Inference only (no autograd): (y | None, a) with y = conv2d(x, layer, view_bias, residual, mode) and
     a = [Swish](GroupNorm(gn.weight, gn.bias, groups)(y)).  Where the conv runs split-K (small S: the sampler) the
     GroupNorm is evaluated by the conv's reduce launch -- one kernel instead of two, and y is only written if `want_y`;
@@ -1045,12 +1163,14 @@ def conv2d_gn(x, layer, gn, groups, silu, view_bias=None, residual=None, mode="s
     m = _MODES[mode]
     H, W = (Hi // 2, Wi // 2) if m == 1 else ((Hi * 2, Wi * 2) if m == 2 else (Hi, Wi))
     lib = _lib.load()
-    fused = (not torch.is_grad_enabled() and not use_winograd(S, Cin, Cout, H, W, KS, m, False) and not _use_b3(KS, m, H * W)
+    fused = (not isinstance(x, LazyGN)
+             and not torch.is_grad_enabled() and not use_winograd(S, Cin, Cout, H, W, KS, m, False) and not _use_b3(KS, m, H * W)
              and not use_small_conv(S, Cin, Cout, H, W, KS, m)      # (one conv launch + the GroupNorm launch instead)
              and lib.vf_conv_fwd_ws_floats(S, Cin, Cout, H, W, KS) > 0)
     if not fused:
-        y = conv2d(x, layer, view_bias=view_bias, residual=residual, mode=mode)
+        y = conv2d(x, layer, view_bias=view_bias, residual=residual, mode=mode, res_fold=res_fold)
         return y, group_norm(y, gn.weight, gn.bias, groups, silu)
+    assert res_fold is None
     _check(x, layer.bias, view_bias, residual, gn.weight, gn.bias)
     y = torch.empty(S, Cout, H, W, device=x.device, dtype=torch.float32)
     a = torch.empty_like(y)
