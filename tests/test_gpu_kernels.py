@@ -503,10 +503,12 @@ def test_linear_swish_embed(dev):
     assert float((got.cpu() - ref).abs().max()) < 2e-6
 
 
-@pytest.mark.parametrize("C,H,S", [(192, 16, 3), (320, 8, 3), (64, 8, 3), (192, 16, 56), (96, 16, 53)])
+@pytest.mark.parametrize("C,H,S", [(192, 16, 3), (320, 8, 3), (64, 8, 3), (192, 16, 56), (96, 16, 53), (64, 16, 1),
+                                   (192, 16, 17)])
 def test_attention_fwd_bwd(dev, C, H, S):
-    """S <= 52 at L=256 and every L=64 call run the key-split kernel (32 queries per workgroup, one wave per 32
-    keys); more views at L=256 run the 128-query kernel (the training shape)."""
+    """S <= 16 at L=256 (C a multiple of 64) runs the 16-query kernel of round 5 (the sampler's), 17 <= S <= 52 and
+    every L=64 call the key-split kernel (32 queries per workgroup, one wave per 32 keys); more views at L=256 run the
+    128-query kernel (the training shape).  All three write the probabilities for the backward pass here."""
     from view_fusion_amd import ops
     L = H * H
     qkv, gy = rnd(S, 3 * C, H, H, seed=1) * 2, rnd(S, C, H, H, seed=2)
@@ -521,7 +523,8 @@ def test_attention_fwd_bwd(dev, C, H, S):
     assert rel(qg.grad, qc.grad) < 5e-5
 
 
-@pytest.mark.parametrize("C,H,S", [(192, 16, 2), (320, 8, 2), (32, 32, 2), (192, 16, 12), (192, 16, 40), (192, 16, 60), (320, 8, 40)])
+@pytest.mark.parametrize("C,H,S", [(192, 16, 2), (320, 8, 2), (32, 32, 2), (192, 16, 12), (192, 16, 40), (192, 16, 60), (320, 8, 40),
+                                   (320, 16, 16), (192, 16, 1), (96, 16, 5)])
 def test_attention_inference_path(dev, C, H, S):
     """no-grad call: fused kernels without the probability write (L=64/256, both view-count regimes) / generic
     path (L=1024)."""

@@ -363,6 +363,146 @@ __global__ __launch_bounds__(L / 32 * 64) void attn_fwd_split_kernel(const float
 #undef VF_AS_LV1
 }
 
+// Very few views (the sampler at B = 1: S <= 16 stacked views), L = 256 (round 5).  In-kernel clocks of the 32-query kernel
+// above at S = 1 (tools/attn_split_stamps.py) show what its 22 us are: eight workgroups = eight compute units do ALL the
+// work, and each of their SIMDs has 2 x (96 + 96) MFMAs of 64 cycles to issue -- 24.6 k cycles = 10 us of pure matrix
+// issue, whatever the staging scheme (LDS chunks, a three-deep register ring, operands straight from global memory, all
+// eight workgroups of a view on one XCD: the score phase took 19-21 k cycles every time).  The only way down is MORE
+// compute units per view: 16 queries per workgroup -> 16 workgroups per view, on v_mfma_f32_16x16x4_f32:
+//   D[16 x 16] += A[16 x 4] B[4 x 16];  lane l: j = l % 16, kk = l / 16;  A[row j][k kk], B[k kk][col j], D[row 4 kk + r][col j]
+//   1. S^T tile: A = K^T (rows = 16 keys, k = 4 channels), B = Q (cols = 16 queries); wave w owns keys [32 w, 32 w + 32) =
+//      two tiles; both operands are 4-byte loads STRAIGHT from global memory / L2 (for a fixed step the 16 lanes of a
+//      quarter read 64 consecutive bytes of one channel row; a wave's K columns are its own), one block of 16 steps ahead
+//      of the MFMAs -- no LDS, no barrier in this phase;
+//   2. softmax over the 256 keys of the lane's query: 8 registers, two cross-quarter shuffles, then across the waves
+//      through LDS (fixed order);
+//   3. P -> LDS as [key / 4][query][key % 4]: the lane's four accumulator rows are four consecutive keys = ONE
+//      ds_write_b128, and the same float4 is the B operand of four consecutive MFMAs of step 4;
+//   4. O tile (16 channels x 16 queries) = V P^T over a key half: 2 C / 16 items of 32 MFMAs, item i = w + 8 r of wave w
+//      (every SIMD carries the same number); A = one float4 of V per four MFMAs (k order = 16 blk + 4 kk + i); the two
+//      halves of a tile are computed by waves 2k, 2k + 1 and summed through LDS in a fixed order.
+// C a multiple of 64.  With many views this kernel would stream K and V 16 times per view: it is the sampler's kernel.
+__global__ __launch_bounds__(512) void attn_fwd_q16_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                           float* __restrict__ P, int C, float alpha) {
+    constexpr int L = 256, NW = 8, QB = 16, PF = 16;
+    __shared__ __attribute__((aligned(16))) float Pl[(L / 4) * QB * 4];      // [key quad 64][query 16][4]
+    __shared__ float red[2][NW][QB];
+    __shared__ __attribute__((aligned(16))) float oxs[NW / 2][4][64];        // partial O tiles of the upper key halves
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int j = lane & 15, kk = lane >> 4;
+    const int b = blockIdx.y, q0 = blockIdx.x * QB;
+    const float* qb = qkv + (size_t)b * 3 * C * L;
+    const float* kb = qb + (size_t)C * L;
+    const float* vb = qb + (size_t)2 * C * L;
+
+    // ---- 1. scores ----
+    const float* kcol = kb + (size_t)kk * L + 32 * wid + j;          // step s: channel 4 s + kk
+    const float* qcol = qb + (size_t)kk * L + q0 + j;
+    const int nblk = C / (4 * PF);
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+    float kA[PF], kB[PF], qA[PF], lA[PF], lB[PF], rA[PF];            // two register sets: (k tile 0, k tile 1, q) x 2
+#define VF_Q16_LOAD(K0, K1, QD, BLK)                                                                          \
+    { const size_t o_ = (size_t)min((BLK), nblk - 1) * (4 * PF) * L;     /* (past the end: re-read, unused) */   \
+      _Pragma("unroll") for (int s = 0; s < PF; ++s) {                                                         \
+          K0[s] = kcol[o_ + (size_t)(4 * s) * L]; K1[s] = kcol[o_ + (size_t)(4 * s) * L + 16];                  \
+          QD[s] = qcol[o_ + (size_t)(4 * s) * L]; } }
+#define VF_Q16_MMA(K0, K1, QD)                                                                                \
+    { _Pragma("unroll") for (int s = 0; s < PF; ++s) {                                                         \
+          s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(K0[s], QD[s], s0, 0, 0, 0);                                 \
+          s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(K1[s], QD[s], s1, 0, 0, 0); } }
+    VF_Q16_LOAD(kA, kB, qA, 0);
+    for (int blk = 0; blk < nblk; blk += 2) {
+        VF_Q16_LOAD(lA, lB, rA, blk + 1);
+        VF_Q16_MMA(kA, kB, qA);
+        if (blk + 1 < nblk) {
+            VF_Q16_LOAD(kA, kB, qA, blk + 2);
+            VF_Q16_MMA(lA, lB, rA);
+        }
+    }
+#undef VF_Q16_LOAD
+#undef VF_Q16_MMA
+
+    // first V item of this wave: requested now, lands during the softmax.  item i -> channel tile i / 2, key half i % 2
+    const int nitem = 2 * (C / 16);                                  // a multiple of 8 (C a multiple of 64)
+    float4 va0, va1, va2, va3, va4, va5, va6, va7, vn0, vn1, vn2, vn3, vn4, vn5, vn6, vn7;
+#define VF_Q16_LV1(V, G, SRC) V##G = *reinterpret_cast<const float4*>((SRC) + 16 * (G));
+#define VF_Q16_LOADV(V, ITEM) { const int it_ = min((ITEM), nitem - 1);                                        \
+        const float* src_ = vb + (size_t)((it_ >> 1) * 16 + j) * L + 128 * (it_ & 1) + 4 * kk;                  \
+        VF_Q16_LV1(V, 0, src_) VF_Q16_LV1(V, 1, src_) VF_Q16_LV1(V, 2, src_) VF_Q16_LV1(V, 3, src_)             \
+        VF_Q16_LV1(V, 4, src_) VF_Q16_LV1(V, 5, src_) VF_Q16_LV1(V, 6, src_) VF_Q16_LV1(V, 7, src_) }
+    VF_Q16_LOADV(va, wid);
+
+    // ---- 2. softmax over all keys of the lane's query ----
+    float mx = fmaxf(fmaxf(fmaxf(s0[0], s0[1]), fmaxf(s0[2], s0[3])), fmaxf(fmaxf(s1[0], s1[1]), fmaxf(s1[2], s1[3])));
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    if (kk == 0) red[0][wid][j] = mx;
+    __syncthreads();
+    mx = red[0][0][j];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) mx = fmaxf(mx, red[0][w][j]);
+    const float c2 = alpha * 1.44269504088896341f, mc = mx * c2;     // exp(alpha (s - max)) = 2^(c s - c max)
+    float sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        s0[r] = __builtin_amdgcn_exp2f(fmaf(s0[r], c2, -mc));
+        s1[r] = __builtin_amdgcn_exp2f(fmaf(s1[r], c2, -mc));
+        sum += s0[r] + s1[r];
+    }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    if (kk == 0) red[1][wid][j] = sum;
+    __syncthreads();
+    sum = red[1][0][j];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) sum += red[1][w][j];
+    const float inv = 1.0f / sum;
+    s0 *= inv;
+    s1 *= inv;
+
+    // ---- 3. P -> LDS [key / 4][query][key % 4] (+ global): tile t of wave w = keys 32 w + 16 t + 4 kk + r ----
+    *reinterpret_cast<f32x4*>(Pl + ((8 * wid + kk) * QB + j) * 4) = s0;
+    *reinterpret_cast<f32x4*>(Pl + ((8 * wid + 4 + kk) * QB + j) * 4) = s1;
+    if (P) {
+        float* pr = P + ((size_t)b * L + q0 + j) * L + 32 * wid + 4 * kk;
+        *reinterpret_cast<f32x4*>(pr) = s0;
+        *reinterpret_cast<f32x4*>(pr + 16) = s1;
+    }
+    __syncthreads();
+
+    // ---- 4. O tile = V[tile] P^T over a key half ----
+    for (int base = 0; base < nitem; base += NW) {
+        const int it = base + wid, t = it >> 1, h = it & 1;
+        VF_Q16_LOADV(vn, it + NW);                                   // the wave's next item (clamped)
+        f32x4 pb[8];
+#pragma unroll
+        for (int g = 0; g < 8; ++g) pb[g] = *reinterpret_cast<const f32x4*>(Pl + ((32 * h + 4 * g + kk) * QB + j) * 4);
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#define VF_Q16_PV(G) {                                                                                        \
+        o = __builtin_amdgcn_mfma_f32_16x16x4f32(va##G.x, pb[G][0], o, 0, 0, 0);                                  \
+        o = __builtin_amdgcn_mfma_f32_16x16x4f32(va##G.y, pb[G][1], o, 0, 0, 0);                                  \
+        o = __builtin_amdgcn_mfma_f32_16x16x4f32(va##G.z, pb[G][2], o, 0, 0, 0);                                  \
+        o = __builtin_amdgcn_mfma_f32_16x16x4f32(va##G.w, pb[G][3], o, 0, 0, 0); }
+        VF_Q16_PV(0) VF_Q16_PV(1) VF_Q16_PV(2) VF_Q16_PV(3) VF_Q16_PV(4) VF_Q16_PV(5) VF_Q16_PV(6) VF_Q16_PV(7)
+#undef VF_Q16_PV
+        va0 = vn0; va1 = vn1; va2 = vn2; va3 = vn3; va4 = vn4; va5 = vn5; va6 = vn6; va7 = vn7;
+        if (h == 1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) oxs[wid >> 1][r][lane] = o[r];
+        }
+        __syncthreads();
+        if (h == 0) {
+            float* ob = out + ((size_t)b * C + t * 16 + 4 * kk) * L + q0 + j;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ob[(size_t)r * L] = o[r] + oxs[wid >> 1][r][lane];
+        }
+        if (base + NW < nitem) __syncthreads();                      // the exchange slots are reused by the next round
+    }
+#undef VF_Q16_LOADV
+#undef VF_Q16_LV1
+}
+
 }  // namespace
 
 extern "C" {
@@ -377,7 +517,11 @@ int vf_attention_fwd(const float* qkv, float* out, float* P, int S, int C, int L
     // few views (sampler): the key-split kernel cuts the per-wave MFMA chain 8-fold; many views (training): it
     // would re-stream K and V once per 32 queries (L2-bound), the 128-query kernel wins from S ~ 55 on (key-split
     // 44.1 us at S = 44, 128-query 58.9 us at S = 48)
-    if (L == 256 && S <= 52)
+    // (VF_ATTN_Q16=0: tuning aid, the 32-query kernel at every small S)
+    static const bool q16 = !(getenv("VF_ATTN_Q16") && getenv("VF_ATTN_Q16")[0] == '0');
+    if (L == 256 && S <= 16 && C % 64 == 0 && q16)
+        hipLaunchKernelGGL(attn_fwd_q16_kernel, dim3(16, S), dim3(512), 0, st, qkv, out, P, C, alpha);
+    else if (L == 256 && S <= 52)
         hipLaunchKernelGGL(attn_fwd_split_kernel<256>, dim3(8, S), dim3(512), 0, st, qkv, out, P, C, alpha);
     else if (L == 256)
         hipLaunchKernelGGL(attn_fwd_kh_kernel, dim3(2, S), dim3(512), 0, st, qkv, out, P, C, alpha);
