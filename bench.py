@@ -164,7 +164,7 @@ def pmc_launches():
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_pmc_traffic_kib_per_launch.json")), reverse=True):
         try:
             tab = json.load(open(path))
-            return {k: float(d.get("launches", 0)) for k, d in tab.items()}
+            return {k: float(d.get("launches", 0)) for k, d in tab.items() if not k.startswith("_")}
         except (OSError, ValueError, AttributeError):
             continue
     return {}
@@ -179,8 +179,12 @@ def pmc_traffic():
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_pmc_traffic_kib_per_launch.json")), reverse=True):
         try:
             tab = json.load(open(path))
-            return ({k: (2 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0 for k, d in tab.items()},
-                    "profiles/" + os.path.basename(path))
+            meta = tab.pop("_meta", {})
+            src = "profiles/" + os.path.basename(path)
+            if meta.get("commit"):
+                src += " (rocprofv3 --pmc passes of this bench command at commit %s)" % meta["commit"]
+            return ({k: (2 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0 for k, d in tab.items()
+                     if "FETCH_SIZE" in d and "WRITE_SIZE" in d}, src)
         except (OSError, KeyError, ValueError):
             continue
     return {}, None

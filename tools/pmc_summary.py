@@ -28,7 +28,11 @@ def main(out, *dirs):
                 e = tab.setdefault(fam, {})
                 e[ctr] = tot / n
                 e["launches"] = n
+    # which tree the passes ran on (bench.py prints it next to roofline.traffic_source): VF_PMC_COMMIT, set by the caller
+    # -- the GPU box has no .git
+    tab["_meta"] = {"commit": os.environ.get("VF_PMC_COMMIT", "unknown"), "command": os.environ.get("VF_PMC_COMMAND", "")}
     json.dump(tab, open(out, "w"), indent=1)
+    tab.pop("_meta")
     for fam, e in sorted(tab.items(), key=lambda kv: -(2 * kv[1].get("FETCH_SIZE", 0) + kv[1].get("WRITE_SIZE", 0)) * kv[1]["launches"])[:14]:
         print(f"{fam:40s} launches {e['launches']:5d}  HBM {(2 * e.get('FETCH_SIZE', 0) + e.get('WRITE_SIZE', 0)) / 1024:8.1f} MiB/launch")
 
