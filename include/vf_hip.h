@@ -141,6 +141,15 @@ int vf_wino_conv_fill_pct(int S, int Cin, int Cout, int H, int W, int* tiles_out
 int vf_wino_conv_fwd(const float* x, const float* u_packed, const float* bias, const float* view_bias,
                      const float* residual, float* y, float* ws, long ws_floats, int S, int Cin, int Cout, int H,
                      int W, int mode, void* stream);
+/* The same conv with the GroupNorm(+Swish) BEHIND it (unet.py:207-218: the next Block's norm) evaluated by the conv's
+ * fix-up launch -- possible where every tile of the launch is a K-split tail tile (the sampler at a few stacked views,
+ * 16x16 ... 64x64 maps): vf_wino_conv_gn_fusable() says where.  a_out = [Swish](GroupNorm(groups, eps)(y)); y itself is
+ * written only if store_y.  One graph node less than conv + fix-up + GroupNorm. */
+int vf_wino_conv_gn_fusable(int S, int Cin, int Cout, int H, int W, int mode, int groups);
+int vf_wino_conv_fwd_gn(const float* x, const float* u_packed, const float* bias /*|NULL*/, const float* view_bias /*|NULL*/,
+                        const float* residual /*|NULL*/, float* y, int store_y, const float* gn_gamma, const float* gn_beta,
+                        float* a_out, int groups, float eps, int silu, float* ws, long ws_floats, int S, int Cin, int Cout,
+                        int H, int W, int mode, void* stream);
 /* fused Winograd F(4x4,3x3) path (36 products per 4x4 outputs: 2.25 multiplies per output instead of the nested
  * kernel's 3) for the stride-1 3x3 convs on the 32x32 / 64x64 maps, forward and dgrad -- replaces nn.Conv2d 3x3
  * at reference model/unet.py:42,189,214 on those maps; same calling convention as the vf_wino_* entries above, its own

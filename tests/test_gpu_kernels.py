@@ -288,6 +288,46 @@ def test_conv_small_groupnorm_without_a_launch(dev, C0, C1, C2, H, KS2, S):
     assert rel(y, y_ref) < 5e-6, rel(y, y_ref)
 
 
+@pytest.mark.parametrize("Cin,Cout,H,mode,S", [(128, 64, 64, "same", 6), (192, 64, 64, "same", 6), (128, 128, 32, "same", 6),
+                                               (128, 128, 64, "up2", 3), (192, 192, 32, "up2", 6), (320, 128, 32, "same", 6),
+                                               (256, 128, 32, "same", 12), (128, 192, 16, "same", 16), (70, 96, 32, "same", 12)])
+def test_winograd_fixup_evaluates_the_groupnorm(dev, Cin, Cout, H, mode, S):
+    """Round 5, the sampler at a few views: where every tile of the nested Winograd launch is a K-split tail tile the
+    fix-up launch also evaluates the GroupNorm(+Swish) behind the conv (vf_wino_conv_fwd_gn) -- conv output and
+    normalised output against fp64 of conv -> GroupNorm(32) -> Swish (reference unet.py:207-218), with bias, per-view
+    bias and residual, with and without storing y."""
+    from view_fusion_amd import ops
+    layer, gn = torch.nn.Conv2d(Cin, Cout, 3, padding=1), torch.nn.GroupNorm(32, Cout)
+    with torch.no_grad():
+        layer.weight.copy_(rnd(Cout, Cin, 3, 3, seed=5) / math.sqrt(Cin * 9))
+        layer.bias.copy_(rnd(Cout, seed=6) * 0.5 + 0.4)
+        gn.weight.copy_(1 + 0.3 * rnd(Cout, seed=9))
+        gn.bias.copy_(0.2 * rnd(Cout, seed=10))
+    Hin = H // 2 if mode == "up2" else H
+    x, vb, res = rnd(S, Cin, Hin, Hin, seed=7), rnd(S, Cout, seed=8) * 0.3, rnd(S, Cout, H, H, seed=11)
+    inp = F.interpolate(x.double(), scale_factor=2, mode="nearest") if mode == "up2" else x.double()
+    y_ref = F.conv2d(inp, layer.weight.double(), layer.bias.double(), padding=1) + vb.double()[:, :, None, None] + res.double()
+    a_ref = F.group_norm(y_ref, 32, gn.weight.double(), gn.bias.double(), 1e-5)
+    a_ref = a_ref * torch.sigmoid(a_ref)
+    layer, gn = layer.to(dev), gn.to(dev)
+    lib = ops._lib.load()
+    m = ops._MODES[mode]
+    with torch.no_grad():
+        if not (ops.wino_kind(S, Cin, Cout, H, H, 3, m, False) == 1 and lib.vf_wino_conv_gn_fusable(S, Cin, Cout, H, H, m, 32)):
+            pytest.skip("this shape does not take the fused fix-up at this S under the natural policy")
+        ops.KERNEL_LOG = []
+        try:
+            y, a = ops.conv2d_gn(x.to(dev), layer, gn, 32, True, view_bias=vb.to(dev), residual=res.to(dev), mode=mode,
+                                 want_y=True)
+            y2, a2 = ops.conv2d_gn(x.to(dev), layer, gn, 32, True, view_bias=vb.to(dev), residual=res.to(dev), mode=mode)
+            torch.cuda.synchronize()
+            assert [e[5] for e in ops.KERNEL_LOG if e[5] != "vf_wino_pack_weights"] == ["vf_wino_conv_fwd_gn"] * 2
+        finally:
+            ops.KERNEL_LOG = None
+    assert y2 is None and torch.equal(a, a2)
+    assert rel(y, y_ref) < 2e-5 and rel(a, a_ref) < 2e-5, (rel(y, y_ref), rel(a, a_ref))
+
+
 @pytest.mark.parametrize("S", [1, 4])
 def test_conv_small_cat_and_gn(dev, S):
     """The decoder's 1x1 conv on the never-materialised concatenation, and conv + GroupNorm(+Swish) of the inference

@@ -56,6 +56,8 @@ SIGNATURES = {
     "vf_wino_conv_ws_floats": [_I, _I, _I, _I, _I],
     "vf_wino_conv_fill_pct": [_I, _I, _I, _I, _I, ctypes.POINTER(_I)],
     "vf_wino_conv_fwd": [_P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P],
+    "vf_wino_conv_gn_fusable": [_I, _I, _I, _I, _I, _I, _I],
+    "vf_wino_conv_fwd_gn": [_P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _F, _I, _P, _L, _I, _I, _I, _I, _I, _I, _P],
     "vf_wino44_supported": [_I, _I, _I],
     "vf_wino44_pack_sizes": [_I, _I, ctypes.POINTER(_L), ctypes.POINTER(_L)],
     "vf_wino44_pack_weights": [_P, _P, _P, _I, _I, _P],

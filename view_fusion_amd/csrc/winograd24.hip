@@ -699,14 +699,150 @@ __global__ __launch_bounds__(256) void wino_fixup_kernel(WinoArgs a, int ntail) 
     *reinterpret_cast<float4*>(a.y + o + G::W) = v1;
 }
 
+// Fix-up + GroupNorm(+Swish) in ONE launch (round 5; the sampler at a few views, where EVERY tile of the launch is a K-split
+// tail tile): one workgroup per (view, group) sums the K-range partials of its channels in the fix-up's fixed order, adds
+// bias / per-view bias / residual, optionally stores the conv output and -- the whole group being in its registers --
+// normalises it (two-pass mean / variance, as gn_fwd_kernel and conv_splitk_reduce_gn_kernel) into a_out.  Replaces
+// wino_fixup_kernel + gn_fwd_kernel: one graph node less per 3x3 conv of the 64x64 / 32x32 levels at S = 2 ... 16.
+// Element = one 2x4 output tile of one channel (8 floats); NV elements per thread, 512 threads.
+template <int LOGW, int NV>
+__global__ __launch_bounds__(512) void wino_fixup_gn_kernel(WinoArgs a, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float* __restrict__ a_out,
+                                                            int store_y, int cpg, float eps, int silu) {
+    using G = WGeo<LOGW, 0>;
+    static_assert(G::IPG == 1, "maps of at least 16x16");
+    constexpr int NT = 512, TPV = G::HW / 8;             // 2x4 tiles per view
+    __shared__ float red[NT / 64];
+    const int ngroups = a.Cout / cpg;
+    const int s = blockIdx.x / ngroups, g = blockIdx.x - s * ngroups;
+    const int nel = cpg * TPV, ncot = a.CoutP / WTCO;
+    float4 v0[NV], v1[NV];
+    size_t oo[NV];
+    float gam[NV], bet[NV], badd[NV];
+    float4 t0[NV][4], t1[NV][4];
+    const float* wsb[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {                       // every operand is requested before the first add
+        const int e = min((int)threadIdx.x + i * NT, nel - 1);
+        const int c = g * cpg + e / TPV, tv = e % TPV;
+        const int wg = s * G::WPI + tv / WTT, tl = tv % WTT;
+        const int j = wg * ncot + c / WTCO;              // (nfull == 0: the logical tile IS the tail index)
+        wsb[i] = a.ws + (((size_t)j * a.tail_split * WTCO + c % WTCO) * WTT + tl) * 8;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const float* w8 = wsb[i] + (size_t)min(p, a.tail_split - 1) * (WTCO * WTT * 8);
+            t0[i][p] = *reinterpret_cast<const float4*>(w8);
+            t1[i][p] = *reinterpret_cast<const float4*>(w8 + 4);
+        }
+        const int orow = G::g_row(wg) + 2 * G::t_row(tl), ocol = 4 * G::t_col(tl);
+        oo[i] = ((size_t)s * a.Cout + c) * G::HW + (size_t)orow * G::W + ocol;
+        float b = 0.f;
+        if (a.bias) b += a.bias[c];
+        if (a.vbias) b += a.vbias[(size_t)s * a.Cout + c];
+        badd[i] = b;
+        gam[i] = gamma[c];
+        bet[i] = beta[c];
+        v0[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        v1[i] = v0[i];
+        if (a.res) {
+            v0[i] = *reinterpret_cast<const float4*>(a.res + oo[i]);
+            v1[i] = *reinterpret_cast<const float4*>(a.res + oo[i] + G::W);
+        }
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {                    // fixed summation order, as wino_fixup_kernel
+            if (p < a.tail_split) {
+                q0.x += t0[i][p].x; q0.y += t0[i][p].y; q0.z += t0[i][p].z; q0.w += t0[i][p].w;
+                q1.x += t1[i][p].x; q1.y += t1[i][p].y; q1.z += t1[i][p].z; q1.w += t1[i][p].w;
+            }
+        }
+        if (a.tail_split > 4) {                          // partials 4 .. 7: a second batch of loads (deep-K layers only)
+            float4 u0[4], u1[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const float* w8 = wsb[i] + (size_t)min(4 + p, a.tail_split - 1) * (WTCO * WTT * 8);
+                u0[p] = *reinterpret_cast<const float4*>(w8);
+                u1[p] = *reinterpret_cast<const float4*>(w8 + 4);
+            }
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                if (4 + p < a.tail_split) {
+                    q0.x += u0[p].x; q0.y += u0[p].y; q0.z += u0[p].z; q0.w += u0[p].w;
+                    q1.x += u1[p].x; q1.y += u1[p].y; q1.z += u1[p].z; q1.w += u1[p].w;
+                }
+            }
+        }
+        const float b = badd[i];
+        q0.x += b; q0.y += b; q0.z += b; q0.w += b;
+        q1.x += b; q1.y += b; q1.z += b; q1.w += b;
+        v0[i] = make_float4(q0.x + v0[i].x, q0.y + v0[i].y, q0.z + v0[i].z, q0.w + v0[i].w);
+        v1[i] = make_float4(q1.x + v1[i].x, q1.y + v1[i].y, q1.z + v1[i].z, q1.w + v1[i].w);
+        const bool ok = (int)threadIdx.x + i * NT < nel;
+        if (store_y && ok) {
+            *reinterpret_cast<float4*>(a.y + oo[i]) = v0[i];
+            *reinterpret_cast<float4*>(a.y + oo[i] + G::W) = v1[i];
+        }
+        if (!ok) { v0[i] = make_float4(0.f, 0.f, 0.f, 0.f); v1[i] = v0[i]; }
+        sum += ((v0[i].x + v0[i].y) + (v0[i].z + v0[i].w)) + ((v1[i].x + v1[i].y) + (v1[i].z + v1[i].w));
+    }
+    const float inv_n = 1.0f / (float)(nel * 8);
+    const float mean = block_sum<NT>(sum, red) * inv_n;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const float d0 = v0[i].x - mean, d1 = v0[i].y - mean, d2 = v0[i].z - mean, d3 = v0[i].w - mean;
+        const float d4 = v1[i].x - mean, d5 = v1[i].y - mean, d6 = v1[i].z - mean, d7 = v1[i].w - mean;
+        const float q = ((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) + ((d4 * d4 + d5 * d5) + (d6 * d6 + d7 * d7));
+        sq += (int)threadIdx.x + i * NT < nel ? q : 0.f;
+    }
+    const float var = block_sum<NT>(sq, red) * inv_n;
+    const float rstd = 1.0f / sqrtf(var + eps);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        if ((int)threadIdx.x + i * NT < nel) {
+            const float ga = gam[i] * rstd, be = bet[i] - mean * ga;
+            float4 o0 = make_float4(v0[i].x * ga + be, v0[i].y * ga + be, v0[i].z * ga + be, v0[i].w * ga + be);
+            float4 o1 = make_float4(v1[i].x * ga + be, v1[i].y * ga + be, v1[i].z * ga + be, v1[i].w * ga + be);
+            if (silu) {
+                o0.x = silu_f(o0.x); o0.y = silu_f(o0.y); o0.z = silu_f(o0.z); o0.w = silu_f(o0.w);
+                o1.x = silu_f(o1.x); o1.y = silu_f(o1.y); o1.z = silu_f(o1.z); o1.w = silu_f(o1.w);
+            }
+            *reinterpret_cast<float4*>(a_out + oo[i]) = o0;
+            *reinterpret_cast<float4*>(a_out + oo[i] + G::W) = o1;
+        }
+    }
+}
+
 // tiles of a launch: groups of 32 output tiles (256 pixels) x 64-channel tiles
 inline int wino_groups(int S, int H, int W) {
     const int tiles = (H / 2) * (W / 4);
     return tiles >= WTT ? S * (tiles / WTT) : (S + WTT / tiles - 1) / (WTT / tiles);
 }
 
+struct WinoGn {                      // GroupNorm(+Swish) behind the conv, evaluated by the fix-up launch (or gamma = null)
+    const float* gamma = nullptr;
+    const float* beta = nullptr;
+    float* a_out = nullptr;
+    int groups = 0, silu = 0, store_y = 1;
+    float eps = 0.f;
+};
+
+// Can the fix-up launch of this shape evaluate the GroupNorm?  Every tile a K-split tail tile, maps of
+// at least 16x16 (one view per workgroup), a (view, group) of at most 2048 2x4 tiles.
+inline bool wino_gn_fusable(int S, int Cin, int Cout, int H, int W, int groups) {
+    if (W < 16 || groups <= 0 || Cout % groups != 0) return false;
+    const int T = wino_groups(S, H, W) * (rup(Cout, WTCO) / WTCO);
+    int nfull, split;
+    wino_tail_plan(T, rup(Cin, WCK) / WCK, &nfull, &split);
+    return nfull == 0 && split >= 2 && split <= 8 && (long)(Cout / groups) * (H * W / 8) <= 2048;
+}
+
 template <int LOGW, int MODE>
-int launch_wino(WinoArgs a, size_t ws_floats, hipStream_t st) {
+int launch_wino(WinoArgs a, size_t ws_floats, hipStream_t st, const WinoGn& gn = WinoGn()) {
     using G = WGeo<LOGW, MODE>;
     const int T = G::groups(a.S) * (a.CoutP / WTCO);
     wino_tail_plan(T, a.CinP / WCK, &a.nfull, &a.tail_split);
@@ -716,8 +852,23 @@ int launch_wino(WinoArgs a, size_t ws_floats, hipStream_t st) {
         a.tail_split = 1;
     }
     const int nt = T - a.nfull;
+    if (gn.gamma && !(a.nfull == 0 && a.tail_split >= 2)) return (int)hipErrorInvalidValue;     // (callers ask wino_gn_fusable first)
     a.npers = a.nfull < WINO_PERSIST ? a.nfull : WINO_PERSIST;
     hipLaunchKernelGGL((wino_conv_kernel<LOGW, MODE>), dim3(a.npers + nt * a.tail_split), dim3(512), 0, st, a);
+    if constexpr (LOGW >= 4) {
+        if (gn.gamma) {
+            const int cpg = a.Cout / gn.groups;
+            const long nel = (long)cpg * ((1 << (2 * LOGW)) / 8);
+            const dim3 grid(a.S * gn.groups);
+#define VF_FGN(NV) hipLaunchKernelGGL((wino_fixup_gn_kernel<LOGW, NV>), grid, dim3(512), 0, st, a, gn.gamma, gn.beta, gn.a_out, \
+                                      gn.store_y, cpg, gn.eps, gn.silu)
+            if (nel <= 512) VF_FGN(1);
+            else if (nel <= 1024) VF_FGN(2);
+            else VF_FGN(4);
+#undef VF_FGN
+            VF_RETURN_LAST_ERROR();
+        }
+    }
     if (nt > 0)
         hipLaunchKernelGGL((wino_fixup_kernel<LOGW>), dim3((nt * WTCO * WTT + 255) / 256), dim3(256), 0, st, a, nt);
     VF_RETURN_LAST_ERROR();
@@ -793,6 +944,35 @@ int vf_wino_conv_fwd(const float* x, const float* u_packed, const float* bias, c
     if (W == 16) return mode == 0 ? launch_wino<4, 0>(a, nws, st) : launch_wino<4, 2>(a, nws, st);
     if (W == 32) return mode == 0 ? launch_wino<5, 0>(a, nws, st) : launch_wino<5, 2>(a, nws, st);
     return mode == 0 ? launch_wino<6, 0>(a, nws, st) : launch_wino<6, 2>(a, nws, st);
+}
+
+// 1 if vf_wino_conv_fwd_gn can evaluate GroupNorm(groups) in the conv's fix-up launch at this shape (the sampler at a few
+// views: every tile of the launch a K-split tail tile; 16x16 ... 64x64 maps)
+int vf_wino_conv_gn_fusable(int S, int Cin, int Cout, int H, int W, int mode, int groups) {
+    return (vf_wino_supported(H, W, mode) && wino_gn_fusable(S, Cin, Cout, H, W, groups)) ? 1 : 0;
+}
+
+// vf_wino_conv_fwd + a = [Swish](GroupNorm(groups, eps; gamma, beta)(y)) with the norm evaluated by the fix-up launch
+// (reference unet.py:207-218: conv -> GroupNorm -> Swish of the next Block).  y is written only if store_y.
+// hipErrorInvalidValue unless vf_wino_conv_gn_fusable().
+int vf_wino_conv_fwd_gn(const float* x, const float* u_packed, const float* bias, const float* view_bias,
+                        const float* residual, float* y, int store_y, const float* gn_gamma, const float* gn_beta,
+                        float* a_out, int groups, float eps, int silu, float* ws, long ws_floats, int S, int Cin, int Cout,
+                        int H, int W, int mode, void* stream) {
+    if (S <= 0) return 0;
+    if (!vf_wino_conv_gn_fusable(S, Cin, Cout, H, W, mode, groups) || !ws || !gn_gamma || !gn_beta || !a_out)
+        return (int)hipErrorInvalidValue;
+    WinoArgs a;
+    a.x = x; a.u = u_packed; a.bias = bias; a.vbias = view_bias; a.res = residual; a.y = y;
+    a.S = S; a.Cin = Cin; a.Cout = Cout; a.CinP = rup(Cin, WCK); a.CoutP = rup(Cout, WTCO);
+    a.ws = ws;
+    WinoGn gn;
+    gn.gamma = gn_gamma; gn.beta = gn_beta; gn.a_out = a_out; gn.groups = groups; gn.silu = silu; gn.store_y = store_y; gn.eps = eps;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t nws = (size_t)ws_floats;
+    if (W == 16) return mode == 0 ? launch_wino<4, 0>(a, nws, st, gn) : launch_wino<4, 2>(a, nws, st, gn);
+    if (W == 32) return mode == 0 ? launch_wino<5, 0>(a, nws, st, gn) : launch_wino<5, 2>(a, nws, st, gn);
+    return mode == 0 ? launch_wino<6, 0>(a, nws, st, gn) : launch_wino<6, 2>(a, nws, st, gn);
 }
 
 }  // extern "C"

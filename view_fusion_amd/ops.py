@@ -804,6 +804,8 @@ RES_FOLD = os.environ.get("VF_RES_FOLD", "1") == "1"
 # cost the two convs 2.4-5.5 us on the 32x32 / 16x16 / 8x8 maps and 14.7 us on the 64x64 maps (256 workgroups per
 # channel hammer the same atomics).  OFF by default; VF_GN_LAZY=1 turns it on.
 GN_LAZY = os.environ.get("VF_GN_LAZY", "0") == "1"
+# Round 5, sampler at N >= 2: the Winograd conv's fix-up launch evaluates the GroupNorm behind the conv (vf_wino_conv_fwd_gn)
+WINO_GN_FUSION = os.environ.get("VF_WINO_GN", "1") == "1"
 
 
 class LazyGN:
@@ -1167,6 +1169,21 @@ def conv2d_gn(x, layer, gn, groups, silu, view_bias=None, residual=None, mode="s
              and not torch.is_grad_enabled() and not use_winograd(S, Cin, Cout, H, W, KS, m, False) and not _use_b3(KS, m, H * W)
              and not use_small_conv(S, Cin, Cout, H, W, KS, m)      # (one conv launch + the GroupNorm launch instead)
              and lib.vf_conv_fwd_ws_floats(S, Cin, Cout, H, W, KS) > 0)
+    # Winograd route at a few views (the sampler at N = 2 ... 16): every tile of the launch is a K-split tail tile, and the
+    # fix-up launch that sums the partials normalises too (vf_wino_conv_fwd_gn, round 5): conv + fix-up/GroupNorm instead
+    # of conv + fix-up + GroupNorm
+    if (WINO_GN_FUSION and not fused and not isinstance(x, LazyGN) and not torch.is_grad_enabled() and res_fold is None
+            and m in (0, 2) and KS == 3 and wino_kind(S, Cin, Cout, H, W, KS, m, False) == 1
+            and lib.vf_wino_conv_gn_fusable(S, Cin, Cout, H, W, m, groups)):
+        _check(x, layer.bias, view_bias, residual, gn.weight, gn.bias)
+        y = torch.empty(S, Cout, H, W, device=x.device, dtype=torch.float32) if want_y else None
+        a = torch.empty(S, Cout, H, W, device=x.device, dtype=torch.float32)
+        wf, _ = _packed_wino(layer, False, 1)
+        ws, nws = _wino_ws(x.device, S, Cin, Cout, H, W, 1)
+        _launch("conv_fwd", 2.0 * S * Cout * Cin * 9 * H * W, "vf_wino_conv_fwd_gn", _ptr(x), _ptr(wf), _ptr(layer.bias),
+                _ptr(view_bias), _ptr(residual), _ptr(y), int(want_y), _ptr(gn.weight), _ptr(gn.bias), _ptr(a), groups, 1e-5,
+                int(silu), _ptr(ws), nws, S, Cin, Cout, H, W, m, _stream(), tag=(Cin, Cout, H, KS, m))
+        return y, a
     if not fused:
         y = conv2d(x, layer, view_bias=view_bias, residual=residual, mode=mode, res_fold=res_fold)
         return y, group_norm(y, gn.weight, gn.bias, groups, silu)
