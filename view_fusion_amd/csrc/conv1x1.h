@@ -16,4 +16,5 @@ struct C11Args {
 };
 
 bool vfi_conv1x1_supported(const C11Args& a);
+int vfi_conv1x1_halves(const C11Args& a);      // 2: 128-channel workgroups, 1: 64-channel ones, 0: not taken
 int vfi_conv1x1_launch(const C11Args& a, hipStream_t st);

@@ -23,29 +23,36 @@ namespace {
 
 constexpr int XPS = 132;                 // LDS row stride of the activation image (128 pixels + 4: 16-byte aligned rows)
 constexpr int XSZ = 32 * XPS;            // floats of one activation buffer
+constexpr int VFI_C11_MINCIN64 = 128;    // fewest input channels the 64-channel variant is taken for (policy, see vfi_conv1x1_halves)
 #define VF_G1 __attribute__((address_space(1)))
 
-__global__ __launch_bounds__(512, 4) void conv1x1_kernel(C11Args a) {
+// NCW = 64-channel halves per workgroup: 2 (rounds 4: 128 channels x 128 pixels, 8 waves) or 1 (round 5: 64 channels x 128
+// pixels, 4 waves -- the layers with an ODD number of 64-channel tiles (Cout = 64, 192, 320), where the 128-channel
+// workgroup idles half the waves of its last column, and the short-K 64x64-map layers, which want more workgroups per CU
+// streaming at once: four of these fit where two of the others did)
+template <int NCW>
+__global__ __launch_bounds__(256 * NCW, 4) void conv1x1_kernel(C11Args a) {
     __shared__ __attribute__((aligned(16))) float Xl[2 * XSZ];
+    constexpr int NTH = 256 * NCW, NE = 1024 / NTH;      // staging elements (float4) per thread and chunk: 2 / 4
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int cw = wid & 1, pq = wid >> 1;
+    const int cw = NCW == 2 ? (wid & 1) : 0, pq = NCW == 2 ? (wid >> 1) : wid;
     const int li = lane & 31, lh = lane >> 5;
-    const int ncp = (a.nct + 1) >> 1;                    // 128-channel workgroup columns
+    const int ncp = NCW == 2 ? ((a.nct + 1) >> 1) : a.nct;   // workgroup columns of 64 NCW channels
     const unsigned logical = xcd_remap(blockIdx.x, gridDim.x);
     const int cp = logical % ncp, tp = logical / ncp;    // channel column fastest: neighbours share the pixel tile
-    const int cot_raw = 2 * cp + cw;
+    const int cot_raw = NCW * cp + cw;
     const bool have_co = cot_raw < a.nct;                // (odd number of 64-channel tiles: the last column's upper half idles)
     const int cot = have_co ? cot_raw : a.nct - 1;
     const int nch = a.Cin >> 5;
 
-    // ---- activation staging: element e = tid + 512 i -> (channel e >> 5, float4 e & 31) of the 32 x 128 chunk
-    unsigned xo[2][2];                                   // byte offsets of this thread's two elements in x / in x2
-    int xl[2];
+    // ---- activation staging: element e = tid + NTH i -> (channel e >> 5, float4 e & 31) of the 32 x 128 chunk
+    unsigned xo[NE][2];                                  // byte offsets of this thread's elements in x / in x2
+    int xl[NE];
     const int CA = a.x2 ? a.C1 : a.Cin, CB = a.Cin - a.C1;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int e = tid + 512 * i;
+    for (int i = 0; i < NE; ++i) {
+        const int e = tid + NTH * i;
         const int ci = e >> 5, q = e & 31;
         const int px = min(tp * 128 + 4 * q, a.npx - 4);             // (pixels past the batch: re-read the last ones)
         const int s = px >> a.hwsh, hw = px & (a.HW - 1);
@@ -53,8 +60,8 @@ __global__ __launch_bounds__(512, 4) void conv1x1_kernel(C11Args a) {
         xo[i][1] = 4u * (unsigned)(((size_t)s * CB + ci) * a.HW + hw);
         xl[i] = ci * XPS + 4 * q;
     }
-    f32x4 xr0, xr1;
-    auto fetch_x = [&](int c, f32x4& r0, f32x4& r1) {
+    f32x4 xr0, xr1, xr2, xr3;                            // (xr2, xr3: the 64-channel variant stages four float4 per thread)
+    auto fetch_x = [&](int c, f32x4& r0, f32x4& r1, f32x4& r2, f32x4& r3) {
         const int c0 = c << 5;
         const bool second = a.x2 && c0 >= a.C1;          // (uniform: the split is chunk aligned)
         const char* b_ = reinterpret_cast<const char*>(second ? a.x2 : a.x) + (size_t)(second ? c0 - a.C1 : c0) * a.HW * 4;
@@ -62,11 +69,21 @@ __global__ __launch_bounds__(512, 4) void conv1x1_kernel(C11Args a) {
         asm("" : "+s"(b_), "+v"(o0), "+v"(o1));
         r0 = *(const VF_G1 f32x4*)((const VF_G1 char*)b_ + o0);
         r1 = *(const VF_G1 f32x4*)((const VF_G1 char*)b_ + o1);
+        if constexpr (NE == 4) {
+            unsigned o2 = second ? xo[NE - 2][1] : xo[NE - 2][0], o3 = second ? xo[NE - 1][1] : xo[NE - 1][0];
+            asm("" : "+v"(o2), "+v"(o3));
+            r2 = *(const VF_G1 f32x4*)((const VF_G1 char*)b_ + o2);
+            r3 = *(const VF_G1 f32x4*)((const VF_G1 char*)b_ + o3);
+        }
     };
 #define VF_XSTORE(BUF, R0, R1)                                                                          \
     {                                                                                                   \
         *reinterpret_cast<f32x4*>(Xl + (BUF) * XSZ + xl[0]) = R0;                                        \
         *reinterpret_cast<f32x4*>(Xl + (BUF) * XSZ + xl[1]) = R1;                                        \
+        if constexpr (NE == 4) {                                                                        \
+            *reinterpret_cast<f32x4*>(Xl + (BUF) * XSZ + xl[NE - 2]) = xr2;                              \
+            *reinterpret_cast<f32x4*>(Xl + (BUF) * XSZ + xl[NE - 1]) = xr3;                              \
+        }                                                                                               \
     }
 
     // ---- weights: A fragments of (group g, 32-row block cb) of this wave's 64-channel tile, current chunk
@@ -119,7 +136,7 @@ __global__ __launch_bounds__(512, 4) void conv1x1_kernel(C11Args a) {
         const int cn_ = min((C) + 1, clast);                                                             \
         VF_GROUP(0, bA, VF_BFRAG(bB, PAR, 1), VF_XSTORE((PAR) ^ 1, xr0, xr1));                           \
         VF_ALOAD(0, 0, cn_); VF_ALOAD(0, 1, cn_);                                                        \
-        VF_GROUP(1, bB, VF_BFRAG(bA, PAR, 2), fetch_x(min((C) + 2, clast), xr0, xr1));                   \
+        VF_GROUP(1, bB, VF_BFRAG(bA, PAR, 2), fetch_x(min((C) + 2, clast), xr0, xr1, xr2, xr3));                   \
         VF_ALOAD(1, 0, cn_); VF_ALOAD(1, 1, cn_);                                                        \
         VF_GROUP(2, bA, VF_BFRAG(bB, PAR, 3), (void)0);                                                  \
         VF_ALOAD(2, 0, cn_); VF_ALOAD(2, 1, cn_);                                                        \
@@ -132,9 +149,9 @@ __global__ __launch_bounds__(512, 4) void conv1x1_kernel(C11Args a) {
     // ---- prologue: weights(0), activations(0) -> X[0], activations(1) in registers
     float bA[4], bB[4];
     VF_ALOAD_ALL(0);
-    fetch_x(0, xr0, xr1);
+    fetch_x(0, xr0, xr1, xr2, xr3);
     VF_XSTORE(0, xr0, xr1);
-    fetch_x(min(1, clast), xr0, xr1);
+    fetch_x(min(1, clast), xr0, xr1, xr2, xr3);
     VF_LDS_BARRIER();
     VF_BFRAG(bA, 0, 0);
     {
@@ -205,6 +222,8 @@ __global__ __launch_bounds__(512, 4) void conv1x1_kernel(C11Args a) {
 // 64x64-map layers are at 3.9 TB/s of HBM traffic with the generic kernel already), and 128 x 128 tiles give the 16x16
 // maps too few workgroups (24576 pixels per layer at S = 96).  So: whole 32-channel chunks from either source,
 // tile-aligned output split, at least eight chunks, an even number of 64-channel tiles, two workgroups per CU.
+int vfi_conv1x1_halves(const C11Args& a);
+
 bool vfi_conv1x1_supported(const C11Args& a) {
     if (a.Cin % 32 != 0 || a.HW < 64 || (a.HW & (a.HW - 1)) != 0 || a.npx < 128 || a.npx % 4 != 0) return false;
     if (a.x2 && (a.C1 <= 0 || a.C1 >= a.Cin || a.C1 % 32 != 0)) return false;
@@ -216,11 +235,31 @@ bool vfi_conv1x1_supported(const C11Args& a) {
     static const bool force = getenv("VF_CONV1X1_FORCE") != nullptr;     // tests / tuning: wherever the shape is legal
     const long tiles = (long)((a.npx + 127) / 128) * ((a.nct + 1) / 2);
     if (force) return tiles >= 64;
-    return a.Cin >= 256 && (a.nct & 1) == 0 && tiles >= 512;
+    return vfi_conv1x1_halves(a) != 0;
+}
+
+// 2: the 128-channel workgroup, 1: the 64-channel one, 0: the generic kernel.  VF_CONV1X1_NCW = 1 | 2 forces a variant
+// wherever the kernel is taken at all (tuning aid).
+int vfi_conv1x1_halves(const C11Args& a) {
+    static const int forced = getenv("VF_CONV1X1_NCW") ? atoi(getenv("VF_CONV1X1_NCW")) : 0;
+    if (forced == 1 || forced == 2) return forced;
+    static const bool force = getenv("VF_CONV1X1_FORCE") != nullptr;
+    const long ptiles = (a.npx + 127) / 128;
+    if (a.Cin >= 256 && (a.nct & 1) == 0 && ptiles * (a.nct / 2) >= 512) return 2;      // round 4's rule
+    if (force) return (a.nct & 1) ? 1 : 2;
+    static const bool on64 = !(getenv("VF_CONV1X1_64") && getenv("VF_CONV1X1_64")[0] == '0');
+    // round 5 (tools/conv1x1_table.py, profiles/r05_conv1x1_variants.txt): the 64-channel workgroup where the 128-channel one
+    // does not apply AND it beats the generic kernel: at least four 64-channel tiles and K >= 128 -- 192 -> 576 @16x16 69.5
+    // -> 63.0 us, 192 -> 384 49.8 -> 44.6, 128 -> 256 @32x32 71.3 -> 68.4, the 8x8 layers with 320 ... 960 channels -4 %; it
+    // loses with three tiles (Cout = 192 @16x16: 60.5 -> 65.0) and on the short-K 64x64 layers (64 -> 128: 97 -> 108)
+    if (on64 && a.Cin >= VFI_C11_MINCIN64 && a.nct >= 4 && ptiles * a.nct >= 192) return 1;
+    return 0;
 }
 
 int vfi_conv1x1_launch(const C11Args& a, hipStream_t st) {
-    const unsigned grid = (unsigned)((a.npx + 127) / 128) * (unsigned)((a.nct + 1) / 2);
-    hipLaunchKernelGGL(conv1x1_kernel, dim3(grid), dim3(512), 0, st, a);
+    const int halves = vfi_conv1x1_halves(a) == 1 ? 1 : 2;
+    const unsigned ptiles = (unsigned)((a.npx + 127) / 128);
+    if (halves == 2) hipLaunchKernelGGL(conv1x1_kernel<2>, dim3(ptiles * (unsigned)((a.nct + 1) / 2)), dim3(512), 0, st, a);
+    else hipLaunchKernelGGL(conv1x1_kernel<1>, dim3(ptiles * (unsigned)a.nct), dim3(256), 0, st, a);
     VF_RETURN_LAST_ERROR();
 }
