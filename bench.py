@@ -194,10 +194,10 @@ def pmc_traffic():
 FAMILIES = {
     "wino_conv": ("wino44_conv_kernel<LOGW,MODE> (Winograd F(4x4,3x3): 64x64 / 32x32 maps) + wino_conv_kernel<LOGW,MODE> "
                   "(nested F(2,3)xF(4,3): 16x16 / 8x8 maps), + tail fix-ups: forward + dgrad of every stride-1 3x3 layer", "mfma"),
-    "direct_conv": ("conv_mfma_kernel<KS,LOGW,MODE,NPT>: forward + dgrad of the 1x1 / stride-2 layers", "mfma"),
+    "direct_conv": ("conv_mfma_kernel<KS,LOGW,MODE,NPT> / conv1x1_kernel<NCW>: forward + dgrad of the 1x1 / stride-2 layers", "mfma"),
     "wino_wgrad": ("wino44_wgrad_kernel (Winograd F(4x4,3x3), + slab-sum launch): weight gradient of the stride-1 3x3 layers", "mfma"),
     "direct_wgrad": ("conv1x1_wgrad_kernel / conv_wgrad_kernel (+ reduce): weight gradient of the 1x1 / stride-2 layers", "mfma"),
-    "attn_fwd": ("attn_fwd_kh_kernel / attn_fwd_split_kernel", "mfma"),
+    "attn_fwd": ("attn_fwd_kh_kernel / attn_fwd_split_kernel / attn_fwd_q16_kernel", "mfma"),
     "attn_bwd": ("attention backward: bgemm_v2_kernel x4 + softmax_bwd_kernel on the materialised P", "mfma"),
     "bgemm": ("bgemm kernels outside attention (noise-level MLP linears)", "mfma"),
     "reduce": ("colsum / colsum_multi / rowsum / bias_grad / sumpool2 (parameter-gradient and pooling reductions)", "hbm"),
@@ -216,7 +216,7 @@ FAMILIES = {
 FAMILY_PMC = {
     "wino_conv": (("wino_conv_kernel", "wino44_conv_kernel"), ("wino_fixup_kernel", "wino44_fixup_kernel")),
     "wino_wgrad": (("wino44_wgrad_kernel",), ("wino44_reduce_kernel",)),
-    "direct_conv": (("conv_mfma_kernel",), ()),
+    "direct_conv": (("conv_mfma_kernel", "conv1x1_kernel"), ()),
     "direct_wgrad": (("conv1x1_wgrad_kernel", "conv_wgrad_kernel"), ("wgrad_reduce_kernel",)),
     "attn_fwd": (("attn_fwd_kh_kernel",), ()),
     "attn_bwd": (("bgemm_v2_kernel", "softmax_bwd_kernel"), ()),      # (one launcher call per kernel)
