@@ -75,7 +75,8 @@ int vf_conv_fwd_gn(const float* x, const float* w_packed, const float* bias, con
 /* The sampler's convolutions at few stacked views (model/view_fusion.py:179-214 driving model/unet.py:42,189,198,214,
  * 238,255,256 with S = 1 ... a dozen): ONE launch per layer, K split over the waves of a workgroup and summed in LDS in a
  * fixed order; reads the UNPACKED OIHW parameter.  x2 != NULL (1x1 only): input channels [C1, Cin) come from x2.
- * H = W = the (output = input) map, stride 1: mode must be 0 (vf_conv_small_supported says which layers are taken:
+ * H = W = the output map, stride 1: mode 0, or mode 2 for 3x3 (x stored at half size, nearest-x2 upsampled on read: the
+ * Upsample conv of unet.py:185-190; round 5) (vf_conv_small_supported says which layers are taken:
  * 1x1 with Cin % 4 == 0, 3x3 with Cin % 32 == 0, power-of-two maps of at least 4x4). */
 int vf_conv_small_supported(int Cin, int Cout, int H, int W, int KS, int mode);
 int vf_conv_small(const float* x, const float* x2 /*|NULL*/, int C1, const float* w_oihw, const float* bias /*|NULL*/,

@@ -158,7 +158,9 @@ def test_conv_down2_tap_adds_the_skip_gradient_in_the_dgrad_epilogue(dev, Cin, H
 
 SMALL_CASES = [c for c in CONV_CASES if c[4] == "same" and c[0] % (4 if c[3] == 1 else 32) == 0] + [
     (64, 100, 16, 3, "same"), (32, 40, 4, 3, "same"), (68, 33, 8, 1, "same"), (96, 50, 8, 3, "same"),
-    (384, 192, 16, 3, "same"), (512, 192, 16, 3, "same"), (256, 128, 32, 3, "same"), (192, 64, 64, 3, "same")]
+    (384, 192, 16, 3, "same"), (512, 192, 16, 3, "same"), (256, 128, 32, 3, "same"), (192, 64, 64, 3, "same"),
+    # round 5: the Upsample conv (nearest x2 folded into the patch addressing of the one-launch kernel)
+    (128, 128, 32, 3, "up2"), (192, 192, 16, 3, "up2"), (64, 40, 4, 3, "up2"), (32, 64, 8, 3, "up2")]
 
 
 @pytest.mark.parametrize("S", [1, 3])

@@ -382,10 +382,15 @@ __global__ __launch_bounds__(L / 32 * 64) void attn_fwd_split_kernel(const float
 //      (every SIMD carries the same number); A = one float4 of V per four MFMAs (k order = 16 blk + 4 kk + i); the two
 //      halves of a tile are computed by waves 2k, 2k + 1 and summed through LDS in a fixed order.
 // C a multiple of 64.  With many views this kernel would stream K and V 16 times per view: it is the sampler's kernel.
-__global__ __launch_bounds__(512) void attn_fwd_q16_kernel(const float* __restrict__ qkv, float* __restrict__ out,
-                                                           float* __restrict__ P, int C, float alpha) {
-    constexpr int L = 256, NW = 8, QB = 16, PF = 16;
-    __shared__ __attribute__((aligned(16))) float Pl[(L / 4) * QB * 4];      // [key quad 64][query 16][4]
+// L = 64 (the 8x8 mid block, C = 320): the same kernel with two waves (32 keys each), four workgroups per view, O items =
+// whole 16-channel tiles over all 64 keys (no key halves, no exchange).
+template <int L>
+__global__ __launch_bounds__(L / 32 * 64) void attn_fwd_q16_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                                   float* __restrict__ P, int C, float alpha) {
+    constexpr int NW = L / 32, QB = 16, PF = 16;
+    constexpr int KPI = L < 128 ? L : 128;           // keys per O item
+    constexpr int NG = KPI / 16, NH = L / KPI;       // float4 groups per item (8 / 4), key halves per tile (2 / 1)
+    __shared__ __attribute__((aligned(16))) float Pl[(L / 4) * QB * 4];      // [key quad][query 16][4]
     __shared__ float red[2][NW][QB];
     __shared__ __attribute__((aligned(16))) float oxs[NW / 2][4][64];        // partial O tiles of the upper key halves
 
@@ -423,12 +428,13 @@ __global__ __launch_bounds__(512) void attn_fwd_q16_kernel(const float* __restri
 #undef VF_Q16_LOAD
 #undef VF_Q16_MMA
 
-    // first V item of this wave: requested now, lands during the softmax.  item i -> channel tile i / 2, key half i % 2
-    const int nitem = 2 * (C / 16);                                  // a multiple of 8 (C a multiple of 64)
+    // first V item of this wave: requested now, lands during the softmax.  item i -> channel tile i / NH, key half i % NH
+    const int nitem = NH * (C / 16);                                 // a multiple of NW (C a multiple of 64)
     float4 va0, va1, va2, va3, va4, va5, va6, va7, vn0, vn1, vn2, vn3, vn4, vn5, vn6, vn7;
-#define VF_Q16_LV1(V, G, SRC) V##G = *reinterpret_cast<const float4*>((SRC) + 16 * (G));
+    va4 = va5 = va6 = va7 = vn4 = vn5 = vn6 = vn7 = make_float4(0.f, 0.f, 0.f, 0.f);     // (unused at L = 64)
+#define VF_Q16_LV1(V, G, SRC) if constexpr ((G) < NG) V##G = *reinterpret_cast<const float4*>((SRC) + 16 * (G));
 #define VF_Q16_LOADV(V, ITEM) { const int it_ = min((ITEM), nitem - 1);                                        \
-        const float* src_ = vb + (size_t)((it_ >> 1) * 16 + j) * L + 128 * (it_ & 1) + 4 * kk;                  \
+        const float* src_ = vb + (size_t)((it_ / NH) * 16 + j) * L + KPI * (it_ % NH) + 4 * kk;                 \
         VF_Q16_LV1(V, 0, src_) VF_Q16_LV1(V, 1, src_) VF_Q16_LV1(V, 2, src_) VF_Q16_LV1(V, 3, src_)             \
         VF_Q16_LV1(V, 4, src_) VF_Q16_LV1(V, 5, src_) VF_Q16_LV1(V, 6, src_) VF_Q16_LV1(V, 7, src_) }
     VF_Q16_LOADV(va, wid);
@@ -471,33 +477,38 @@ __global__ __launch_bounds__(512) void attn_fwd_q16_kernel(const float* __restri
     }
     __syncthreads();
 
-    // ---- 4. O tile = V[tile] P^T over a key half ----
+    // ---- 4. O tile = V[tile] P^T over a key half (L = 256) / over all keys (L = 64) ----
     for (int base = 0; base < nitem; base += NW) {
-        const int it = base + wid, t = it >> 1, h = it & 1;
+        const int it = base + wid, t = it / NH, h = it % NH;
         VF_Q16_LOADV(vn, it + NW);                                   // the wave's next item (clamped)
-        f32x4 pb[8];
+        f32x4 pb[NG];
 #pragma unroll
-        for (int g = 0; g < 8; ++g) pb[g] = *reinterpret_cast<const f32x4*>(Pl + ((32 * h + 4 * g + kk) * QB + j) * 4);
+        for (int g = 0; g < NG; ++g) pb[g] = *reinterpret_cast<const f32x4*>(Pl + (((KPI / 4) * h + 4 * g + kk) * QB + j) * 4);
         f32x4 o = {0.f, 0.f, 0.f, 0.f};
-#define VF_Q16_PV(G) {                                                                                        \
-        o = __builtin_amdgcn_mfma_f32_16x16x4f32(va##G.x, pb[G][0], o, 0, 0, 0);                                  \
-        o = __builtin_amdgcn_mfma_f32_16x16x4f32(va##G.y, pb[G][1], o, 0, 0, 0);                                  \
-        o = __builtin_amdgcn_mfma_f32_16x16x4f32(va##G.z, pb[G][2], o, 0, 0, 0);                                  \
-        o = __builtin_amdgcn_mfma_f32_16x16x4f32(va##G.w, pb[G][3], o, 0, 0, 0); }
+#define VF_Q16_PV(G) if constexpr ((G) < NG) {                                                                \
+        o = __builtin_amdgcn_mfma_f32_16x16x4f32(va##G.x, pb[(G) < NG ? (G) : 0][0], o, 0, 0, 0);                 \
+        o = __builtin_amdgcn_mfma_f32_16x16x4f32(va##G.y, pb[(G) < NG ? (G) : 0][1], o, 0, 0, 0);                 \
+        o = __builtin_amdgcn_mfma_f32_16x16x4f32(va##G.z, pb[(G) < NG ? (G) : 0][2], o, 0, 0, 0);                 \
+        o = __builtin_amdgcn_mfma_f32_16x16x4f32(va##G.w, pb[(G) < NG ? (G) : 0][3], o, 0, 0, 0); }
         VF_Q16_PV(0) VF_Q16_PV(1) VF_Q16_PV(2) VF_Q16_PV(3) VF_Q16_PV(4) VF_Q16_PV(5) VF_Q16_PV(6) VF_Q16_PV(7)
 #undef VF_Q16_PV
         va0 = vn0; va1 = vn1; va2 = vn2; va3 = vn3; va4 = vn4; va5 = vn5; va6 = vn6; va7 = vn7;
-        if (h == 1) {
+        float* ob = out + ((size_t)b * C + t * 16 + 4 * kk) * L + q0 + j;
+        if constexpr (NH == 2) {
+            if (h == 1) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) oxs[wid >> 1][r][lane] = o[r];
-        }
-        __syncthreads();
-        if (h == 0) {
-            float* ob = out + ((size_t)b * C + t * 16 + 4 * kk) * L + q0 + j;
+                for (int r = 0; r < 4; ++r) oxs[wid >> 1][r][lane] = o[r];
+            }
+            __syncthreads();
+            if (h == 0) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) ob[(size_t)r * L] = o[r] + oxs[wid >> 1][r][lane];
+                for (int r = 0; r < 4; ++r) ob[(size_t)r * L] = o[r] + oxs[wid >> 1][r][lane];
+            }
+            if (base + NW < nitem) __syncthreads();                  // the exchange slots are reused by the next round
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ob[(size_t)r * L] = o[r];
         }
-        if (base + NW < nitem) __syncthreads();                      // the exchange slots are reused by the next round
     }
 #undef VF_Q16_LOADV
 #undef VF_Q16_LV1
@@ -520,7 +531,9 @@ int vf_attention_fwd(const float* qkv, float* out, float* P, int S, int C, int L
     // (VF_ATTN_Q16=0: tuning aid, the 32-query kernel at every small S)
     static const bool q16 = !(getenv("VF_ATTN_Q16") && getenv("VF_ATTN_Q16")[0] == '0');
     if (L == 256 && S <= 16 && C % 64 == 0 && q16)
-        hipLaunchKernelGGL(attn_fwd_q16_kernel, dim3(16, S), dim3(512), 0, st, qkv, out, P, C, alpha);
+        hipLaunchKernelGGL(attn_fwd_q16_kernel<256>, dim3(16, S), dim3(512), 0, st, qkv, out, P, C, alpha);
+    else if (L == 64 && S <= 16 && C % 64 == 0 && q16)
+        hipLaunchKernelGGL(attn_fwd_q16_kernel<64>, dim3(4, S), dim3(128), 0, st, qkv, out, P, C, alpha);
     else if (L == 256 && S <= 52)
         hipLaunchKernelGGL(attn_fwd_split_kernel<256>, dim3(8, S), dim3(512), 0, st, qkv, out, P, C, alpha);
     else if (L == 256)

@@ -48,6 +48,7 @@ struct SmallArgs {
     const float* ib;
     int icpg, isilu;                   // channels per group
     float iinv, ieps;                  // 1 / (2^24 * icpg * H * W)
+    int up;                            // 3x3 only: x is stored at half size, nearest-x2-upsampled on read (Upsample conv, unet.py:185-190)
 };
 
 constexpr float SM_FIX = 16777216.f;   // 2^24: fixed-point unit of the statistics
@@ -235,7 +236,9 @@ __global__ __launch_bounds__(512) void conv3_small_kernel(SmallArgs a) {
     const int pr = lane / PC, pc = lane - pr * PC;
     const int gy = ty0 + pr - 1, gx = tx0 + pc - 1;
     const bool pin = lane < PS && (unsigned)gy < (unsigned)W && (unsigned)gx < (unsigned)W;
-    const float* xp = a.x + ((size_t)s * a.Cin + c0) * HW + (pin ? gy * W + gx : 0);
+    // (Upsample conv: the padding is padding of the UPSAMPLED map -- bounds in output coordinates, source pixel (gy/2, gx/2))
+    const int HWi = a.up ? HW >> 2 : HW;
+    const float* xp = a.x + ((size_t)s * a.Cin + c0) * HWi + (pin ? (a.up ? (gy >> 1) * (W >> 1) + (gx >> 1) : gy * W + gx) : 0);
     float* pl = lds + w * (RND * PS);
     // B table: LDS address of product 16 q + 4 kk + e of a round, for this lane's pixel
     typedef const __attribute__((address_space(3))) float* lds_cptr;      // (32-bit: a generic pointer takes two VGPRs)
@@ -274,7 +277,7 @@ __global__ __launch_bounds__(512) void conv3_small_kernel(SmallArgs a) {
 #pragma unroll
         for (int i = 0; i < RND; ++i) {
             const int c = r * RND + i;
-            P[i] = (pin && c < cw) ? xp[(size_t)c * HW] : 0.f;
+            P[i] = (pin && c < cw) ? xp[(size_t)c * HWi] : 0.f;
         }
         if (gn) {                                  // (the zero padding is padding of the NORMALISED map: stays zero)
 #pragma unroll
@@ -377,11 +380,12 @@ int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
 extern "C" {
 
-// 1 if vf_conv_small handles this layer: square power-of-two output maps of at least 16 pixels, stride 1; 1x1 with Cin a
+// 1 if vf_conv_small handles this layer: square power-of-two output maps of at least 16 pixels, stride 1 (mode 0) or, 3x3
+// only, the nearest-x2-upsampled input of the Upsample conv (mode 2: x stored at H/2 x W/2; round 5); 1x1 with Cin a
 // multiple of 4 (16-byte weight loads straight from the OIHW tensor), 3x3 with Cin a multiple of 32 (whole channel
 // groups per wave)
 int vf_conv_small_supported(int Cin, int Cout, int H, int W, int KS, int mode) {
-    if (H != W || H < 4 || (H & (H - 1)) || Cin < 1 || Cout < 1 || mode != 0) return 0;
+    if (H != W || H < 4 || (H & (H - 1)) || Cin < 1 || Cout < 1 || (mode != 0 && !(mode == 2 && KS == 3 && H >= 8))) return 0;
     if (KS == 1) return Cin % 4 == 0;
     if (KS == 3) return Cin % 32 == 0;
     return 0;
@@ -407,6 +411,7 @@ static int conv_small_launch(const float* x, const float* x2, int C1, const floa
     if (gn.ist && (x2 || !gn.ig || !gn.ib || gn.groups <= 0 || Cin % gn.groups != 0 || (KS == 1 && Cin > SM_GN_MAXC)
                    || (KS == 3 && Cin / 8 > 64)))
         return (int)hipErrorInvalidValue;
+    if (mode == 2 && (rx || gn.ist)) return (int)hipErrorInvalidValue;
     if (rx && (KS != 3 || residual || !rw || rC < 4 || rC % 4 != 0 || (rx2 ? (rC1 <= 0 || rC1 >= rC) : rC1 != rC)))
         return (int)hipErrorInvalidValue;
     if (S <= 0) return 0;
@@ -419,6 +424,7 @@ static int conv_small_launch(const float* x, const float* x2, int C1, const floa
     a.ost = gn.ost; a.ist = gn.ist; a.ig = gn.ig; a.ib = gn.ib;
     a.icpg = gn.ist ? Cin / gn.groups : 1; a.isilu = gn.silu; a.ieps = gn.eps;
     a.iinv = gn.ist ? (float)(1.0 / (16777216.0 * (double)a.icpg * (double)H * (double)W)) : 0.f;
+    a.up = mode == 2 ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
     if (KS == 1) {
         const long grid = (long)S * ((Cout + 31) / 32) * (H * W / SM_PX);
