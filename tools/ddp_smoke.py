@@ -22,7 +22,10 @@ def child(kind):
     from view_fusion_amd import train
     torch.cuda.set_device(0)
     eager = kind.endswith("-eager")
-    kind = kind.replace("-eager", "")
+    split = kind.endswith("-split")            # the default launch mode of a real multi-rank run (round 5)
+    if split:
+        os.environ["VF_CAPTURE_COLLECTIVES"] = "0"
+    kind = kind.replace("-eager", "").replace("-split", "")
     if kind != "none":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -47,8 +50,8 @@ def child(kind):
     if tr.arena is not None:
         a = tr.arena
         extra = f" copied/step {a.copied / n:.0f} of {len(a.params)} segments {[(hi - lo) * 4 >> 20 for lo, hi in a.seg_range]} MiB"
-    kind = kind + ("-eager" if eager else "")
-    print(f"reducer={kind:11s} graph replays {tr.graph_steps:2d}  {ms:.2f} ms/step loss {loss.item():.6f} param-checksum {chk:.9e}{extra}", flush=True)
+    kind = kind + ("-eager" if eager else "") + ("-split" if split else "")
+    print(f"reducer={kind:11s} mode {tr.mode:8s} graph replays {tr.graph_steps:2d}  {ms:.2f} ms/step loss {loss.item():.6f} param-checksum {chk:.9e}{extra}", flush=True)
     if kind != "none":
         dist.destroy_process_group()
 
@@ -57,5 +60,5 @@ if __name__ == "__main__":
     if len(sys.argv) > 1:
         child(sys.argv[1])
     else:
-        for kind in ("none-eager", "none", "ddp", "arena-eager", "arena"):
+        for kind in ("none-eager", "none", "ddp", "arena-eager", "arena-split", "arena"):
             subprocess.run([sys.executable, os.path.abspath(__file__), kind], check=False)
