@@ -179,7 +179,7 @@ class Trainer:
         self._graph_epoch = None    # FusedAdam.graph_epoch the kept graphs were captured under (None: none captured)
         self.graph_steps = 0        # iterations that ran as a replay (diagnostics / tests)
         self.world = world
-        self._check_base = self.GRAPH_AFTER     # multi-rank agreement: flag read at _check_base + 1, 2, 4, 8, ...
+        self._check_base = self.GRAPH_AFTER     # multi-rank agreement: flag read at _check_base + 1, 4, 16, 64, ...
         self.demotions = 0
 
     @property
@@ -211,12 +211,12 @@ class Trainer:
 
     def _agree(self):
         """Multi-rank agreement on the launch mode (see the class doc).  Called at the top of every step; reads the
-        arena's accumulated failure flag (one host sync) only at iterations _check_base + 2^j."""
+        arena's accumulated failure flag (one host sync) only at iterations _check_base + 4^j."""
         a = self.arena
         if a is None or a.flag_acc is None:
             return
         d = self.it - self._check_base
-        if d < 1 or (d & (d - 1)) != 0:
+        if d < 1 or (d & (d - 1)) != 0 or (d.bit_length() & 1) == 0:      # d = 1, 4, 16, 64, ...: powers of four
             return
         if float(a.flag_acc.item()) == 0.0:        # the same averaged value on every rank
             return
