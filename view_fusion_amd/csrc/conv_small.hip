@@ -75,22 +75,30 @@ constexpr int SM_PX = 16;
 
 // Epilogue operands (bias + per-view bias + residual of the output element this thread will finish) are requested at
 // kernel start: their latency runs under the main loop instead of behind the workgroup's last barrier.
+// Round 5: every load here is UNCONDITIONAL (clamped indices, a valid stand-in address for an absent operand, the value
+// dropped by a select) and the three values are only summed in the epilogue.  Before, the predicated loads sat in
+// branches and `add` was formed at once: the compiler put an s_waitcnt vmcnt(0) behind them, and the same for the
+// predicated patch / weight loads of the rounds -- four to five global round trips in sequence (~1 us each at these
+// occupancies) in front of the first MFMA of a 7 us kernel.
 template <int RS>
 struct SmallEpi {
-    float add;        // bias + per-view bias + residual
+    float b0, b1, r;  // bias, per-view bias, residual (or the folded residual conv's bias)
     size_t o;         // output index, or ~0 for a thread without an output element
     __device__ __forceinline__ void fetch(const SmallArgs& a, int s, int cot, int pt) {
         constexpr int TCO = 16 * RS;
         const int tid = threadIdx.x, HW = 1 << (2 * a.logW);
         const int co = cot * TCO + (tid >> 4), op = pt * SM_PX + (tid & 15);
-        o = ~(size_t)0;
-        add = 0.f;
-        if (tid < TCO * SM_PX && co < a.Cout) {
-            o = ((size_t)s * a.Cout + co) * HW + op;
-            float b0 = a.bias ? a.bias[co] : 0.f, b1 = a.vbias ? a.vbias[(size_t)s * a.Cout + co] : 0.f;
-            float r = a.res ? a.res[o] : (a.rbias ? a.rbias[co] : 0.f);
-            add = (b0 + b1) + r;
-        }
+        const int coc = min(co, a.Cout - 1);
+        const size_t oc = ((size_t)s * a.Cout + coc) * HW + op;                 // a valid element for every thread
+        o = (tid < TCO * SM_PX && co < a.Cout) ? oc : ~(size_t)0;
+        // (raw values: the selects that drop a stand-in are part of add(), i.e. of the epilogue -- a select here would be
+        //  the first USE of the loads and put their wait in front of the main loop)
+        b0 = *(a.bias ? a.bias + coc : a.w);
+        b1 = *(a.vbias ? a.vbias + (size_t)s * a.Cout + coc : a.w);
+        r = *(a.res ? a.res + oc : (a.rbias ? a.rbias + coc : a.w));
+    }
+    __device__ __forceinline__ float add(const SmallArgs& a) const {
+        return ((a.bias ? b0 : 0.f) + (a.vbias ? b1 : 0.f)) + ((a.res || a.rbias) ? r : 0.f);
     }
 };
 
@@ -110,7 +118,7 @@ __device__ __forceinline__ void small_epilogue(const SmallArgs& a, float* red, c
         v = red[tid];
 #pragma unroll
         for (int i = 1; i < 8; ++i) v += red[i * (TCO * SM_PX) + tid];
-        v += ep.add;
+        v += ep.add(a);
         a.y[ep.o] = v;
     }
     if (a.ost && tid < TCO * SM_PX) {              // (whole waves: TCO * 16 is a multiple of 64)
@@ -129,10 +137,10 @@ __device__ __forceinline__ void small_epilogue(const SmallArgs& a, float* red, c
 // ---- 1x1: wave w owns products (= input channels) [w n, (w+1) n), n a multiple of 16; in its q-th group of 16 the lane
 // quarter kk holds the channels 16 q + 4 kk + (0..3): one 16-byte weight load per lane, the four quarters of a weight
 // row 64 contiguous bytes; B = the lane's pixel of those four channel planes
-constexpr int SM_NB = 8;
+constexpr int SM_NB = 4;
 constexpr int SM_GN_MAXC = 1024;       // most input channels of a 1x1 conv with the GroupNorm applied on load
 template <bool CAT>
-__global__ __launch_bounds__(512) void conv1_small_kernel(SmallArgs a) {
+__global__ __launch_bounds__(512, 4) void conv1_small_kernel(SmallArgs a) {       // (<= 128 VGPRs: two workgroups per CU)
     __shared__ float red[8 * 32 * SM_PX];
     __shared__ float gtab[3 * SM_GN_MAXC];         // input GroupNorm: mean | rstd gamma | beta per channel
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 15, kk = lane >> 4;
@@ -165,14 +173,16 @@ __global__ __launch_bounds__(512) void conv1_small_kernel(SmallArgs a) {
         for (int q = 0; q < SM_NB; ++q) {
             const int k = kw + mb + 16 * q;
             const bool ok = mb + 16 * q < a.n && k < K;
-            A0[q] = ok ? *reinterpret_cast<const f32x4*>(wa0 + k) : (f32x4){0.f, 0.f, 0.f, 0.f};
-            A1[q] = ok ? *reinterpret_cast<const f32x4*>(wa1 + k) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            const int kc = min(k, K - 4);             // (unconditional loads: clamped index, value dropped by a select)
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(wa0 + kc), w1 = *reinterpret_cast<const f32x4*>(wa1 + kc);
+            A0[q] = ok ? w0 : (f32x4){0.f, 0.f, 0.f, 0.f};
+            A1[q] = ok ? w1 : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int ci = k + e;
-                float v = 0.f;
-                if (ok) v = (CAT && ci >= a.C1) ? xs2[(size_t)(ci - a.C1) * HW] : xs[(size_t)ci * HW];
-                B[4 * q + e] = v;
+                const int ci = kc + e;
+                const float* src = (CAT && ci >= a.C1) ? xs2 + (size_t)(ci - a.C1) * HW : xs + (size_t)ci * HW;
+                const float v = *src;
+                B[4 * q + e] = ok ? v : 0.f;
             }
         }
         if (gn) {
@@ -225,8 +235,9 @@ __global__ __launch_bounds__(512) void conv3_small_kernel(SmallArgs a) {
     const int pt = b % ptiles; b /= ptiles;
     const int cot = b % ncot;
     const int s = b / ncot;
-    SmallEpi<RS> ep;
-    ep.fetch(a, s, cot, pt);
+    SmallEpi<RS> ep;          // (its three loads are issued in round 0 BEHIND the round's own loads: the compiler guards the
+                              //  loop's address registers with an s_waitcnt vmcnt(0) at the top of every round, which
+                              //  would otherwise make round 0 wait for them before it has requested anything)
     const int K = a.Cin * 9;
     const int cw = a.Cin >> 3;                     // channels per wave (multiple of 4)
     const int c0 = w * cw;
@@ -275,10 +286,17 @@ __global__ __launch_bounds__(512) void conv3_small_kernel(SmallArgs a) {
         f32x4 A[RS][NQ];
         float P[RND];
 #pragma unroll
-        for (int i = 0; i < RND; ++i) {
-            const int c = r * RND + i;
-            P[i] = (pin && c < cw) ? xp[(size_t)c * HWi] : 0.f;
+        for (int i = 0; i < RND; ++i)                                // (unconditional: xp already points at a valid element)
+            P[i] = xp[(size_t)min(r * RND + i, cw - 1) * HWi];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            // (unconditional: a group past the round's products re-reads the round's first group)
+            const size_t wo = (size_t)r * (RND * 9) + (16 * q + 4 * kk < np ? 16 * q : 0);
+#pragma unroll
+            for (int rs = 0; rs < RS; ++rs) A[rs][q] = *reinterpret_cast<const f32x4*>(wa[rs] + wo);
         }
+        if (r == 0) ep.fetch(a, s, cot, pt);
+        __builtin_amdgcn_sched_barrier(0);           // every load of the round is in flight before the first value is used
         if (gn) {                                  // (the zero padding is padding of the NORMALISED map: stays zero)
 #pragma unroll
             for (int i = 0; i < RND; ++i) {
@@ -288,14 +306,15 @@ __global__ __launch_bounds__(512) void conv3_small_kernel(SmallArgs a) {
                 const float b_ = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gbeta), c));
                 P[i] = (pin && r * RND + i < cw) ? small_gn_apply(P[i], m_, s_, b_, a.isilu) : 0.f;
             }
+        } else {
+#pragma unroll
+            for (int i = 0; i < RND; ++i) P[i] = (pin && r * RND + i < cw) ? P[i] : 0.f;
         }
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const bool ok = 16 * q + 4 * kk < np;
 #pragma unroll
-            for (int rs = 0; rs < RS; ++rs)
-                A[rs][q] = ok ? *reinterpret_cast<const f32x4*>(wa[rs] + (size_t)r * (RND * 9) + 16 * q)
-                              : (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int rs = 0; rs < RS; ++rs) A[rs][q] = ok ? A[rs][q] : (f32x4){0.f, 0.f, 0.f, 0.f};
         }
         if (lane < PS) {
 #pragma unroll
@@ -337,15 +356,17 @@ __global__ __launch_bounds__(512) void conv3_small_kernel(SmallArgs a) {
             for (int q = 0; q < NBR; ++q) {
                 const int k = kw + mb + 16 * q;
                 const bool ok = mb + 16 * q < a.rn && k < a.rC;
+                const int kc = min(k, a.rC - 4);          // (unconditional loads, as everywhere in this file)
 #pragma unroll
-                for (int rs = 0; rs < RS; ++rs)
-                    A[rs][q] = ok ? *reinterpret_cast<const f32x4*>(wr[rs] + k) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int rs = 0; rs < RS; ++rs) {
+                    const f32x4 wv = *reinterpret_cast<const f32x4*>(wr[rs] + kc);
+                    A[rs][q] = ok ? wv : (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const int ci = k + e;
-                    float v = 0.f;
-                    if (ok) v = ci >= a.rC1 ? xs2[(size_t)(ci - a.rC1) * HW] : xs[(size_t)ci * HW];
-                    B[4 * q + e] = v;
+                    const int ci = kc + e;
+                    const float v = *(ci >= a.rC1 ? xs2 + (size_t)(ci - a.rC1) * HW : xs + (size_t)ci * HW);
+                    B[4 * q + e] = ok ? v : 0.f;
                 }
             }
 #pragma unroll
