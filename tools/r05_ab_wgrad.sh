@@ -1,3 +1,6 @@
+# A/B of two builds of the C ABI on one box.  build/ab/libvf_base*.so = the library of the commit BEFORE the change under test:
+#   git stash; python -m view_fusion_amd.build; mkdir -p build/ab; cp view_fusion_amd/lib/libvf_hip.so build/ab/libvf_baseN.so; git stash pop; python -m view_fusion_amd.build
+# (scratch files, removed after the round's measurements; results: profiles/r05_*.md)
 set -x
 cd $GRAFT_REPO_ROOT
 python -m pytest tests/test_gpu_kernels.py -q -x -k "wgrad or winograd" -p no:cacheprovider 2>&1 | tail -5
