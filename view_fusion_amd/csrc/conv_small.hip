@@ -16,6 +16,7 @@
 //   1x1 (conv1_small_kernel): the B values are gathered from global memory directly (16 consecutive pixels per
 //   quarter), optionally from the decoder's never-materialised concatenation [x | x2].
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -281,62 +282,77 @@ __global__ __launch_bounds__(512) void conv3_small_kernel(SmallArgs a) {
     float gmean = 0.f, gscale = 1.f, gbeta = 0.f;
     if (gn && lane < cw) small_gn_coef(a, s, c0 + lane, gmean, gscale, gbeta);
     const int nr = (cw + RND - 1) / RND;
-    for (int r = 0; r < nr; ++r) {
-        const int np = 9 * min(RND, cw - r * RND);     // products of this round (72 or 36)
-        f32x4 A[RS][NQ];
-        float P[RND];
-#pragma unroll
-        for (int i = 0; i < RND; ++i)                                // (unconditional: xp already points at a valid element)
-            P[i] = xp[(size_t)min(r * RND + i, cw - 1) * HWi];
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            // (unconditional: a group past the round's products re-reads the round's first group)
-            const size_t wo = (size_t)r * (RND * 9) + (16 * q + 4 * kk < np ? 16 * q : 0);
-#pragma unroll
-            for (int rs = 0; rs < RS; ++rs) A[rs][q] = *reinterpret_cast<const f32x4*>(wa[rs] + wo);
-        }
-        if (r == 0) ep.fetch(a, s, cot, pt);
-        __builtin_amdgcn_sched_barrier(0);           // every load of the round is in flight before the first value is used
-        if (gn) {                                  // (the zero padding is padding of the NORMALISED map: stays zero)
-#pragma unroll
-            for (int i = 0; i < RND; ++i) {
-                const int c = min(r * RND + i, cw - 1);
-                const float m_ = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gmean), c));
-                const float s_ = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gscale), c));
-                const float b_ = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gbeta), c));
-                P[i] = (pin && r * RND + i < cw) ? small_gn_apply(P[i], m_, s_, b_, a.isilu) : 0.f;
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < RND; ++i) P[i] = (pin && r * RND + i < cw) ? P[i] : 0.f;
-        }
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const bool ok = 16 * q + 4 * kk < np;
-#pragma unroll
-            for (int rs = 0; rs < RS; ++rs) A[rs][q] = ok ? A[rs][q] : (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-        if (lane < PS) {
-#pragma unroll
-            for (int i = 0; i < RND; ++i) pl[i * PS + lane] = P[i];      // (channels past the wave's range: zeros)
-        }
-        // (a wave reads only what it wrote itself: LDS operations of one wave execute in order, no workgroup barrier)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            if (16 * q < np) {                     // (wave-uniform)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float bv = *tb[q][e];
-#pragma unroll
-                    for (int rs = 0; rs < RS; ++rs)
-                        acc[rs] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[rs][q][e], bv, acc[rs], 0, 0, 0);
-                }
-            }
-        }
-        __builtin_amdgcn_wave_barrier();           // the next round's patch overwrites what this round read
+    // Rounds (macros on named arrays: everything stays in registers).  Measured per additional round (tools/small_conv_rounds.py,
+    // S = 1, chain replay): 6.0 us at 64x64, 3.2 at 32x32, 1.8 at 16x16 -- against 2.4 / 1.2 / 0.6 us of MFMA issue.  It is NOT
+    // the load latency: requesting round r + 1 before the MFMAs of round r (a second register set) made every shape 5-20 %
+    // SLOWER (profiles/r05_sampler.md); what a round pays for is the texture path -- every 16-byte weight load touches 16
+    // rows of the OIHW tensor -- and the LDS hand-over.  Reading the round's B values from LDS in two batches ahead of the
+    // MFMAs (instead of four at a time between them) is worth 3-7 %.
+#define VF_S3_LOAD(P_, A_, R_)                                                                              \
+    {                                                                                                       \
+        const int np_ = 9 * min(RND, cw - (R_) * RND);                                                      \
+        _Pragma("unroll") for (int i = 0; i < RND; ++i)           /* (unconditional: xp points at a valid element) */ \
+            P_[i] = xp[(size_t)min((R_) * RND + i, cw - 1) * HWi];                                           \
+        _Pragma("unroll") for (int q = 0; q < NQ; ++q) {                                                    \
+            /* (unconditional: a group past the round's products re-reads the round's first group) */       \
+            const size_t wo = (size_t)(R_) * (RND * 9) + (16 * q + 4 * kk < np_ ? 16 * q : 0);              \
+            _Pragma("unroll") for (int rs = 0; rs < RS; ++rs) A_[rs][q] = *reinterpret_cast<const f32x4*>(wa[rs] + wo); \
+        }                                                                                                   \
     }
+#define VF_S3_COMPUTE(P_, A_, R_)                                                                           \
+    {                                                                                                       \
+        const int np = 9 * min(RND, cw - (R_) * RND);      /* products of this round (72 or 36) */          \
+        if (gn) {                                  /* (the zero padding is padding of the NORMALISED map: stays zero) */ \
+            _Pragma("unroll") for (int i = 0; i < RND; ++i) {                                               \
+                const int c = min((R_) * RND + i, cw - 1);                                                  \
+                const float m_ = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gmean), c)); \
+                const float s_ = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gscale), c)); \
+                const float b_ = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gbeta), c)); \
+                P_[i] = (pin && (R_) * RND + i < cw) ? small_gn_apply(P_[i], m_, s_, b_, a.isilu) : 0.f;    \
+            }                                                                                               \
+        } else {                                                                                            \
+            _Pragma("unroll") for (int i = 0; i < RND; ++i) P_[i] = (pin && (R_) * RND + i < cw) ? P_[i] : 0.f; \
+        }                                                                                                   \
+        _Pragma("unroll") for (int q = 0; q < NQ; ++q) {                                                    \
+            const bool ok = 16 * q + 4 * kk < np;                                                           \
+            _Pragma("unroll") for (int rs = 0; rs < RS; ++rs) A_[rs][q] = ok ? A_[rs][q] : (f32x4){0.f, 0.f, 0.f, 0.f}; \
+        }                                                                                                   \
+        if (lane < PS) {                                                                                    \
+            _Pragma("unroll") for (int i = 0; i < RND; ++i) pl[i * PS + lane] = P_[i];   /* (channels past the wave's range: zeros) */ \
+        }                                                                                                   \
+        /* (a wave reads only what it wrote itself: LDS operations of one wave execute in order, no workgroup barrier) */ \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                                              \
+        __builtin_amdgcn_wave_barrier();                                                                    \
+        /* B values: groups 0-2 are read from LDS in one batch in front of their MFMAs, groups 3-4 while those run (one    \
+           exposed LDS latency per round instead of five; a slot past the round's products reads a valid address and     \
+           meets a zero weight) */                                                                         \
+        float bv_[NQ][4];                                                                                   \
+        _Pragma("unroll") for (int q = 0; q < 3; ++q)                                                       \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) bv_[q][e] = *tb[q][e];                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+        _Pragma("unroll") for (int q = 3; q < NQ; ++q)                                                      \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) bv_[q][e] = *tb[q][e];                            \
+        _Pragma("unroll") for (int q = 0; q < NQ; ++q) {                                                    \
+            if (16 * q < np) {                     /* (wave-uniform) */                                      \
+                _Pragma("unroll") for (int e = 0; e < 4; ++e)                                               \
+                    _Pragma("unroll") for (int rs = 0; rs < RS; ++rs)                                       \
+                        acc[rs] = __builtin_amdgcn_mfma_f32_16x16x4f32(A_[rs][q][e], bv_[q][e], acc[rs], 0, 0, 0); \
+            }                                                                                               \
+        }                                                                                                   \
+        __builtin_amdgcn_wave_barrier();           /* the next round's patch overwrites what this round read */ \
+    }
+    {
+        f32x4 A0[RS][NQ];
+        float P0[RND];
+        for (int r = 0; r < nr; ++r) {
+            VF_S3_LOAD(P0, A0, r);
+            if (r == 0) ep.fetch(a, s, cot, pt);     // (behind round 0's loads)
+            __builtin_amdgcn_sched_barrier(0);       // every load of the round is in flight before the first value is used
+            VF_S3_COMPUTE(P0, A0, r);
+        }
+    }
+#undef VF_S3_LOAD
+#undef VF_S3_COMPUTE
     // ---- the block's residual 1x1 convolution as extra K (reference unet.py:238,245: block2(...) + res_conv(x)): the
     // wave's share of the rC residual-input channels, products dealt as in conv1_small_kernel (one 16-byte weight load
     // per lane and 16 products, B = the lane's pixel of four channel planes, straight from global memory -- a tile's 16
