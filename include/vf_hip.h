@@ -93,13 +93,18 @@ int vf_conv_small_res(const float* x, const float* w_oihw, const float* bias /*|
  * integer sums (x, x^2 in 2^-24 units) left by the launch that produced x; the normalisation is applied while x is
  * staged (not with x2).  out_stats != NULL ([S][Cout][2] uint64, ZERO before the launch): the launch adds the sums of
  * y and y^2 per (view, channel) with integer atomics -- order-independent, bit-reproducible.  rx != NULL: as
- * vf_conv_small_res.  mode 0 only. */
+ * vf_conv_small_res.  w_packed != NULL (3x3): weights from vf_conv_small_pack.  mode 0, or 2 for a plain 3x3 conv. */
 int vf_conv_small_gn(const float* x, const float* x2 /*|NULL*/, int C1, const float* w_oihw, const float* bias /*|NULL*/,
                      const float* view_bias /*|NULL*/, const float* residual /*|NULL*/, float* y, int S, int Cin,
                      int Cout, int H, int W, int KS, const unsigned long long* in_stats /*|NULL*/,
                      const float* in_gamma, const float* in_beta, int in_groups, float eps, int silu,
                      unsigned long long* out_stats /*|NULL*/, const float* rx /*|NULL*/, const float* rx2 /*|NULL*/,
-                     int rC1, int rC, const float* rw_oihw, const float* rbias /*|NULL*/, void* stream);
+                     int rC1, int rC, const float* rw_oihw, const float* rbias /*|NULL*/, const float* w_packed /*|NULL*/,
+                     int mode, void* stream);
+/* 3x3 weights in the load order of the one-launch kernel (every weight load of a wave = 1 KB of consecutive memory instead
+ * of 16 pieces of 16 OIHW rows); static weights (the sampler) are packed once.  Cin % 32 == 0. */
+long vf_conv_small_pack_floats(int Cout, int Cin);
+int vf_conv_small_pack(const float* w_oihw, float* w_packed, int Cout, int Cin, void* stream);
 /* split-K workspace the call above wants at this shape (0 when the natural grid fills the chip) */
 long vf_conv_fwd_ws_floats(int S, int Cin, int Cout, int H, int W, int KS);
 /* 1x1 conv on the channel concatenation [x1 (C1 channels, multiple of 64) | x2] (residual conv of the decoder

@@ -160,7 +160,8 @@ SMALL_CASES = [c for c in CONV_CASES if c[4] == "same" and c[0] % (4 if c[3] == 
     (64, 100, 16, 3, "same"), (32, 40, 4, 3, "same"), (68, 33, 8, 1, "same"), (96, 50, 8, 3, "same"),
     (384, 192, 16, 3, "same"), (512, 192, 16, 3, "same"), (256, 128, 32, 3, "same"), (192, 64, 64, 3, "same"),
     # round 5: the Upsample conv (nearest x2 folded into the patch addressing of the one-launch kernel)
-    (128, 128, 32, 3, "up2"), (192, 192, 16, 3, "up2"), (64, 40, 4, 3, "up2"), (32, 64, 8, 3, "up2")]
+    (128, 128, 32, 3, "up2"), (192, 192, 16, 3, "up2"), (64, 40, 4, 3, "up2"), (32, 64, 8, 3, "up2"),
+    (64, 6, 64, 3, "same"), (64, 48, 64, 3, "same")]       # (fewer than 32 / an odd number of 16-row blocks under 32-channel workgroups)
 
 
 @pytest.mark.parametrize("S", [1, 3])
@@ -189,7 +190,10 @@ def test_conv_small_sampler_kernel(dev, Cin, Cout, Hin, KS, mode, S):
             y = ops.conv2d(x.to(dev), layer, view_bias=vb.to(dev), residual=res.to(dev), mode=mode)
             y0 = ops.conv2d(x.to(dev), layer, mode=mode)
         torch.cuda.synchronize()
-        assert [e[5] for e in ops.KERNEL_LOG] == ["vf_conv_small", "vf_conv_small"]
+        # (3x3: the general entry with the packed weight copy, made once per weight version; 1x1: the plain entry)
+        names = [e[5] for e in ops.KERNEL_LOG if e[5] != "vf_conv_small_pack"]
+        assert names == (["vf_conv_small_gn"] * 2 if KS == 3 else ["vf_conv_small"] * 2), names
+        assert sum(e[5] == "vf_conv_small_pack" for e in ops.KERNEL_LOG) == (1 if KS == 3 else 0)
     finally:
         ops.KERNEL_LOG = None
         ops.SMALL_CONV_MAX_WGS, ops.SMALL_CONV_MAX_CIN3, ops.SMALL_CONV_MAX_S3 = saved
@@ -228,7 +232,7 @@ def test_conv_small_with_folded_residual_conv(dev, C, H, rC1, rC2, S):
             y = ops.conv2d(a2.to(dev), conv, view_bias=vb.to(dev), res_fold=fold)
             y_nb = ops.conv2d(a2.to(dev), conv, res_fold=fold)
         torch.cuda.synchronize()
-        assert [e[5] for e in ops.KERNEL_LOG] == ["vf_conv_small_res", "vf_conv_small_res"]
+        assert [e[5] for e in ops.KERNEL_LOG if e[5] != "vf_conv_small_pack"] == ["vf_conv_small_gn"] * 2   # (general entry: packed weights + fold)
     finally:
         ops.KERNEL_LOG = None
         ops.SMALL_CONV_MAX_WGS, ops.SMALL_CONV_MAX_CIN3, ops.SMALL_CONV_MAX_S3 = saved
@@ -276,7 +280,7 @@ def test_conv_small_groupnorm_without_a_launch(dev, C0, C1, C2, H, KS2, S):
                 y = ops.conv2d(ops.LazyGN(h, st, gn, 32, silu), conv2)
                 outs.append((h.clone(), st.clone(), y.clone()))
         torch.cuda.synchronize()
-        assert [e[5] for e in ops.KERNEL_LOG] == ["vf_conv_small_gn"] * 4
+        assert [e[5] for e in ops.KERNEL_LOG if e[5] != "vf_conv_small_pack"] == ["vf_conv_small_gn"] * 4
     finally:
         ops.KERNEL_LOG, ops.STATS, ops.GN_LAZY = None, None, lazy_default
         ops.SMALL_CONV_MAX_WGS, ops.SMALL_CONV_MAX_CIN3, ops.SMALL_CONV_MAX_S3 = saved

@@ -86,7 +86,9 @@ SIGNATURES = {
     "vf_conv_small": [_P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "vf_conv_small_res": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _I, _P, _P, _P],
     "vf_conv_small_gn": [_P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _F, _I, _P, _P, _P, _I, _I,
-                         _P, _P, _P],
+                         _P, _P, _P, _I, _P],
+    "vf_conv_small_pack_floats": [_I, _I],
+    "vf_conv_small_pack": [_P, _P, _I, _I, _P],
     "vf_adam_multi_dev": [_P, _I, _L, _P, _F, _F, _F, _P],
     "vf_adam_set_scalars": [_P, _F, _F, _F, _P],
     "vf_psnr": [_P, _P, _P, _I, _I, _P],
@@ -96,7 +98,8 @@ SIGNATURES = {
     "vf_compose_mse_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "vf_p_sample_tail": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
 }
-_RESTYPE = {"vf_conv1x1_bf16x3_pack_dwords": _L, "vf_conv_wgrad_ws_floats": _L, "vf_time_affine_ws_floats": _L, "vf_wino_conv_ws_floats": _L, "vf_wino44_conv_ws_floats": _L, "vf_wino_wgrad_ws_floats": _L, "vf_conv_fwd_ws_floats": _L}
+_RESTYPE = {"vf_conv1x1_bf16x3_pack_dwords": _L, "vf_conv_wgrad_ws_floats": _L, "vf_time_affine_ws_floats": _L, "vf_wino_conv_ws_floats": _L, "vf_wino44_conv_ws_floats": _L, "vf_wino_wgrad_ws_floats": _L, "vf_conv_fwd_ws_floats": _L,
+            "vf_conv_small_pack_floats": _L}
 
 _lib = None
 N_CALLS = 0          # C-ABI launcher invocations so far (bench.py: launches per sampler step)

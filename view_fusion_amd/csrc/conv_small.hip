@@ -50,6 +50,7 @@ struct SmallArgs {
     int icpg, isilu;                   // channels per group
     float iinv, ieps;                  // 1 / (2^24 * icpg * H * W)
     int up;                            // 3x3 only: x is stored at half size, nearest-x2-upsampled on read (Upsample conv, unet.py:185-190)
+    const float* wp;                   // 3x3 only: the weights in the packed order of vf_conv_small_pack, or null (unpacked OIHW)
 };
 
 constexpr float SM_FIX = 16777216.f;   // 2^24: fixed-point unit of the statistics
@@ -222,7 +223,12 @@ __global__ __launch_bounds__(512, 4) void conv1_small_kernel(SmallArgs a) {     
 // (channel and tap of product 16 q + 4 kk + e), computed once per workgroup.
 // The loads are NOT double buffered: two register sets cost the second resident workgroup, which hides more latency
 // than the prefetch did (measured).
-template <int LOGTC, int RS>
+// PACKED: the weights come from the copy made by vf_conv_small_pack -- [16-row block][wave 8][round][group 5][lane 64]
+// float4, i.e. every weight load of a wave is 1 KB of consecutive memory (8 cache lines) instead of sixteen 64-byte pieces
+// of sixteen OIHW rows.  Round 5: the rounds of this kernel wait for the texture path, not for latency -- with every lane
+// of a quarter reading the SAME row (timing experiment) a round costs 4.0 instead of 6.0 us at 64x64, 2.3 instead of 3.1 at
+// 32x32 (profiles/r05_sampler.md).  The sampler's weights are static during a generate() call: packed once per weight version.
+template <int LOGTC, int RS, bool PACKED>
 __global__ __launch_bounds__(512) void conv3_small_kernel(SmallArgs a) {
     constexpr int TC = 1 << LOGTC, TR = SM_PX / TC, PC = TC + 2, PR = TR + 2, PS = PR * PC;     // 54 / 40 / 36
     constexpr int RND = 8, NQ = 5;                 // channels per wave and round; groups of 16 products (72 -> 80)
@@ -271,7 +277,17 @@ __global__ __launch_bounds__(512) void conv3_small_kernel(SmallArgs a) {
     const float* wa[RS];
 #pragma unroll
     for (int rs = 0; rs < RS; ++rs)
+#ifdef VF_SMALL_FAKEW     /* diagnostic build (timing only, wrong results): every lane of a quarter reads the SAME weight row */
+        wa[rs] = a.w + (size_t)min(cot * TCO + 16 * rs, a.Cout - 1) * K + (size_t)c0 * 9 + 4 * kk;
+#else
         wa[rs] = a.w + (size_t)min(cot * TCO + 16 * rs + j, a.Cout - 1) * K + (size_t)c0 * 9 + 4 * kk;
+#endif
+
+    const int nrp = (cw + RND - 1) / RND;
+    const f32x4* wpk[RS];
+#pragma unroll
+    for (int rs = 0; rs < RS; ++rs)
+        wpk[rs] = reinterpret_cast<const f32x4*>(a.wp) + (((size_t)(cot * RS + rs) * 8 + w) * nrp) * (NQ * 64) + lane;
 
     f32x4 acc[RS];
 #pragma unroll
@@ -296,7 +312,8 @@ __global__ __launch_bounds__(512) void conv3_small_kernel(SmallArgs a) {
         _Pragma("unroll") for (int q = 0; q < NQ; ++q) {                                                    \
             /* (unconditional: a group past the round's products re-reads the round's first group) */       \
             const size_t wo = (size_t)(R_) * (RND * 9) + (16 * q + 4 * kk < np_ ? 16 * q : 0);              \
-            _Pragma("unroll") for (int rs = 0; rs < RS; ++rs) A_[rs][q] = *reinterpret_cast<const f32x4*>(wa[rs] + wo); \
+            _Pragma("unroll") for (int rs = 0; rs < RS; ++rs)                                               \
+                A_[rs][q] = PACKED ? wpk[rs][((R_) * NQ + q) * 64] : *reinterpret_cast<const f32x4*>(wa[rs] + wo); \
         }                                                                                                   \
     }
 #define VF_S3_COMPUTE(P_, A_, R_)                                                                           \
@@ -401,14 +418,34 @@ __global__ __launch_bounds__(512) void conv3_small_kernel(SmallArgs a) {
     small_epilogue<RS>(a, lds, acc, ep);
 }
 
-template <int RS>
+template <int RS, bool PACKED>
 int launch_conv3(const SmallArgs& a, hipStream_t st) {
     const int W = 1 << a.logW;
     const long grid = (long)a.S * ((a.Cout + 16 * RS - 1) / (16 * RS)) * (W * W / SM_PX);
-    if (W >= 16) hipLaunchKernelGGL((conv3_small_kernel<4, RS>), dim3((unsigned)grid), dim3(512), 0, st, a);
-    else if (W == 8) hipLaunchKernelGGL((conv3_small_kernel<3, RS>), dim3((unsigned)grid), dim3(512), 0, st, a);
-    else hipLaunchKernelGGL((conv3_small_kernel<2, RS>), dim3((unsigned)grid), dim3(512), 0, st, a);
+    if (W >= 16) hipLaunchKernelGGL((conv3_small_kernel<4, RS, PACKED>), dim3((unsigned)grid), dim3(512), 0, st, a);
+    else if (W == 8) hipLaunchKernelGGL((conv3_small_kernel<3, RS, PACKED>), dim3((unsigned)grid), dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((conv3_small_kernel<2, RS, PACKED>), dim3((unsigned)grid), dim3(512), 0, st, a);
     VF_RETURN_LAST_ERROR();
+}
+
+// [16-row block 2 ceil(Cout/32)][wave 8][round nr][group 5][lane 64] float4: lane (j, kk) of group q, round r, wave wv holds
+// W[16 blk + j][(wv cw + 8 r) 9 + 16 q + 4 kk + (0..3)], zero past the round's products / past Cout
+__global__ __launch_bounds__(256) void conv3_small_pack_kernel(const float* __restrict__ w, float4* __restrict__ out, int Cout,
+                                                                int Cin, long n4) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n4) return;
+    const int cw = Cin >> 3, nr = (cw + 7) / 8;
+    const int lane = (int)(idx & 63), q = (int)((idx >> 6) % 5), r = (int)((idx / 320) % nr);
+    const int wv = (int)((idx / (320L * nr)) & 7), blk = (int)(idx / (320L * nr * 8));
+    const int j = lane & 15, kk = lane >> 4, co = blk * 16 + j;
+    const int np = 9 * min(8, cw - r * 8), k0 = 16 * q + 4 * kk;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (co < Cout && k0 < np) {
+        const float* p = w + (size_t)co * Cin * 9 + (size_t)(wv * cw + r * 8) * 9 + k0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = p[e];
+    }
+    out[idx] = make_float4(v[0], v[1], v[2], v[3]);
 }
 
 int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
@@ -437,6 +474,7 @@ struct SmallGn {                       // GroupNorm on the input (applied on loa
     int groups = 0, silu = 0;
     float eps = 0.f;
     unsigned long long* ost = nullptr;
+    const float* wp = nullptr;         // packed 3x3 weights (vf_conv_small_pack), or null
 };
 
 static int conv_small_launch(const float* x, const float* x2, int C1, const float* w, const float* bias,
@@ -462,6 +500,7 @@ static int conv_small_launch(const float* x, const float* x2, int C1, const floa
     a.icpg = gn.ist ? Cin / gn.groups : 1; a.isilu = gn.silu; a.ieps = gn.eps;
     a.iinv = gn.ist ? (float)(1.0 / (16777216.0 * (double)a.icpg * (double)H * (double)W)) : 0.f;
     a.up = mode == 2 ? 1 : 0;
+    a.wp = KS == 3 ? gn.wp : nullptr;
     hipStream_t st = (hipStream_t)stream;
     if (KS == 1) {
         const long grid = (long)S * ((Cout + 31) / 32) * (H * W / SM_PX);
@@ -471,7 +510,8 @@ static int conv_small_launch(const float* x, const float* x2, int C1, const floa
     }
     // 32-channel tiles when they alone fill the chip, 16-channel tiles (twice the workgroups) otherwise
     const long wgs32 = (long)S * ((Cout + 31) / 32) * (H * W / SM_PX);
-    return wgs32 >= 256 ? launch_conv3<2>(a, st) : launch_conv3<1>(a, st);
+    if (a.wp) return wgs32 >= 256 ? launch_conv3<2, true>(a, st) : launch_conv3<1, true>(a, st);
+    return wgs32 >= 256 ? launch_conv3<2, false>(a, st) : launch_conv3<1, false>(a, st);
 }
 
 int vf_conv_small(const float* x, const float* x2, int C1, const float* w, const float* bias, const float* view_bias,
@@ -498,16 +538,32 @@ int vf_conv_small_res(const float* x, const float* w, const float* bias, const f
 //   out_stats != NULL: [S][Cout][2] 64-bit integers, ZERO before the launch; the launch adds the sums of y and y^2 of
 //                      every (view, channel) with integer atomics (order-independent: bit-reproducible).
 //   rx != NULL (3x3): the residual 1x1 conv folded in, as vf_conv_small_res.
+//   w_packed != NULL (3x3): the weights in the order of vf_conv_small_pack (w is then only the stand-in address).
+//   mode: 0, or 2 (3x3: x stored at half size, nearest-x2 upsampled on read; not with in_stats / rx).
 int vf_conv_small_gn(const float* x, const float* x2, int C1, const float* w, const float* bias, const float* view_bias,
                      const float* residual, float* y, int S, int Cin, int Cout, int H, int W, int KS,
                      const unsigned long long* in_stats, const float* in_gamma, const float* in_beta, int in_groups,
                      float eps, int silu, unsigned long long* out_stats, const float* rx, const float* rx2, int rC1,
-                     int rC, const float* rw, const float* rbias, void* stream) {
+                     int rC, const float* rw, const float* rbias, const float* w_packed, int mode, void* stream) {
     SmallGn gn;
+    gn.wp = w_packed;
     gn.ist = in_stats; gn.ig = in_gamma; gn.ib = in_beta; gn.groups = in_groups; gn.silu = silu; gn.eps = eps;
     gn.ost = out_stats;
-    return conv_small_launch(x, x2, C1, w, bias, view_bias, residual, y, S, Cin, Cout, H, W, KS, 0, rx, rx2,
+    return conv_small_launch(x, x2, C1, w, bias, view_bias, residual, y, S, Cin, Cout, H, W, KS, mode, rx, rx2,
                              rx ? (rx2 ? rC1 : rC) : 0, rx ? rC : 0, rw, rbias, stream, gn);
+}
+
+// Packed copy of a 3x3 layer's weights for the one-launch kernel (w_packed of vf_conv_small_gn): floats needed / the pack.
+long vf_conv_small_pack_floats(int Cout, int Cin) {
+    const int cw = Cin >> 3, nr = (cw + 7) / 8;
+    return (long)((Cout + 31) / 32) * 2 * 8 * nr * 5 * 64 * 4;      // whole 32-row tiles: a 32-channel workgroup reads two blocks
+}
+int vf_conv_small_pack(const float* w_oihw, float* w_packed, int Cout, int Cin, void* stream) {
+    if (Cin % 32 != 0 || Cout < 1) return (int)hipErrorInvalidValue;
+    const long n4 = vf_conv_small_pack_floats(Cout, Cin) / 4;
+    hipLaunchKernelGGL(conv3_small_pack_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w_oihw,
+                       (float4*)w_packed, Cout, Cin, n4);
+    VF_RETURN_LAST_ERROR();
 }
 
 }  // extern "C"

@@ -786,10 +786,44 @@ def use_small_conv(S, Cin, Cout, H, W, KS, m):
     return wgs <= SMALL_CONV_MAX_WGS[1] and Cin <= SMALL_CONV_MAX_CIN3 and S <= SMALL_CONV_MAX_S3
 
 
+SMALL_PACK = os.environ.get("VF_SMALL_PACK", "1") == "1"
+
+
+def _packed_small(layer_or_weight):
+    """3x3 weights in the load order of the one-launch kernel (vf_conv_small_pack), cached on the parameter and keyed on
+    its version counter like _packed (inference only: the sampler's weights are static during a generate() call).
+    None when packing is off or the holder is a bare tensor without a place for the cache."""
+    w = layer_or_weight.weight if hasattr(layer_or_weight, "weight") else layer_or_weight
+    if not SMALL_PACK or w.shape[2] != 3 or torch.is_grad_enabled():
+        return None
+    key = (w._version, w.data_ptr(), w.device)
+    cache = getattr(w, "_vf_small_pack", None)
+    if cache is not None and cache[0] == key:
+        return cache[1]
+    Cout, Cin = w.shape[0], w.shape[1]
+    n = _lib.load().vf_conv_small_pack_floats(Cout, Cin)
+    wp = cache[1] if (cache is not None and cache[1].numel() == n and cache[1].device == w.device) else \
+        torch.empty(n, device=w.device, dtype=torch.float32)
+    wd = w.detach()
+    _check(wd)
+    _call("vf_conv_small_pack", _ptr(wd), _ptr(wp), Cout, Cin, _stream())
+    try:
+        w._vf_small_pack = (key, wp)
+    except AttributeError:
+        pass
+    return wp
+
+
 def _conv_small(x, x2, weight, bias, view_bias, residual, S, Cin, Cout, H, W, KS, m):
     wd = weight.detach()
     _check(wd)
     y = torch.empty(S, Cout, H, W, device=x.device, dtype=torch.float32)
+    wp = _packed_small(weight) if KS == 3 else None
+    if wp is not None:            # the general entry takes the packed copy
+        _launch("conv_fwd", 2.0 * S * Cout * Cin * 9 * H * W, "vf_conv_small_gn", _ptr(x), None, 0, _ptr(wd), _ptr(bias),
+                _ptr(view_bias), _ptr(residual), _ptr(y), S, Cin, Cout, H, W, 3, None, None, None, 0, 1e-5, 0, None, None,
+                None, 0, 0, None, None, _ptr(wp), m, _stream(), tag=(Cin, Cout, H, KS, m))
+        return y
     _launch("conv_fwd", 2.0 * S * Cout * Cin * KS * KS * H * W, "vf_conv_small", _ptr(x), _ptr(x2),
             x.shape[1] if x2 is not None else 0, _ptr(wd), _ptr(bias), _ptr(view_bias), _ptr(residual), _ptr(y), S, Cin,
             Cout, H, W, KS, m, _stream(), tag=(Cin, Cout, H, KS, m))
@@ -883,7 +917,8 @@ def _conv_small_gn(x, layer, view_bias=None, residual=None, res_fold=None, want_
             _ptr(lazy.gn.weight) if lazy is not None else None, _ptr(lazy.gn.bias) if lazy is not None else None,
             lazy.groups if lazy is not None else 0, 1e-5, int(lazy.silu) if lazy is not None else 0,
             ctypes.c_void_p(stats.data_ptr()) if stats is not None else None, _ptr(rx), _ptr(rx2), rC1, rC, _ptr(rwd),
-            _ptr(rl.bias) if rl is not None else None, _stream(), tag=(Cin, Cout, H, KS, 0))
+            _ptr(rl.bias) if rl is not None else None, _ptr(_packed_small(layer)) if KS == 3 else None, 0, _stream(),
+            tag=(Cin, Cout, H, KS, 0))
     return (y, stats) if want_stats else y
 
 
@@ -903,6 +938,12 @@ def _conv_small_res(x, layer, view_bias, res_layer, rx, rx2):
     wd, rwd = layer.weight.detach(), res_layer.weight.detach()
     _check(x, wd, rwd, layer.bias, view_bias, rx, rx2, res_layer.bias)
     y = torch.empty(S, Cout, H, W, device=x.device, dtype=torch.float32)
+    wp = _packed_small(layer)
+    if wp is not None:
+        _launch("conv_fwd", 2.0 * S * Cout * (Cin * 9 + rC) * H * W, "vf_conv_small_gn", _ptr(x), None, 0, _ptr(wd),
+                _ptr(layer.bias), _ptr(view_bias), None, _ptr(y), S, Cin, Cout, H, W, 3, None, None, None, 0, 1e-5, 0, None,
+                _ptr(rx), _ptr(rx2), rC1, rC, _ptr(rwd), _ptr(res_layer.bias), _ptr(wp), 0, _stream(), tag=(Cin, Cout, H, 3, 0))
+        return y
     _launch("conv_fwd", 2.0 * S * Cout * (Cin * 9 + rC) * H * W, "vf_conv_small_res", _ptr(x), _ptr(wd), _ptr(layer.bias),
             _ptr(view_bias), _ptr(y), S, Cin, Cout, H, W, _ptr(rx), _ptr(rx2), rC1, rC, _ptr(rwd), _ptr(res_layer.bias),
             _stream(), tag=(Cin, Cout, H, 3, 0))
