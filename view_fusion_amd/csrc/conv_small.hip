@@ -277,11 +277,7 @@ __global__ __launch_bounds__(512) void conv3_small_kernel(SmallArgs a) {
     const float* wa[RS];
 #pragma unroll
     for (int rs = 0; rs < RS; ++rs)
-#ifdef VF_SMALL_FAKEW     /* diagnostic build (timing only, wrong results): every lane of a quarter reads the SAME weight row */
-        wa[rs] = a.w + (size_t)min(cot * TCO + 16 * rs, a.Cout - 1) * K + (size_t)c0 * 9 + 4 * kk;
-#else
         wa[rs] = a.w + (size_t)min(cot * TCO + 16 * rs + j, a.Cout - 1) * K + (size_t)c0 * 9 + 4 * kk;
-#endif
 
     const int nrp = (cw + RND - 1) / RND;
     const f32x4* wpk[RS];
