@@ -200,6 +200,11 @@ int vf_bgemm(const float* A, const float* B, float* C, const float* bias /*[N]|N
 /* fused attention forward (unet.py:258-277 core): qkv [S][3C][L] -> out [S][C][L]; optionally
  * P [S][L][L] (softmax probabilities, saved for backward).  L in {64,256}, C % 32 == 0. */
 int vf_attention_fwd(const float* qkv, float* out, float* P /*|NULL*/, int S, int C, int L, void* stream);
+/* attention backward (autograd of unet.py:267-274), L = 256, C % 32 == 0, first of three launches:
+ * dS = P o (dP - rowsum(P o dP)) with dP = dO^T V computed in the kernel, and dQ = K dS^T / sqrt(C) -> q third of dqkv;
+ * qkv, dqkv [S][3C][L], dO [S][C][L], P, dS [S][L][L] (dS must not alias P).  dV and dK stay vf_bgemm calls. */
+int vf_attention_dscore(const float* qkv, const float* dO, const float* P, float* dS, float* dqkv, int S, int C, int L,
+                        void* stream);
 int vf_softmax_fwd(const float* x, float* y, int rows, int cols, void* stream);
 int vf_softmax_bwd(const float* y, const float* dy, float* dx, int rows, int cols, void* stream);
 

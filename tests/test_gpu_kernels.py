@@ -550,11 +550,14 @@ def test_linear_swish_embed(dev):
 
 
 @pytest.mark.parametrize("C,H,S", [(192, 16, 3), (320, 8, 3), (64, 8, 3), (192, 16, 56), (96, 16, 53), (64, 16, 1),
-                                   (192, 16, 17)])
+                                   (192, 16, 17), (192, 16, 100), (32, 16, 24), (96, 16, 3)])
 def test_attention_fwd_bwd(dev, C, H, S):
-    """S <= 16 at L=256 (C a multiple of 64) runs the 16-query kernel of round 5 (the sampler's), 17 <= S <= 52 and
-    every L=64 call the key-split kernel (32 queries per workgroup, one wave per 32 keys); more views at L=256 run the
-    128-query kernel (the training shape).  All three write the probabilities for the backward pass here."""
+    """S <= 16 at L=256 (C a multiple of 64) runs the 16-query kernel of round 5 (the sampler's); every other L=256 call the
+    32-query kernel (round 5: 8 S workgroups, whole groups of eight views placed per XCD + a plain-order remainder -- S = 17,
+    53, 56; C = 32 is its shortest channel loop) or, where 2 S workgroups fill the chip better (S = 100), the 128-query
+    kernel; L=64 the key-split kernel.  All write the probabilities for the backward pass here.  Backward at L=256: one
+    launch of the 32-query kernel in its second role (dS from dP = dO^T V and P in registers, then dQ = K dS^T) + the dV and dK
+    batched products; at L=64 four batched products + the softmax backward."""
     from view_fusion_amd import ops
     L = H * H
     qkv, gy = rnd(S, 3 * C, H, H, seed=1) * 2, rnd(S, C, H, H, seed=2)
@@ -570,7 +573,7 @@ def test_attention_fwd_bwd(dev, C, H, S):
 
 
 @pytest.mark.parametrize("C,H,S", [(192, 16, 2), (320, 8, 2), (32, 32, 2), (192, 16, 12), (192, 16, 40), (192, 16, 60), (320, 8, 40),
-                                   (320, 16, 16), (192, 16, 1), (96, 16, 5)])
+                                   (320, 16, 16), (192, 16, 1), (96, 16, 5), (192, 16, 96), (192, 16, 128), (64, 16, 150)])
 def test_attention_inference_path(dev, C, H, S):
     """no-grad call: fused kernels without the probability write (L=64/256, both view-count regimes) / generic
     path (L=1024)."""

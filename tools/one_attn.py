@@ -11,7 +11,7 @@ from view_fusion_amd import _lib  # noqa: E402
 
 dev = torch.device("cuda:0")
 for (L, C) in ((256, 192), (64, 320)):
-    for S in (1, 6, 12, 32, 44, 48, 96):
+    for S in ((1, 6, 12, 17, 20, 24, 28, 32, 44, 48, 53, 56, 64, 72, 80, 88, 96, 100, 104, 112, 120, 128, 144, 160, 192, 256) if L == 256 else (1, 6, 12, 48, 96)):
         for wantP in (False, True):
             g = torch.Generator(device="cpu").manual_seed(S + L)
             qkv = torch.randn(S, 3 * C, L, generator=g).to(dev)

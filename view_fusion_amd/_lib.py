@@ -74,6 +74,7 @@ SIGNATURES = {
     "vf_time_affine_bwd": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "vf_bgemm": [_P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _L, _L, _L, _L, _L, _F, _F, _P],
     "vf_attention_fwd": [_P, _P, _P, _I, _I, _I, _P],
+    "vf_attention_dscore": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
     "vf_softmax_fwd": [_P, _P, _I, _I, _P],
     "vf_softmax_bwd": [_P, _P, _P, _I, _I, _P],
     "vf_sincos_embed": [_P, _P, _P, _I, _I, _P],

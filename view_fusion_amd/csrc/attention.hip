@@ -9,9 +9,13 @@
 //     the k order, V is fetched in that order with one 16-byte read per four MFMAs;
 //   * O comes out with the query on the lane -> coalesced NCHW stores.
 // Optionally writes P (S,L,L) for the backward pass.  Bound: fp32 MFMA.
-//   attn_fwd_kh_kernel        L = 256, many views (training): 128 queries per workgroup, 8 waves = 4 query blocks x
-//                             2 key halves; K/Q chunks and V tiles double-buffered in LDS
-//   attn_fwd_split_kernel<L>  few views (sampler) and L = 64: 32 queries per workgroup, one wave per 32 keys
+//   attn_fwd_q32_kernel       L = 256, S >= 17 (training, round 5): 32 queries per workgroup, 4 waves = 4 key quarters,
+//                             three workgroups per compute unit, the eight workgroups of a view on one XCD
+//   attn_fwd_kh_kernel        L = 256 where 2 S workgroups fill the chip better than 8 S (S = 97..128, 225..256, ...):
+//                             128 queries per workgroup, 8 waves = 4 query blocks x 2 key halves; K/Q chunks and V
+//                             tiles double-buffered in LDS
+//   attn_fwd_split_kernel<L>  L = 64: 32 queries per workgroup, one wave per 32 keys
+//   attn_fwd_q16_kernel<L>    S <= 16 (the sampler): 16 queries per workgroup
 #include "common.h"
 
 namespace {
@@ -219,6 +223,279 @@ __global__ __launch_bounds__(512) void attn_fwd_kh_kernel(const float* __restric
         long long* o = reinterpret_cast<long long*>(P) + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8;
         o[0] = st_[0]; o[1] = st_[1]; o[2] = st_[2]; o[3] = st_[3]; o[4] = clock64(); o[5] = 0;
         o[6] = rt0_; o[7] = wall_clock64();
+    }
+#endif
+}
+
+// Many views, L = 256, 32 queries per workgroup (round 5).  The 128-query kernel above launches 2 S workgroups: at S = 96
+// that is 192 workgroups on 256 compute units -- a quarter of the chip idles whatever the kernel does inside.  This one
+// launches 8 S workgroups of FOUR waves (three resident per compute unit: 768 = 3 x 256 at S = 96): wave w owns the
+// keys [64 w, 64 w + 64) of the workgroup's 32 queries.
+//   * scores: as above (K / Q chunks of 16 channels double-buffered in LDS, one barrier per chunk), two key tiles per wave;
+//   * softmax: statistics of the four key quarters combined through LDS;
+//   * O = V P^T: a wave needs only ITS 64 key columns of V, so every wave stages its own [32 channels][32 keys] pieces
+//     (coalesced 128-byte row segments -> a wave-private LDS slot -> the MFMA k order; no workgroup barrier), and the four
+//     partial O tiles are summed through LDS once per 32-channel tile: every wave finishes four of the sixteen rows;
+//   * K and V are streamed once per 32 queries, i.e. four times as often as above: the eight workgroups of a view are
+//     placed on ONE XCD (block id -> (view, query block) below), so the re-reads hit that XCD's L2.
+// DSCORE (the same kernel as the first half of the attention BACKWARD, round 5): "K" = V, "Q" = dO, so the score phase
+// leaves dP^T = V^T dO in the accumulators, again one query per lane; with the forward's probabilities P (read in the layout
+// the forward stored them) the softmax backward is in-register:  dS = P (dP - sum_keys P dP)  -> dS (S, L, L), which the
+// dK product still needs.  The second phase then runs with K in the place of V: alpha K dS^T = dQ -> the q third of `out` =
+// dqkv (S, 3C, L).  Replaces the dP product (which wrote 25 MB at S = 96), the softmax-backward launch that read it back
+// and the dQ product (which read dS again).
+template <bool DSCORE>
+__global__ __launch_bounds__(256, 3) void attn_fwd_q32_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                              float* __restrict__ P, int C, float alpha, int S,
+                                                              const float* __restrict__ dO, float* __restrict__ dS) {
+    constexpr int L = 256, NTH = 256, NKT = 2, CKA = 16;
+    constexpr int KS = L + 32;                       // K row stride: the two lane halves hit different banks
+    constexpr int KQ = CKA * KS + CKA * 32;          // one K / Q chunk
+    constexpr int RSV = 36, VW = 32 * RSV;           // a wave's V piece [32 channels][32 keys (+ 4)]
+    constexpr int OEX = 4 * 16 * 64;                 // partial O tiles of the four waves
+    constexpr int PV = 4 * VW + 2 * OEX;
+    __shared__ __attribute__((aligned(16))) float lds[2 * KQ > PV ? 2 * KQ : PV];
+    __shared__ float red[2][4][32];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    // block id -> (view, query block): blocks i, i + 8, i + 16 ... run on the same XCD; the eight query blocks of a view
+    // take eight consecutive slots of one XCD (views past the last whole group of eight: plain order)
+    int b, u;
+    {
+        const int i = blockIdx.x, nfull = (S >> 3) << 6;
+        if (i < nfull) { const int j = i >> 3; b = ((j >> 3) << 3) + (i & 7); u = j & 7; }
+        else { const int r = i - nfull; b = ((S >> 3) << 3) + (r >> 3); u = r & 7; }
+    }
+    const int q0 = u * 32;
+    // operands of the two phases: scores = kp^T qp, second phase = vp (.)^T
+    const float* qp = DSCORE ? dO + (size_t)b * C * L : qkv + (size_t)b * 3 * C * L;
+    const float* kp = qkv + ((size_t)b * 3 + (DSCORE ? 2 : 1)) * C * L;
+    const float* vp = qkv + ((size_t)b * 3 + (DSCORE ? 1 : 2)) * C * L;
+#ifdef VF_ATTN_STAMPS   // diagnostic build only (tools/attn_stamps.py q32): phase clocks of wave 0, in the P slot
+    long long st_[6] = {clock64(), 0, 0, 0, 0, 0}, rt0_ = wall_clock64();
+#endif
+
+    f32x16 acc[NKT];
+#pragma unroll
+    for (int t = 0; t < NKT; ++t) acc[t] = (f32x16){0};
+
+    // K chunk = 16 x 256 floats = 1024 float4 (wave w: rows 4 w .. 4 w + 3, one row per instruction); Q chunk = 16 x 32 =
+    // 128 float4 (waves 2 and 3 repeat what 0 and 1 write: no branch in the loop).  In-kernel clocks of the first version:
+    //   * a lone workgroup spent 1900 cycles per chunk for 1024 cycles of MFMAs -- and still did with the chunks requested
+    //     two iterations ahead: not load latency, but what stands between the barrier and the first MFMA (five LDS stores,
+    //     twenty address instructions, five loads, then the first operand reads queue up behind the stores);
+    //   * so: the first operands are read right behind the barrier, the stores and loads of the staging sit BEHIND the
+    //     first pair of MFMAs, and the loads take a scalar base + one per-lane offset (no vector address arithmetic).
+    // Chunks are requested two iterations ahead (two register sets, the loop runs in pairs).
+    f32x4 ka0, ka1, ka2, ka3, qa, kb0, kb1, kb2, kb3, qb_;
+    const int qe = tid & 127;
+    unsigned kvo = (unsigned)((4 * w * L + 4 * lane) * 4);                      // bytes
+    unsigned qvo = (unsigned)(((qe >> 3) * L + q0 + 4 * (qe & 7)) * 4);
+    float* const kst = lds + 4 * w * KS + 4 * lane;
+    float* const qst = lds + CKA * KS + (qe >> 3) * 32 + 4 * (qe & 7);
+#define VF_GLD4(BASE, OFS, IMM) (*(const __attribute__((address_space(1))) f32x4*)((const __attribute__((address_space(1))) char*)(BASE) + (OFS) + (IMM)))
+#define VF_A3_LK(R, I, KC) R##I = VF_GLD4(KC, kvo, (I) * (L * 4));
+#define VF_A3_LOAD(R, Q, C0) { const char* kc_ = uniform_ptr(kp + (size_t)(C0) * L);                               \
+        const char* qc_ = uniform_ptr(qp + (size_t)(C0) * L);                                                    \
+        asm("" : "+s"(kc_), "+s"(qc_), "+v"(kvo), "+v"(qvo));                                                    \
+        VF_A3_LK(R, 0, kc_) VF_A3_LK(R, 1, kc_) VF_A3_LK(R, 2, kc_) VF_A3_LK(R, 3, kc_)                             \
+        Q = VF_GLD4(qc_, qvo, 0); }
+#define VF_A3_SK(R, I, BUF) *reinterpret_cast<f32x4*>(kst + (BUF) * KQ + (I) * KS) = R##I;
+#define VF_A3_STORE(R, Q, BUF) { VF_A3_SK(R, 0, BUF) VF_A3_SK(R, 1, BUF) VF_A3_SK(R, 2, BUF) VF_A3_SK(R, 3, BUF)   \
+        *reinterpret_cast<f32x4*>(qst + (BUF) * KQ) = Q; }
+#define VF_A3_MFMAS(BUF, MID) {                                                                                 \
+        const float* Kl = lds + (BUF) * KQ;                                                                    \
+        const float* kq = Kl + lh * KS + w * (NKT * 32) + li;                                                  \
+        const float* qq = Kl + CKA * KS + lh * 32 + li;                                                        \
+        float bq = qq[0], ak0 = kq[0], ak1 = kq[32];                                                           \
+        _Pragma("unroll")                                                                                      \
+        for (int s = 0; s < CKA / 2; ++s) {                                                                    \
+            float bqn = bq, an0 = ak0, an1 = ak1;                                                              \
+            if (s + 1 < CKA / 2) {                                                                             \
+                bqn = qq[(2 * s + 2) * 32];                                                                    \
+                an0 = kq[(2 * s + 2) * KS];                                                                    \
+                an1 = kq[(2 * s + 2) * KS + 32];                                                               \
+            }                                                                                                  \
+            __builtin_amdgcn_sched_barrier(0);                                                                 \
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ak0, bq, acc[0], 0, 0, 0);                           \
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ak1, bq, acc[1], 0, 0, 0);                           \
+            __builtin_amdgcn_sched_barrier(0);                                                                 \
+            if (s == 0) { MID __builtin_amdgcn_sched_barrier(0); }                                             \
+            bq = bqn; ak0 = an0; ak1 = an1;                                                                    \
+        } }
+    VF_A3_LOAD(ka, qa, 0);
+    VF_A3_STORE(ka, qa, 0);
+    VF_A3_LOAD(ka, qa, CKA);                             // (C >= 32: the dispatcher's C % 32 == 0)
+    VF_A3_LOAD(kb, qb_, min(2 * CKA, C - CKA));
+    __syncthreads();
+    for (int c0 = 0; c0 < C; c0 += 2 * CKA) {            // chunks c0 (buffer 0) and c0 + 16 (buffer 1)
+        // behind the first MFMAs: chunk c0 + 16 -> buffer 1 (last read before the barrier), request chunk c0 + 48
+        // (clamped at the end: re-reads the last one, unused)
+        VF_A3_MFMAS(0, VF_A3_STORE(ka, qa, 1) VF_A3_LOAD(ka, qa, min(c0 + 3 * CKA, C - CKA)));
+        VF_LDS_BARRIER();
+        VF_A3_MFMAS(1, VF_A3_STORE(kb, qb_, 0) VF_A3_LOAD(kb, qb_, min(c0 + 4 * CKA, C - CKA)));
+        VF_LDS_BARRIER();
+    }
+#undef VF_A3_MFMAS
+#undef VF_A3_LOAD
+#undef VF_A3_STORE
+#undef VF_A3_LK
+#undef VF_A3_SK
+
+    // V pieces of this wave: piece n = (channel tile n / 2, key tile n & 1) = 32 rows x 128 bytes, four float4 per lane
+    // (8 rows per instruction); piece 0 is requested now and lands during the softmax
+#ifdef VF_ATTN_STAMPS
+    st_[1] = clock64();
+#endif
+    f32x4 va0, va1, va2, va3, vb0, vb1, vb2, vb3;        // even pieces | odd pieces: requested two pieces ahead
+    // (lane group l / 8 takes rows 4 (l / 8) + I: the four loads of a piece differ by an immediate offset)
+    unsigned vvo = (unsigned)((4 * (lane >> 3) * L + w * (NKT * 32) + 4 * (lane & 7)) * 4);    // bytes
+    float* const Vw = lds + w * VW;
+    float* const vdst = Vw + 4 * (lane >> 3) * RSV + 4 * (lane & 7);
+#define VF_A3_LV(R, I, VC) R##I = VF_GLD4(VC, vvo, (I) * (L * 4));
+#define VF_A3_LOADV(R, N) { const char* vc_ = uniform_ptr(vp + (size_t)(((N) >> 1) * 32) * L + ((N) & 1) * 32);      \
+        asm("" : "+s"(vc_), "+v"(vvo));                                                                          \
+        VF_A3_LV(R, 0, vc_) VF_A3_LV(R, 1, vc_) VF_A3_LV(R, 2, vc_) VF_A3_LV(R, 3, vc_) }
+#define VF_A3_SV(R, I) *reinterpret_cast<f32x4*>(vdst + (I) * RSV) = R##I;
+#define VF_A3_STOREV(R) { VF_A3_SV(R, 0) VF_A3_SV(R, 1) VF_A3_SV(R, 2) VF_A3_SV(R, 3) }
+    const int npiece = C / 16;                           // two per 32-channel tile
+    VF_A3_LOADV(va, 0);
+    VF_A3_LOADV(vb, 1);
+
+    const int qi = q0 + li;
+    if constexpr (DSCORE) {
+        // acc[t][r] = dP[query qi][key 64 w + 32 t + 8 (r / 4) + 4 lh + r % 4]
+        const size_t prow = ((size_t)b * L + qi) * L + w * (NKT * 32) + 4 * lh;
+        float4 pv[NKT][4];
+#pragma unroll
+        for (int t = 0; t < NKT; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) pv[t][g] = *reinterpret_cast<const float4*>(P + prow + t * 32 + 8 * g);
+        float dot = 0.f;
+#pragma unroll
+        for (int t = 0; t < NKT; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                dot += (pv[t][g].x * acc[t][4 * g] + pv[t][g].y * acc[t][4 * g + 1]) +
+                       (pv[t][g].z * acc[t][4 * g + 2] + pv[t][g].w * acc[t][4 * g + 3]);
+        dot += __shfl_xor(dot, 32, 64);
+        if (lh == 0) red[0][w][li] = dot;
+        __syncthreads();
+        VF_A3_STOREV(va);                                // (the staging buffers of the score phase are dead since this barrier)
+        VF_A3_LOADV(va, min(2, npiece - 1));
+        dot = (red[0][0][li] + red[0][1][li]) + (red[0][2][li] + red[0][3][li]);
+#pragma unroll
+        for (int t = 0; t < NKT; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 d = make_float4(pv[t][g].x * (acc[t][4 * g] - dot), pv[t][g].y * (acc[t][4 * g + 1] - dot),
+                                             pv[t][g].z * (acc[t][4 * g + 2] - dot), pv[t][g].w * (acc[t][4 * g + 3] - dot));
+                *reinterpret_cast<float4*>(dS + prow + t * 32 + 8 * g) = d;
+                acc[t][4 * g] = d.x; acc[t][4 * g + 1] = d.y; acc[t][4 * g + 2] = d.z; acc[t][4 * g + 3] = d.w;
+            }
+    } else {
+    // softmax over all keys of the lane's query: this wave's 64 keys, then the other waves' statistics
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < NKT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, acc[t][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    if (lh == 0) red[0][w][li] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0][0][li], red[0][1][li]), fmaxf(red[0][2][li], red[0][3][li]));
+    const float c2 = alpha * 1.44269504088896341f, mc = mx * c2;     // exp(alpha (s - max)) = 2^(c s - c max), one v_exp_f32
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < NKT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float p = __builtin_amdgcn_exp2f(fmaf(acc[t][r], c2, -mc));
+            acc[t][r] = p;
+            sum += p;
+        }
+    sum += __shfl_xor(sum, 32, 64);
+    if (lh == 0) red[1][w][li] = sum;
+    VF_A3_STOREV(va);                                    // (the K / Q buffers are dead since the loop's last barrier)
+    VF_A3_LOADV(va, min(2, npiece - 1));
+    __syncthreads();
+    const float inv = 1.0f / ((red[1][0][li] + red[1][1][li]) + (red[1][2][li] + red[1][3][li]));
+#pragma unroll
+    for (int t = 0; t < NKT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] *= inv;
+
+#ifdef VF_ATTN_STAMPS
+    st_[2] = clock64();
+    if (false) {
+#else
+    if (P) {
+#endif
+        float* pr = P + ((size_t)b * L + qi) * L + w * (NKT * 32);
+#pragma unroll
+        for (int t = 0; t < NKT; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4*>(pr + t * 32 + 8 * g + 4 * lh) =
+                    make_float4(acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]);
+    }
+    }
+
+#ifdef VF_ATTN_STAMPS
+    st_[3] = clock64();
+#endif
+    // O = V P^T.  The wave's LDS instructions execute in order: piece n + 1 is written to the wave's slot behind the last
+    // read of piece n, no barrier.  After the two pieces of a channel tile the four partial tiles meet in oex.
+    float* const oex = lds + 4 * VW;
+    const float* vq = Vw + li * RSV + 4 * lh;
+#define VF_A3_PV(T) {                                                                                          \
+        float4 av = *reinterpret_cast<const float4*>(vq);                                                      \
+        _Pragma("unroll")                                                                                      \
+        for (int g = 0; g < 4; ++g) {                                                                          \
+            float4 avn = av;                                                                                   \
+            if (g + 1 < 4) avn = *reinterpret_cast<const float4*>(vq + (g + 1) * 8);                           \
+            __builtin_amdgcn_sched_barrier(0);                                                                 \
+            o = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, acc[T][4 * g + 0], o, 0, 0, 0);                      \
+            o = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, acc[T][4 * g + 1], o, 0, 0, 0);                      \
+            o = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, acc[T][4 * g + 2], o, 0, 0, 0);                      \
+            o = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, acc[T][4 * g + 3], o, 0, 0, 0);                      \
+            __builtin_amdgcn_sched_barrier(0);                                                                 \
+            av = avn;                                                                                          \
+        } }
+    for (int ct = 0; ct < npiece / 2; ++ct) {            // channel tile ct = pieces 2 ct (key tile 0), 2 ct + 1 (key tile 1)
+        f32x16 o = {0};
+        VF_A3_PV(0)
+        VF_A3_STOREV(vb);                                // piece 2 ct + 1
+        VF_A3_LOADV(vb, min(2 * ct + 3, npiece - 1));    // (clamped at the end: re-read, unused)
+        VF_A3_PV(1)
+        VF_A3_STOREV(va);                                // piece 2 ct + 2 (at the end: rewritten, unused)
+        VF_A3_LOADV(va, min(2 * ct + 4, npiece - 1));
+        float* ox = oex + (ct & 1) * OEX;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ox[(w * 16 + r) * 64 + lane] = o[r];
+        VF_LDS_BARRIER();
+        // rows 4 w .. 4 w + 3 of the tile: channels 32 ct + 8 w + (0..3) + 4 lh
+        float* ob = out + ((size_t)b * (DSCORE ? 3 * C : C) + ct * 32 + 8 * w + 4 * lh) * L + qi;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float* x_ = ox + (4 * w + r) * 64 + lane;
+            const float v_ = (x_[0] + x_[16 * 64]) + (x_[32 * 64] + x_[48 * 64]);
+            ob[(size_t)r * L] = DSCORE ? alpha * v_ : v_;
+        }
+    }
+#undef VF_A3_PV
+#undef VF_A3_LOADV
+#undef VF_A3_STOREV
+#undef VF_A3_LV
+#undef VF_A3_SV
+#undef VF_GLD4
+#ifdef VF_ATTN_STAMPS
+    if (tid == 0 && P) {
+        long long* o_ = reinterpret_cast<long long*>(P) + (size_t)blockIdx.x * 8;
+        o_[0] = st_[0]; o_[1] = st_[1]; o_[2] = st_[2]; o_[3] = st_[3]; o_[4] = clock64(); o_[5] = 0;
+        o_[6] = rt0_; o_[7] = wall_clock64();
     }
 #endif
 }
@@ -525,16 +802,24 @@ int vf_attention_fwd(const float* qkv, float* out, float* P, int S, int C, int L
     if (C % 32 != 0) return (int)hipErrorInvalidValue;
     const float alpha = 1.0f / sqrtf((float)C);
     hipStream_t st = (hipStream_t)stream;
-    // few views (sampler): the key-split kernel cuts the per-wave MFMA chain 8-fold; many views (training): it
-    // would re-stream K and V once per 32 queries (L2-bound), the 128-query kernel wins from S ~ 55 on (key-split
-    // 44.1 us at S = 44, 128-query 58.9 us at S = 48)
-    // (VF_ATTN_Q16=0: tuning aid, the 32-query kernel at every small S)
+    // L = 256 (round 5; profiles/r05_attention_q32.md has the sweep):
+    //   S <= 16 (the sampler)          16-query kernel: 16 S workgroups
+    //   otherwise                      32-query kernel (8 S workgroups of four waves, three per compute unit) or the
+    //                                  128-query kernel (2 S workgroups of eight waves, one per compute unit), whichever
+    //                                  quantises better on 256 compute units: measured ~17.7 us per started group of
+    //                                  32 views against ~66 us per started group of 128 views (S = 96: 54 against 65 us,
+    //                                  S = 128: 72 against 67 us, S = 160: 90 against 117 us)
+    // (VF_ATTN_Q16=0 / VF_ATTN_Q32=0: tuning aids -- the round-4 choice: key-split kernel up to S = 52, 128-query kernel above)
     static const bool q16 = !(getenv("VF_ATTN_Q16") && getenv("VF_ATTN_Q16")[0] == '0');
+    static const bool q32 = !(getenv("VF_ATTN_Q32") && getenv("VF_ATTN_Q32")[0] == '0');
+    const bool q32_wins = 177 * ((S + 31) / 32) + 30 < 660 * ((S + 127) / 128);
     if (L == 256 && S <= 16 && C % 64 == 0 && q16)
         hipLaunchKernelGGL(attn_fwd_q16_kernel<256>, dim3(16, S), dim3(512), 0, st, qkv, out, P, C, alpha);
     else if (L == 64 && S <= 16 && C % 64 == 0 && q16)
         hipLaunchKernelGGL(attn_fwd_q16_kernel<64>, dim3(4, S), dim3(128), 0, st, qkv, out, P, C, alpha);
-    else if (L == 256 && S <= 52)
+    else if (L == 256 && q32 && q32_wins)
+        hipLaunchKernelGGL(attn_fwd_q32_kernel<false>, dim3(8 * S), dim3(256), 0, st, qkv, out, P, C, alpha, S, nullptr, nullptr);
+    else if (L == 256 && S <= 52 && !q32)
         hipLaunchKernelGGL(attn_fwd_split_kernel<256>, dim3(8, S), dim3(512), 0, st, qkv, out, P, C, alpha);
     else if (L == 256)
         hipLaunchKernelGGL(attn_fwd_kh_kernel, dim3(2, S), dim3(512), 0, st, qkv, out, P, C, alpha);
@@ -542,6 +827,19 @@ int vf_attention_fwd(const float* qkv, float* out, float* P, int S, int C, int L
         hipLaunchKernelGGL(attn_fwd_split_kernel<64>, dim3(2, S), dim3(128), 0, st, qkv, out, P, C, alpha);
     else
         return (int)hipErrorInvalidValue;
+    VF_RETURN_LAST_ERROR();
+}
+
+// Attention backward at L = 256 (C a multiple of 32), first launch (attn_fwd_q32_kernel<true>):
+//     dS = P o (dP - rowsum(P o dP)),  dP = dO^T V (never written);    dQ = K dS^T / sqrt(C) -> q third of dqkv
+// qkv, dqkv [S][3C][L], dO [S][C][L], P, dS [S][L][L] (dS may not alias P: the dV product still reads P; the dK product
+// reads dS).
+int vf_attention_dscore(const float* qkv, const float* dO, const float* P, float* dS, float* dqkv, int S, int C, int L,
+                        void* stream) {
+    if (S <= 0) return 0;
+    if (L != 256 || C % 32 != 0 || C < 32) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(attn_fwd_q32_kernel<true>, dim3(8 * S), dim3(256), 0, (hipStream_t)stream, qkv, dqkv,
+                       const_cast<float*>(P), C, 1.0f / sqrtf((float)C), S, dO, dS);
     VF_RETURN_LAST_ERROR();
 }
 

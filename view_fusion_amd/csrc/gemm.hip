@@ -21,6 +21,7 @@ struct GemmArgs {
     int M, N, K;
     long sAb, sAm, sAk, sBb, sBk, sBn, sCb, sCm, sCn;
     float alpha, beta;
+    int xcd_batches;      // bgemm_v2: number of whole groups of eight batch items dealt one item per XCD (0: plain order)
 };
 
 __global__ __launch_bounds__(256) void bgemm_kernel(GemmArgs g) {
@@ -90,7 +91,20 @@ __global__ __launch_bounds__(256) void bgemm_v2_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) float Bl[B_KC ? BN * KS_ : BK * BN];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid & 1, wn = wid >> 1, li = lane & 31, lh = lane >> 5;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN, b = blockIdx.z;
+    // Batched products (attention backward: 12-16 tiles per view, 96 views): consecutive workgroups go to different XCDs,
+    // so in plain order the tiles of ONE view run on all eight XCDs and every XCD's L2 fetches that view's operands from
+    // HBM (PMC: 110 MB per launch for 63 MB of operands + result).  Whole groups of eight views are dealt one view per
+    // XCD (round 5); the views past the last whole group keep the plain order.
+    int bx = blockIdx.x, by = blockIdx.y, b = blockIdx.z;
+    if (g.xcd_batches) {
+        const int nt = gridDim.x * gridDim.y, i = bx + gridDim.x * (by + gridDim.y * b);
+        if (i < (g.xcd_batches << 3) * nt) {
+            const int j = i >> 3, tile = j % nt;
+            b = ((j / nt) << 3) + (i & 7);
+            bx = tile % gridDim.x; by = tile / gridDim.x;
+        }
+    }
+    const int m0 = by * BM, n0 = bx * BN;
     const float* A = g.A + (long)b * g.sAb;
     const float* B = g.B + (long)b * g.sBb;
 
@@ -384,6 +398,8 @@ int vf_bgemm(const float* A, const float* B, float* C, const float* bias, int ba
     g.sCb = sCb; g.sCm = sCm; g.sCn = sCn; g.alpha = alpha; g.beta = beta;
     const dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, batch);
     hipStream_t st = (hipStream_t)stream;
+    static const bool xcd = !(getenv("VF_GEMM_XCD") && getenv("VF_GEMM_XCD")[0] == '0');     // (tuning aid)
+    g.xcd_batches = xcd ? batch / 8 : 0;
     auto mul4 = [](long v) { return (v & 3) == 0; };
     const bool a_kc = sAk == 1, a_mc = sAm == 1, b_kc = sBk == 1, b_nc = sBn == 1;
     const bool fast = (a_kc || a_mc) && (b_kc || b_nc) && sCn == 1 && mul4(K) && mul4(sAb) && mul4(sBb) &&

@@ -1429,6 +1429,10 @@ def sincos_embedding(level, angle, dim):
 
 
 # ---------------------------------------------------------------------------------------------
+# VF_ATTN_DSCORE=0: tuning aid -- the attention backward's dP product + softmax backward as two launches (rounds 1-4)
+ATTN_DSCORE = os.environ.get("VF_ATTN_DSCORE", "1") != "0"
+
+
 class _AttentionFn(torch.autograd.Function):
     """softmax(Q^T K / sqrt(C)) applied to V for single-head spatial attention; qkv (S,3C,H,W)."""
 
@@ -1463,14 +1467,23 @@ class _AttentionFn(torch.autograd.Function):
         dS = torch.empty_like(P)
         global _KIND_OVERRIDE
         _KIND_OVERRIDE = "attn_bwd" if KERNEL_LOG is not None else None
-        # dP[i][j] = sum_c dO[c][i] v[c][j]
-        _bgemm(dO, qkv, dS, None, S, L, L, C, (C * L, 1, L), (C3 * L, L, 1), (L * L, L, 1), offB=2 * C * L)
+        fused_dq = False
+        if L == 256 and C % 32 == 0 and ATTN_DSCORE:
+            # one launch (round 5): dS = P o (dP - rowsum(P o dP)) with dP[i][j] = sum_c dO[c][i] v[c][j] never written,
+            # and dQ[c][i] = alpha sum_j k[c][j] dS[i][j] from the dS values still in registers
+            _call("vf_attention_dscore", _ptr(qkv), _ptr(dO), _ptr(P), _ptr(dS), _ptr(dqkv), S, C, L, _stream(),
+                  flops=4.0 * S * L * L * C)
+            fused_dq = True
+        else:
+            # dP[i][j] = sum_c dO[c][i] v[c][j]
+            _bgemm(dO, qkv, dS, None, S, L, L, C, (C * L, 1, L), (C3 * L, L, 1), (L * L, L, 1), offB=2 * C * L)
+            _call("vf_softmax_bwd", _ptr(P), _ptr(dS), _ptr(dS), S * L, L, _stream())
         # dV[c][j] = sum_i dO[c][i] P[i][j]
         _bgemm(dO, P, dqkv, None, S, C, L, L, (C * L, L, 1), (L * L, L, 1), (C3 * L, L, 1), offC=2 * C * L)
-        _call("vf_softmax_bwd", _ptr(P), _ptr(dS), _ptr(dS), S * L, L, _stream())
-        # dQ[c][i] = alpha sum_j k[c][j] dS[i][j]
-        _bgemm(qkv, dS, dqkv, None, S, C, L, L, (C3 * L, L, 1), (L * L, 1, L), (C3 * L, L, 1), alpha,
-               offA=C * L, offC=0)
+        if not fused_dq:
+            # dQ[c][i] = alpha sum_j k[c][j] dS[i][j]
+            _bgemm(qkv, dS, dqkv, None, S, C, L, L, (C3 * L, L, 1), (L * L, 1, L), (C3 * L, L, 1), alpha,
+                   offA=C * L, offC=0)
         # dK[c][j] = alpha sum_i q[c][i] dS[i][j]
         _bgemm(qkv, dS, dqkv, None, S, C, L, L, (C3 * L, L, 1), (L * L, L, 1), (C3 * L, L, 1), alpha,
                offA=0, offC=C * L)
