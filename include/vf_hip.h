@@ -205,6 +205,9 @@ int vf_attention_fwd(const float* qkv, float* out, float* P /*|NULL*/, int S, in
  * qkv, dqkv [S][3C][L], dO [S][C][L], P, dS [S][L][L] (dS must not alias P).  dV and dK stay vf_bgemm calls. */
 int vf_attention_dscore(const float* qkv, const float* dO, const float* P, float* dS, float* dqkv, int S, int C, int L,
                         void* stream);
+/* ... second launch (C % 64 == 0): dV = dO P and dK = q dS / sqrt(C) -> the v and k thirds of dqkv */
+int vf_attention_dvdk(const float* qkv, const float* dO, const float* P, const float* dS, float* dqkv, int S, int C, int L,
+                      void* stream);
 int vf_softmax_fwd(const float* x, float* y, int rows, int cols, void* stream);
 int vf_softmax_bwd(const float* y, const float* dy, float* dx, int rows, int cols, void* stream);
 

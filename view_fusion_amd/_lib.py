@@ -75,6 +75,7 @@ SIGNATURES = {
     "vf_bgemm": [_P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _L, _L, _L, _L, _L, _F, _F, _P],
     "vf_attention_fwd": [_P, _P, _P, _I, _I, _I, _P],
     "vf_attention_dscore": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "vf_attention_dvdk": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
     "vf_softmax_fwd": [_P, _P, _I, _I, _P],
     "vf_softmax_bwd": [_P, _P, _P, _I, _I, _P],
     "vf_sincos_embed": [_P, _P, _P, _I, _I, _P],

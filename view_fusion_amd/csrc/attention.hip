@@ -791,6 +791,109 @@ __global__ __launch_bounds__(L / 32 * 64) void attn_fwd_q16_kernel(const float* 
 #undef VF_Q16_LV1
 }
 
+// Attention backward at L = 256, the two products that contract over the QUERIES (round 5):
+//     dV[c][j] = sum_i dO[c][i] P[i][j]          dK[c][j] = alpha sum_i q[c][i] dS[i][j]
+// one launch for both: (product, view) pairs x (C / 64) x 2 workgroups of 64 channels x 128 keys; four waves = 2 x 2, a wave
+// owns 32 channels x 64 keys = two accumulators that share the A fragment.  Against the general batched kernel (gemm.hip,
+// 64 x 64 tiles, one accumulator per wave, runtime strides and bounds: ~50 scalar / vector instructions and eight exec-mask
+// branches per 16 MFMAs): no bounds, every load = scalar base + constant per-lane offset, the first operand reads sit right
+// behind the barrier and the next chunk's loads behind the first MFMAs.  A chunk = 32 queries: A image [64 c][32 i (+4)]
+// (a lane's four i values = one ds_read_b128, MFMA step e pairs i = e with i = 4 + e like gemm.hip), B image [32 i][128 j (+4)].
+// One LDS buffer + register prefetch (26 KB: every workgroup of the launch is resident, 4-5 per compute unit).
+// Whole groups of eight (product, view) pairs are dealt one pair per XCD.
+__global__ __launch_bounds__(256, 5) void attn_bwd_dvdk_kernel(const float* __restrict__ qkv, const float* __restrict__ dO,
+                                                               const float* __restrict__ P, const float* __restrict__ dS,
+                                                               float* __restrict__ dqkv, int C, float alpha, int S) {
+    constexpr int L = 256, BKQ = 32, AS = BKQ + 4, BS = 128 + 4;
+    __shared__ __attribute__((aligned(16))) float Al[64 * AS];
+    __shared__ __attribute__((aligned(16))) float Bl[BKQ * BS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = w & 1, wn = w >> 1, li = lane & 31, lh = lane >> 5;
+    const int nt = (C / 64) * 2;                         // tiles per (product, view)
+    int pair, tile;
+    {
+        const int i = blockIdx.x, npair = 2 * S, nfull = (npair >> 3) << 3;
+        if (i < nfull * nt) { const int j = i >> 3; pair = ((j / nt) << 3) + (i & 7); tile = j % nt; }
+        else { const int r = i - nfull * nt; pair = nfull + r / nt; tile = r % nt; }
+    }
+    const int b = pair >> 1, z = pair & 1;               // z = 0: dV, 1: dK
+    const int m0 = (tile >> 1) * 64, n0 = (tile & 1) * 128;
+    const float* A = z ? qkv + (size_t)b * 3 * C * L : dO + (size_t)b * C * L;       // [C][L]: q | dO
+    const float* B = (z ? dS : P) + (size_t)b * L * L + n0;                            // [i][j]
+    float* out = dqkv + ((size_t)b * 3 + (z ? 1 : 2)) * C * L;
+
+    // staging: A = 64 rows x 128 bytes (thread: row tid / 8 (+ 32), 16 bytes), B = 32 rows x 512 bytes (row tid / 32 + 8 i)
+    unsigned avo = (unsigned)(((tid >> 3) * L + 4 * (tid & 7)) * 4), bvo = (unsigned)(((tid >> 5) * L + 4 * (tid & 31)) * 4);
+    f32x4 ar0, ar1, br0, br1, br2, br3;
+#define VF_GLD4(BASE, OFS, IMM) (*(const __attribute__((address_space(1))) f32x4*)((const __attribute__((address_space(1))) char*)(BASE) + (OFS) + (IMM)))
+#define VF_KV_LOAD(K0) {                                                                                        \
+        const char* a0_ = uniform_ptr(A + (size_t)m0 * L + (K0));                                                \
+        const char* a1_ = uniform_ptr(A + (size_t)(m0 + 32) * L + (K0));                                         \
+        const char* b0_ = uniform_ptr(B + (size_t)(K0) * L);                                                     \
+        const char* b1_ = uniform_ptr(B + (size_t)((K0) + 8) * L);                                               \
+        const char* b2_ = uniform_ptr(B + (size_t)((K0) + 16) * L);                                              \
+        const char* b3_ = uniform_ptr(B + (size_t)((K0) + 24) * L);                                              \
+        asm("" : "+s"(a0_), "+s"(a1_), "+s"(b0_), "+s"(b1_), "+s"(b2_), "+s"(b3_), "+v"(avo), "+v"(bvo));        \
+        ar0 = VF_GLD4(a0_, avo, 0); ar1 = VF_GLD4(a1_, avo, 0);                                                  \
+        br0 = VF_GLD4(b0_, bvo, 0); br1 = VF_GLD4(b1_, bvo, 0); br2 = VF_GLD4(b2_, bvo, 0); br3 = VF_GLD4(b3_, bvo, 0); }
+    float* const ast = Al + (tid >> 3) * AS + 4 * (tid & 7);
+    float* const bst = Bl + (tid >> 5) * BS + 4 * (tid & 31);
+#define VF_KV_STORE() {                                                                                         \
+        *reinterpret_cast<f32x4*>(ast) = ar0; *reinterpret_cast<f32x4*>(ast + 32 * AS) = ar1;                    \
+        *reinterpret_cast<f32x4*>(bst) = br0; *reinterpret_cast<f32x4*>(bst + 8 * BS) = br1;                     \
+        *reinterpret_cast<f32x4*>(bst + 16 * BS) = br2; *reinterpret_cast<f32x4*>(bst + 24 * BS) = br3; }
+
+    f32x16 acc0 = {0}, acc1 = {0};
+    const float* af = Al + (wm * 32 + li) * AS + 4 * lh;                 // + 8 grp: i = 8 grp + 4 lh + (0..3)
+    const float* bf = Bl + (4 * lh) * BS + wn * 64 + li;                 // + (8 grp + e) BS (+ 32: second accumulator)
+    VF_KV_LOAD(0);
+    for (int k0 = 0; k0 < L; k0 += BKQ) {
+        VF_LDS_BARRIER();                                // every wave is done reading the previous chunk
+        VF_KV_STORE();
+        VF_LDS_BARRIER();
+        float4 a_cur = *reinterpret_cast<const float4*>(af);
+        float b00 = bf[0], b01 = bf[BS], b02 = bf[2 * BS], b03 = bf[3 * BS];
+        float b10 = bf[32], b11 = bf[BS + 32], b12 = bf[2 * BS + 32], b13 = bf[3 * BS + 32];
+#pragma unroll
+        for (int grp = 0; grp < BKQ / 8; ++grp) {
+            float4 a_nxt = a_cur;
+            float c00 = b00, c01 = b01, c02 = b02, c03 = b03, c10 = b10, c11 = b11, c12 = b12, c13 = b13;
+            if (grp + 1 < BKQ / 8) {
+                a_nxt = *reinterpret_cast<const float4*>(af + 8 * (grp + 1));
+                const float* bn = bf + 8 * (grp + 1) * BS;
+                c00 = bn[0]; c01 = bn[BS]; c02 = bn[2 * BS]; c03 = bn[3 * BS];
+                c10 = bn[32]; c11 = bn[BS + 32]; c12 = bn[2 * BS + 32]; c13 = bn[3 * BS + 32];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.x, b00, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.x, b10, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.y, b01, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.y, b11, acc1, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (grp == 0) { VF_KV_LOAD(min(k0 + BKQ, L - BKQ)); __builtin_amdgcn_sched_barrier(0); }   // (clamped at the end: unused)
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.z, b02, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.z, b12, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.w, b03, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.w, b13, acc1, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            a_cur = a_nxt;
+            b00 = c00; b01 = c01; b02 = c02; b03 = c03; b10 = c10; b11 = c11; b12 = c12; b13 = c13;
+        }
+    }
+#undef VF_KV_LOAD
+#undef VF_KV_STORE
+#undef VF_GLD4
+    const float sc = z ? alpha : 1.0f;
+    float* o = out + (size_t)(m0 + wm * 32 + 4 * lh) * L + n0 + wn * 64 + li;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int c = (r & 3) + 8 * (r >> 2);
+        o[(size_t)c * L] = sc * acc0[r];
+        o[(size_t)c * L + 32] = sc * acc1[r];
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -840,6 +943,17 @@ int vf_attention_dscore(const float* qkv, const float* dO, const float* P, float
     if (L != 256 || C % 32 != 0 || C < 32) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(attn_fwd_q32_kernel<true>, dim3(8 * S), dim3(256), 0, (hipStream_t)stream, qkv, dqkv,
                        const_cast<float*>(P), C, 1.0f / sqrtf((float)C), S, dO, dS);
+    VF_RETURN_LAST_ERROR();
+}
+
+// Attention backward at L = 256 (C a multiple of 64), the other launch: dV = dO P and dK = q dS / sqrt(C) -> the v and k
+// thirds of dqkv (attn_bwd_dvdk_kernel).  dS is what vf_attention_dscore wrote.
+int vf_attention_dvdk(const float* qkv, const float* dO, const float* P, const float* dS, float* dqkv, int S, int C, int L,
+                      void* stream) {
+    if (S <= 0) return 0;
+    if (L != 256 || C % 64 != 0 || C < 64) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(attn_bwd_dvdk_kernel, dim3(2 * S * (C / 64) * 2), dim3(256), 0, (hipStream_t)stream, qkv, dO, P, dS,
+                       dqkv, C, 1.0f / sqrtf((float)C), S);
     VF_RETURN_LAST_ERROR();
 }
 

@@ -1431,6 +1431,7 @@ def sincos_embedding(level, angle, dim):
 # ---------------------------------------------------------------------------------------------
 # VF_ATTN_DSCORE=0: tuning aid -- the attention backward's dP product + softmax backward as two launches (rounds 1-4)
 ATTN_DSCORE = os.environ.get("VF_ATTN_DSCORE", "1") != "0"
+ATTN_DVDK = os.environ.get("VF_ATTN_DVDK", "1") != "0"
 
 
 class _AttentionFn(torch.autograd.Function):
@@ -1478,6 +1479,12 @@ class _AttentionFn(torch.autograd.Function):
             # dP[i][j] = sum_c dO[c][i] v[c][j]
             _bgemm(dO, qkv, dS, None, S, L, L, C, (C * L, 1, L), (C3 * L, L, 1), (L * L, L, 1), offB=2 * C * L)
             _call("vf_softmax_bwd", _ptr(P), _ptr(dS), _ptr(dS), S * L, L, _stream())
+        if fused_dq and C % 64 == 0 and ATTN_DVDK:
+            # dV and dK (below) in one launch of a kernel written for these two products (round 5)
+            _call("vf_attention_dvdk", _ptr(qkv), _ptr(dO), _ptr(P), _ptr(dS), _ptr(dqkv), S, C, L, _stream(),
+                  flops=4.0 * S * L * L * C)
+            _KIND_OVERRIDE = None
+            return dqkv, None
         # dV[c][j] = sum_i dO[c][i] P[i][j]
         _bgemm(dO, P, dqkv, None, S, C, L, L, (C * L, L, 1), (L * L, L, 1), (C3 * L, L, 1), offC=2 * C * L)
         if not fused_dq:
