@@ -197,8 +197,9 @@ FAMILIES = {
     "direct_conv": ("conv_mfma_kernel<KS,LOGW,MODE,NPT> / conv1x1_kernel<NCW>: forward + dgrad of the 1x1 / stride-2 layers", "mfma"),
     "wino_wgrad": ("wino44_wgrad_kernel (Winograd F(4x4,3x3), + slab-sum launch): weight gradient of the stride-1 3x3 layers", "mfma"),
     "direct_wgrad": ("conv1x1_wgrad_kernel / conv_wgrad_kernel (+ reduce): weight gradient of the 1x1 / stride-2 layers", "mfma"),
-    "attn_fwd": ("attn_fwd_kh_kernel / attn_fwd_split_kernel / attn_fwd_q16_kernel", "mfma"),
-    "attn_bwd": ("attention backward: bgemm_v2_kernel x4 + softmax_bwd_kernel on the materialised P", "mfma"),
+    "attn_fwd": ("attn_fwd_q32_kernel<false> (L=256) / attn_fwd_split_kernel<64> (L=64); kh / q16 kernels at other S", "mfma"),
+    "attn_bwd": ("attention backward on the materialised P: attn_fwd_q32_kernel<true> (dS + dQ) + attn_bwd_dvdk_kernel at L=256, "
+                 "bgemm_v2_kernel x4 + softmax_bwd_kernel at L=64", "mfma"),
     "bgemm": ("bgemm kernels outside attention (noise-level MLP linears)", "mfma"),
     "reduce": ("colsum / colsum_multi / rowsum / bias_grad / sumpool2 (parameter-gradient and pooling reductions)", "hbm"),
     "pack": ("pack_weights_multi / wino_pack_multi (weight re-layout, once per step)", "hbm"),
@@ -218,8 +219,8 @@ FAMILY_PMC = {
     "wino_wgrad": (("wino44_wgrad_kernel",), ("wino44_reduce_kernel",)),
     "direct_conv": (("conv_mfma_kernel", "conv1x1_kernel"), ()),
     "direct_wgrad": (("conv1x1_wgrad_kernel", "conv_wgrad_kernel"), ("wgrad_reduce_kernel",)),
-    "attn_fwd": (("attn_fwd_kh_kernel",), ()),
-    "attn_bwd": (("bgemm_v2_kernel", "softmax_bwd_kernel"), ()),      # (one launcher call per kernel)
+    "attn_fwd": (("attn_fwd_q32_kernel<false>", "attn_fwd_kh_kernel", "attn_fwd_split_kernel"), ()),
+    "attn_bwd": (("attn_fwd_q32_kernel<true>", "attn_bwd_dvdk_kernel", "bgemm_v2_kernel", "softmax_bwd_kernel"), ()),      # (one launcher call per kernel)
     "gn_fwd": (("gn_fwd_kernel",), ()), "gn_bwd": (("gn_bwd_fused_kernel",), ()), "adam": (("adam_multi_kernel",), ()),
 }
 

@@ -11,6 +11,9 @@ import csv, glob, json, os, re, sys
 
 def family(name):
     name = name.replace("void ", "").replace("(anonymous namespace)::", "")
+    m = re.match(r"(attn_fwd_q32_kernel<(?:true|false)>)", name)      # one kernel, two roles: forward | backward (dS + dQ)
+    if m:
+        return m.group(1)
     m = re.match(r"([\w:]+?)(?:<|\(|$)", name)
     return m.group(1) if m else name
 

@@ -12,6 +12,9 @@ stats, pmc, steps = sys.argv[1], json.load(open(sys.argv[2])), float(sys.argv[3]
 
 def family(name):
     name = name.replace("void ", "").replace("(anonymous namespace)::", "")
+    m = re.match(r"(attn_fwd_q32_kernel<(?:true|false)>)", name)      # one kernel, two roles: forward | backward (dS + dQ)
+    if m:
+        return m.group(1)
     m = re.match(r"([\w:]+?)(?:<|\(|$)", name)
     return m.group(1) if m else name
 
@@ -23,7 +26,7 @@ for r in csv.DictReader(open(stats)):
 tot = sum(v[1] for v in agg.values())
 print("| kernel family | launches/step | ms/step | share | avg µs | HBM MB/launch (PMC) | achieved TB/s | of 8 TB/s | bound |")
 print("|---|---|---|---|---|---|---|---|---|")
-mfma = {"wino_conv_kernel", "wino44_conv_kernel", "wino_wgrad_kernel", "wino44_wgrad_kernel", "conv1x1_bf16x3_kernel", "conv_mfma_kernel", "conv_wgrad_kernel", "attn_fwd_kernel", "attn_fwd_kh_kernel", "attn_fwd_split_kernel", "conv1x1_wgrad_kernel", "bgemm_v2_kernel",
+mfma = {"wino_conv_kernel", "wino44_conv_kernel", "wino_wgrad_kernel", "wino44_wgrad_kernel", "conv1x1_bf16x3_kernel", "conv_mfma_kernel", "conv_wgrad_kernel", "attn_fwd_kernel", "attn_fwd_kh_kernel", "attn_fwd_split_kernel", "attn_fwd_q32_kernel<false>", "attn_fwd_q32_kernel<true>", "attn_bwd_dvdk_kernel", "conv1x1_wgrad_kernel", "bgemm_v2_kernel",
         "bgemm_kernel"}
 for fam, (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     if t / tot < 0.002:
