@@ -331,7 +331,9 @@ def roofline(trainer, batch, S, ms_step, steps=3):
                             "per additional 64-channel co tile (Cout/64 workgroup columns stream the same x), the "
                             "transformed weight image U (24/9 = 2.67x the 3x3 weights, streamed by every workgroup: "
                             "L2 absorbs most, the rest is HBM/MALL fetch), and the K-split partial tiles of the tail "
-                            "round (written raw and re-read by wino_fixup_kernel)",
+                            "round (written raw and re-read by wino_fixup_kernel); per-shape passes (profiles/r05_hbm_per_shape.md) add one "
+                            "more term for the F(4x4) kernel: its writes are 1.31x y because 40 VGPRs are spilled around (not "
+                            "inside) every tile's chunk loop at the 256-register cap",
                step_floor_ms=dict(direct_fp32_mfma=step_tflop_direct / PEAK_FP32_MATRIX_TFLOPS * 1e3,
                                   winograd_adjusted=floor_ms,
                                   hbm=HBM_MB_PER_VIEW_TRAIN * S / 1e3 / PEAK_HBM_GBS * 1e3),
