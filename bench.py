@@ -216,7 +216,7 @@ FAMILIES = {
 # (kernels the launcher always runs, follow-up kernels it runs for some launches)
 FAMILY_PMC = {
     "wino_conv": (("wino_conv_kernel", "wino44_conv_kernel"), ("wino_fixup_kernel", "wino44_fixup_kernel")),
-    "wino_wgrad": (("wino44_wgrad_kernel",), ("wino44_reduce_kernel",)),
+    "wino_wgrad": (("wino44_wgrad_kernel",), ("wino44_reduce_kernel", "wino44_reduce_multi_kernel")),
     "direct_conv": (("conv_mfma_kernel", "conv1x1_kernel"), ()),
     "direct_wgrad": (("conv1x1_wgrad_kernel", "conv_wgrad_kernel"), ("wgrad_reduce_kernel",)),
     "attn_fwd": (("attn_fwd_q32_kernel<false>", "attn_fwd_kh_kernel", "attn_fwd_split_kernel"), ()),

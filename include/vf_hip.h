@@ -179,6 +179,13 @@ long vf_wino_wgrad_ws_floats(int S, int Cin, int Cout, int H, int W);
  * second [Cout] destination for the same sums (a layer sharing this dY, the residual 1x1 conv, gets its own tensor) */
 int vf_wino_wgrad(const float* x, const float* dy, float* dw_oihw, float* db, float* db2, float* ws, long ws_floats,
                   int S, int Cin, int Cout, int H, int W, int mode, void* stream);
+/* the same without the follow-up slab-sum launch (round 5): only the main kernel runs; desc9 (HOST memory, 9 x int64)
+ * receives this layer's row for vf_wino44_reduce_multi, *nblocks its workgroup count; ws must stay untouched until then.
+ * vf_wino44_reduce_multi sums the slabs of many layers in one launch: table = DEVICE copy of the rows, each row's `first`
+ * field (the int32 at byte 64) set to the sum of the preceding rows' workgroup counts, nblocks = the total. */
+int vf_wino_wgrad_main(const float* x, const float* dy, float* dw_oihw, float* db, float* db2, float* ws, long ws_floats,
+                       int S, int Cin, int Cout, int H, int W, int mode, long long* desc9, int* nblocks, void* stream);
+int vf_wino44_reduce_multi(const void* table, int nrows, int nblocks, void* stream);
 
 /* ---- grouped time-embedding affine: all FeatureWiseAffine Linear(K->C_g) layers of the UNet on the same
  *      (S,K) embedding in one launch, unet.py:160-177.  desc = device int64 [ngroups][5] rows

@@ -138,6 +138,47 @@ def test_small_train_step_natural_policy(dev):
     _small_train_step(dev, B=5, N=4, vc=[3, 1, 4, 2, 3], t=[1500, 3, 700, 1999, 42])
 
 
+def test_weight_gradient_slab_sums_are_deferred_into_one_launch(dev):
+    """Round 5: every Winograd weight gradient runs only its main kernel (vf_wino_wgrad_main, a workspace of its own) and
+    ONE vf_wino44_reduce_multi launch at the end of the backward pass fills all dW / db -- bitwise what the per-layer
+    launches give (same slabs, same order).  A pass that ACCUMULATES into existing .grad tensors must not defer (the
+    destination would be read before it is filled)."""
+    from view_fusion_amd import ops
+    vf = make_vf(SMALL, SCHED_TRAIN, dev, True)
+    g = torch.Generator().manual_seed(5)
+    B, N = 3, 2
+    kw = dict(y_cond=torch.rand(B, N, 3, 64, 64, generator=g).to(dev), view_count=torch.tensor([2, 2, 1]),
+              angle=torch.rand(B, 1, generator=g).to(dev) * 6, y_0=torch.rand(B, 3, 64, 64, generator=g).to(dev),
+              noise=torch.randn(B, 3, 64, 64, generator=g).to(dev), t=torch.tensor([1500, 3, 77]).to(dev),
+              u=torch.rand(B, 1, generator=g).to(dev))
+    params = [p for p in vf.denoise_fn.parameters()]
+
+    def run(defer, zero=True):
+        if zero:
+            for p in params:
+                p.grad = None
+        ops.WRED_DEFER, ops.KERNEL_LOG = defer, []
+        try:
+            vf(**kw).backward()
+            torch.cuda.synchronize()
+            return [e[5] for e in ops.KERNEL_LOG], [p.grad.detach().clone() for p in params]
+        finally:
+            ops.WRED_DEFER, ops.KERNEL_LOG = True, None
+
+    names, g_def = run(True)
+    n_main = names.count("vf_wino_wgrad_main")
+    assert n_main >= 20 and names.count("vf_wino44_reduce_multi") == 1 and "vf_wino_wgrad" not in names, \
+        (n_main, names.count("vf_wino44_reduce_multi"), names.count("vf_wino_wgrad"))
+    names, g_now = run(False)
+    assert names.count("vf_wino_wgrad") == n_main and "vf_wino_wgrad_main" not in names
+    for a, b in zip(g_def, g_now):
+        assert torch.equal(a, b)
+    names, g_acc = run(True, zero=False)                  # second pass on top of the existing gradients
+    assert "vf_wino_wgrad_main" not in names and names.count("vf_wino_wgrad") == n_main
+    for a, b in zip(g_acc, g_now):
+        assert float((a - 2 * b).abs().max()) <= 1e-6 * float(b.abs().max()) + 1e-12
+
+
 def _small_train_step(dev, B=2, N=2, vc=(2, 1), t=(1500, 3)):
     from oracle import unet_ref, view_fusion_ref as vfr
     vf = make_vf(SMALL, SCHED_TRAIN, dev, True)

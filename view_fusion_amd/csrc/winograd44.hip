@@ -27,6 +27,7 @@
 // of the 36-slice dU.  wino44_reduce_kernel sums the slabs in a fixed order (no float atomics) and writes dW (one
 // follow-up launch instead of the F(2x2) kernel's two).
 #include "common.h"
+#include <cstring>
 
 namespace {
 inline int rup44(int v, int m) { return (v + m - 1) / m * m; }
@@ -606,14 +607,14 @@ __global__ __launch_bounds__(512, 2) void wino44_wgrad_kernel(W44Args a) {
 // output channel x 64 input channels; thread (ci, g) sums all nine taps of every fourth slab, the four partial sums
 // meet in LDS, and the 9 x 64 results are written out as one contiguous 2304-byte run of dW.
 // Trailing workgroups: db[co] = sum over the slices' dY sums.
-__global__ __launch_bounds__(256) void wino44_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
-                                                            int Cout, int Cin, int CoutP, int CinQ, int nslab,
-                                                            const float* __restrict__ bsum, float* __restrict__ db,
-                                                            float* db2, int nmain) {
-    if ((int)blockIdx.x >= nmain) {
+__device__ __forceinline__ void wino44_reduce_body(const float* __restrict__ ws, float* __restrict__ dw,
+                                                   int Cout, int Cin, int CoutP, int CinQ, int nslab,
+                                                   const float* __restrict__ bsum, float* __restrict__ db,
+                                                   float* db2, int nmain, int bid) {
+    if (bid >= nmain) {
         __shared__ float red[4][64];
         const int cx = threadIdx.x & 63, g = threadIdx.x >> 6;
-        const int co = ((int)blockIdx.x - nmain) * 64 + cx;
+        const int co = (bid - nmain) * 64 + cx;
         float acc8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (co < Cout) {
             for (int z = g; z < nslab; z += 32) {
@@ -637,7 +638,7 @@ __global__ __launch_bounds__(256) void wino44_reduce_kernel(const float* __restr
     __shared__ float dwl[64 * 9];
     const int cx = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int ncb = (Cin + 63) / 64;
-    const int co = blockIdx.x / ncb, cb = (blockIdx.x % ncb) * 64, ci = cb + cx;
+    const int co = bid / ncb, cb = (bid % ncb) * 64, ci = cb + cx;
     const size_t kst = (size_t)CoutP * CinQ, sst = 9 * kst;
     // thread (ci, g): all nine taps of the slabs z = g, g + 4, ...; two slabs (18 independent loads) in flight
     float s9[9];
@@ -681,8 +682,49 @@ __global__ __launch_bounds__(256) void wino44_reduce_kernel(const float* __restr
     for (int e = threadIdx.x; e < nvalid; e += 256) o[e] = dwl[e];
 }
 
+__global__ __launch_bounds__(256) void wino44_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
+                                                            int Cout, int Cin, int CoutP, int CinQ, int nslab,
+                                                            const float* __restrict__ bsum, float* __restrict__ db,
+                                                            float* db2, int nmain) {
+    wino44_reduce_body(ws, dw, Cout, Cin, CoutP, CinQ, nslab, bsum, db, db2, nmain, (int)blockIdx.x);
+}
+
+// The slab sums of MANY layers in one launch (round 5): the weight gradients are not needed before the optimizer step (or
+// the segment's all-reduce), so a host may run only the main kernel per layer (vf_wino_wgrad_main), keep that layer's
+// workspace alive and sum all of them here -- 65 follow-up launches of ~7 us per training iteration become one (or one
+// per all-reduce segment) that runs at the chip's streaming rate.  Row = what wino44_reduce_kernel takes + the row's first
+// workgroup in this launch (9 x 8 bytes).
+struct W44Red {
+    const float* ws;
+    float* dw;
+    const float* bsum;
+    float* db;
+    float* db2;
+    int Cout, Cin, CoutP, CinQ, nslab, nmain, first, pad;
+};
+static_assert(sizeof(W44Red) == 72, "descriptor row = 9 x int64");
+
+__global__ __launch_bounds__(256) void wino44_reduce_multi_kernel(const W44Red* __restrict__ tab, int nrows) {
+    __shared__ int row_s;
+    if (threadIdx.x == 0) {
+        int lo = 0, hi = nrows - 1;                      // last row whose first workgroup is <= blockIdx.x
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (tab[mid].first <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+        }
+        row_s = lo;
+    }
+    __syncthreads();
+    const W44Red d = tab[row_s];
+    wino44_reduce_body(d.ws, d.dw, d.Cout, d.Cin, d.CoutP, d.CinQ, d.nslab, d.bsum, d.db, d.db2, d.nmain,
+                       (int)blockIdx.x - d.first);
+}
+
+// desc (host memory, 9 x int64, or NULL): when given, the slab sum is NOT launched; the row for vf_wino44_reduce_multi
+// is written there (its `first` field left 0: the caller lays the rows out) and the row's workgroup count goes to *nblocks.
 template <int LOGW, int MODE>
-int launch_wino44_wgrad(W44Args a, float* dw, float* db, float* db2, size_t ws_floats, hipStream_t st) {
+int launch_wino44_wgrad(W44Args a, float* dw, float* db, float* db2, size_t ws_floats, hipStream_t st,
+                        long long* desc = nullptr, int* nblocks = nullptr) {
     constexpr int W = 1 << LOGW;
     a.nchunks = a.S * ((W / 4) * (W / 4) / GT44);
     const int nco = a.CoutP / CO44, nci = a.CinQ / CI44;
@@ -698,6 +740,14 @@ int launch_wino44_wgrad(W44Args a, float* dw, float* db, float* db2, size_t ws_f
     a.bsum = db ? a.ws + (size_t)z * slab_floats : nullptr;      // the per-slice dY sums sit behind the slabs
     hipLaunchKernelGGL((wino44_wgrad_kernel<LOGW, MODE>), dim3(nco, nci, z), dim3(512), 0, st, a);
     const int nmain = a.Cout * ((a.Cin + 63) / 64), nbias = db ? (a.Cout + 63) / 64 : 0;
+    if (desc) {
+        W44Red r;
+        r.ws = a.ws; r.dw = dw; r.bsum = a.bsum; r.db = db; r.db2 = db2;
+        r.Cout = a.Cout; r.Cin = a.Cin; r.CoutP = a.CoutP; r.CinQ = a.CinQ; r.nslab = z; r.nmain = nmain; r.first = 0; r.pad = 0;
+        memcpy(desc, &r, sizeof(r));
+        *nblocks = nmain + nbias;
+        VF_RETURN_LAST_ERROR();
+    }
     hipLaunchKernelGGL(wino44_reduce_kernel, dim3(nmain + nbias), dim3(256), 0, st, a.ws, dw, a.Cout, a.Cin, a.CoutP,
                        a.CinQ, z, a.bsum, db, db2, nmain);
     VF_RETURN_LAST_ERROR();
@@ -742,6 +792,37 @@ int vf_wino_wgrad(const float* x, const float* dy, float* dw, float* db, float* 
     if (W == 32) VF_WG(5);
     VF_WG(6);
 #undef VF_WG
+}
+
+// vf_wino_wgrad without its follow-up launch: the main kernel only; desc9 (HOST memory, 9 x int64) receives the row that
+// vf_wino44_reduce_multi needs for this layer, *nblocks its workgroup count.  ws must stay untouched until that launch.
+int vf_wino_wgrad_main(const float* x, const float* dy, float* dw, float* db, float* db2, float* ws, long ws_floats, int S,
+                       int Cin, int Cout, int H, int W, int mode, long long* desc9, int* nblocks, void* stream) {
+    if (!desc9 || !nblocks) return (int)hipErrorInvalidValue;
+    *nblocks = 0;
+    if (S <= 0) return 0;
+    if (!vf_wino_wgrad_supported(H, W, mode)) return (int)hipErrorInvalidValue;
+    W44Args a;
+    a.x = x; a.dy = dy; a.ws = ws; a.S = S; a.Cin = Cin; a.Cout = Cout;
+    a.CoutP = rup44(Cout, CO44); a.CinQ = rup44(Cin, CI44);
+    hipStream_t st = (hipStream_t)stream;
+#define VF_WG(LW) \
+    return mode == 2 ? launch_wino44_wgrad<LW, 2>(a, dw, db, db2, (size_t)ws_floats, st, desc9, nblocks) \
+                     : launch_wino44_wgrad<LW, 0>(a, dw, db, db2, (size_t)ws_floats, st, desc9, nblocks)
+    if (W == 8) VF_WG(3);
+    if (W == 16) VF_WG(4);
+    if (W == 32) VF_WG(5);
+    VF_WG(6);
+#undef VF_WG
+}
+
+// table: DEVICE memory, nrows rows of 9 x int64 as written by vf_wino_wgrad_main, with the `first` field (int32 at byte 64
+// of a row) = the sum of the preceding rows' workgroup counts; nblocks = the total.
+int vf_wino44_reduce_multi(const void* table, int nrows, int nblocks, void* stream) {
+    if (nrows <= 0 || nblocks <= 0) return 0;
+    hipLaunchKernelGGL(wino44_reduce_multi_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream,
+                       (const W44Red*)table, nrows);
+    VF_RETURN_LAST_ERROR();
 }
 
 }  // extern "C"

@@ -219,6 +219,12 @@ def _gout(p, *shape, like):
 COLSUM_DEFER = True
 _PENDING_COLSUMS = []
 _PENDING_TASK = None      # torch._C._current_graph_task_id() of the backward pass the pending entries belong to
+# Round 5: the slab sums behind the Winograd weight-gradient kernels (65 launches of ~7 us per iteration) are deferred the
+# same way -- every layer runs only its main kernel into a workspace of its own (vf_wino_wgrad_main) and registers a
+# descriptor row; ONE vf_wino44_reduce_multi launch per flush fills dW (and the bias gradients that ride along).  Same
+# conditions, same flush points, same graph-task bookkeeping as the GroupNorm sums.  VF_WRED_DEFER=0: tuning aid.
+WRED_DEFER = os.environ.get("VF_WRED_DEFER", "1") != "0"
+_PENDING_WRED = []        # [(row: list of 9 int64, workgroups, keep-alive tensors)]
 
 
 _CS_TABLE = {}          # device -> {"rows": last uploaded table, "ring": [[pinned, device table, event, rows], ...], "next": i}
@@ -234,9 +240,13 @@ _CS_RING = 16           # staging buffers in rotation (the gradient arena flushe
 _CAPTURE_TABLE = None   # [device table (rows x 6 int64), rows used, host rows, keep-alive] while a Trainer is capturing
 
 
-def begin_capture(device, max_rows):
-    global _CAPTURE_TABLE
+_CAPTURE_TABLE_W = None  # the same for the deferred slab sums: [device table (rows x 9 int64), rows used, host rows, keep-alive]
+
+
+def begin_capture(device, max_rows, max_conv_rows=0):
+    global _CAPTURE_TABLE, _CAPTURE_TABLE_W
     _CAPTURE_TABLE = [torch.empty(max(1, max_rows), 6, dtype=torch.int64, device=device), 0, [], []]
+    _CAPTURE_TABLE_W = [torch.empty(max(1, max_conv_rows), 9, dtype=torch.int64, device=device), 0, [], []] if max_conv_rows else None
 
 
 def prime_tables(net, S, device):
@@ -258,16 +268,80 @@ def prime_tables(net, S, device):
 def end_capture():
     """Upload the tables of the capture that just ended; returns what the graph's owner must keep referenced for as
     long as it replays the graph."""
-    global _CAPTURE_TABLE
+    global _CAPTURE_TABLE, _CAPTURE_TABLE_W
     ct, _CAPTURE_TABLE = _CAPTURE_TABLE, None
+    cw, _CAPTURE_TABLE_W = _CAPTURE_TABLE_W, None
     drop_pending_colsums()          # (only a capture that failed half-way leaves any)
     if ct is not None and ct[1]:
         ct[0][:ct[1]].copy_(torch.tensor(ct[2], dtype=torch.int64))
-    return ct
+    if cw is not None and cw[1]:
+        cw[0][:cw[1]].copy_(torch.tensor(cw[2], dtype=torch.int64))
+    return ct, cw
+
+
+_WR_TABLE = {}          # device -> {"ring": [[pinned, device table, event, key, rows, workgroups], ...], "next": i}
+
+
+def _wred_rows(pend):
+    rows, first = [], 0
+    for row, nblk, _ in pend:
+        r = list(row)
+        r[8] = (r[8] & ~0xFFFFFFFF) | first          # `first` = the int32 at byte 64 of the row
+        rows.append(r)
+        first += nblk
+    return rows, first
+
+
+def _flush_wred():
+    global _PENDING_WRED
+    pend, _PENDING_WRED = _PENDING_WRED, []
+    if not pend:
+        return
+    if torch.cuda.is_current_stream_capturing():
+        cw = _CAPTURE_TABLE_W
+        rows, total = _wred_rows(pend)
+        if cw is None or cw[1] + len(rows) > cw[0].shape[0]:
+            raise _lib.VFHipError("deferred weight-gradient slab sums inside a stream capture need ops.begin_capture() "
+                                  "with max_conv_rows >= the number of 3x3 layers (one backward pass per capture)")
+        _launch("conv_wgrad", 0.0, "vf_wino44_reduce_multi", ctypes.c_void_p(cw[0].data_ptr() + 72 * cw[1]), len(rows),
+                total, _stream())
+        cw[1] += len(rows)
+        cw[2] += rows
+        cw[3].append(pend)
+        return
+    key = tuple(v for e in pend for v in e[0])
+    dev = pend[0][2][0].device
+    ent = _WR_TABLE.setdefault(dev, {"ring": [], "next": 0})
+    slot = None
+    for r in ent["ring"]:          # the caching allocator cycles through a few address sets: reuse an uploaded table
+        if r[3] == key:
+            slot = r
+            break
+    if slot is None:
+        rows, total = _wred_rows(pend)
+        n = max(128, len(rows))
+        if len(ent["ring"]) < _CS_RING:
+            slot = [torch.empty(n, 9, dtype=torch.int64).pin_memory(), torch.empty(n, 9, dtype=torch.int64, device=dev),
+                    torch.cuda.Event(), None, 0, 0]
+            ent["ring"].append(slot)
+        else:
+            slot = ent["ring"][ent["next"] % _CS_RING]
+            ent["next"] += 1
+            if slot[0].shape[0] < n:
+                slot[0], slot[1] = (torch.empty(n, 9, dtype=torch.int64).pin_memory(),
+                                    torch.empty(n, 9, dtype=torch.int64, device=dev))
+            slot[2].synchronize()
+        slot[0][:len(rows)].copy_(torch.tensor(rows, dtype=torch.int64))
+        slot[1][:len(rows)].copy_(slot[0][:len(rows)], non_blocking=True)
+        slot[2].record()
+        slot[3], slot[4], slot[5] = key, len(rows), total
+    _launch("conv_wgrad", 0.0, "vf_wino44_reduce_multi", ctypes.c_void_p(slot[1].data_ptr()), slot[4], slot[5], _stream())
+    _flush_wred.keep = pend             # workspaces / destinations stay referenced until the next flush
 
 
 def _flush_colsums():
     global _PENDING_COLSUMS, _PENDING_TASK
+    _flush_wred()
     pend, _PENDING_COLSUMS, _PENDING_TASK = _PENDING_COLSUMS, [], None
     if not pend:
         return
@@ -335,30 +409,39 @@ def _defer_ok(params):
 
 def _colsum(parts, dgb, batch, S, C, params):
     """dgb[b][c] = sum_s parts[b][s][c], now or (see above) deferred to the flush of the running backward pass."""
-    global _PENDING_TASK
-    task = torch._C._current_graph_task_id()
-    if (COLSUM_DEFER and task != -1 and _defer_ok(params)
-            and (_CAPTURE_TABLE is not None or not torch.cuda.is_current_stream_capturing())):
-        if _PENDING_COLSUMS and _PENDING_TASK != task:
-            # entries of another graph task: a backward pass that failed (its callback never ran) -- or the OUTER pass
-            # of a re-entrant backward (torch.utils.checkpoint, autograd.grad inside a backward), whose destinations
-            # autograd will still hand out.  Outside a capture filling them now is always right (the entries keep
-            # their tensors alive); inside a capture the abort path has already dropped them (drop_pending_colsums).
-            if torch.cuda.is_current_stream_capturing():
-                _PENDING_COLSUMS.clear()
-            else:
-                _flush_colsums()
-        if not _PENDING_COLSUMS:
-            _PENDING_TASK = task
-            torch.autograd.Variable._execution_engine.queue_callback(_flush_colsums)
+    # (entries of another graph task: a backward pass that failed (its callback never ran) -- or the OUTER pass of a
+    # re-entrant backward (torch.utils.checkpoint, autograd.grad inside a backward), whose destinations autograd will still
+    # hand out.  Outside a capture filling them now is always right (the entries keep their tensors alive); inside a
+    # capture the abort path has already dropped them (drop_pending_colsums).  _defer_begin does that.)
+    if _defer_begin(params, _CAPTURE_TABLE):
         _PENDING_COLSUMS.append((parts, dgb, batch, S, C))
         return
     _call("vf_colsum", _ptr(parts), _ptr(dgb), batch, S, C, _stream())
 
 
+def _defer_begin(params, capture_table):
+    """Common entry of the two deferrals: True when a destination may be filled at the flush of the running backward
+    pass; makes sure that flush is queued and that entries of another graph task are dealt with first."""
+    global _PENDING_TASK
+    task = torch._C._current_graph_task_id()
+    if not (COLSUM_DEFER and task != -1 and _defer_ok(params)
+            and (capture_table is not None or not torch.cuda.is_current_stream_capturing())):
+        return False
+    if (_PENDING_COLSUMS or _PENDING_WRED) and _PENDING_TASK != task:
+        if torch.cuda.is_current_stream_capturing():
+            _PENDING_COLSUMS.clear()
+            _PENDING_WRED.clear()
+        else:
+            _flush_colsums()
+    if not _PENDING_COLSUMS and not _PENDING_WRED:
+        _PENDING_TASK = task
+        torch.autograd.Variable._execution_engine.queue_callback(_flush_colsums)
+    return True
+
+
 def flush_colsums():
     """Fill the destinations registered so far (the gradient arena calls this before a segment's all-reduce)."""
-    if _PENDING_COLSUMS:
+    if _PENDING_COLSUMS or _PENDING_WRED:
         _flush_colsums()
 
 
@@ -366,6 +449,7 @@ def drop_pending_colsums():
     """Forget deferred sums of a backward pass that did not complete (capture failure paths)."""
     global _PENDING_TASK
     _PENDING_COLSUMS.clear()
+    _PENDING_WRED.clear()
     _PENDING_TASK = None
 
 
@@ -1043,7 +1127,7 @@ class _Conv2dFn(torch.autograd.Function):
         arena = reducer.ACTIVE is not None
         hit = _rowsum_get(dy) if (want_b or want_v) else None
         if hit is not None:
-            dvb, db = hit[1], hit[2]
+            dvb, db = hit[1], (hit[2].view_as(hit[2]) if hit[2] is not None else None)   # (a fresh object: see _fresh)
         db2 = None            # this dY's channel sums for the residual 1x1 conv, in a tensor of its own
         if ctx.needs_input_grad[1] and use_winograd_wgrad(S, Cin, Cout, H, W, KS, m):
             need = _lib.load().vf_wino_wgrad_ws_floats(S, Cin, Cout, H, W)
@@ -1056,8 +1140,26 @@ class _Conv2dFn(torch.autograd.Function):
                 db = db_here = _gout(ctx.pb, Cout, like=x)
                 if hr:
                     db2 = _gout(ctx.twin, Cout, like=x)
-            _launch("conv_wgrad", ctx.flops, "vf_wino_wgrad", _ptr(x), _ptr(dy), _ptr(dw), _ptr(db_here), _ptr(db2),
-                    _ptr(ws), ws.numel(), S, Cin, Cout, H, W, m, st, tag=ctx.tag)
+            owners = [ctx.pw] + ([ctx.pb] if db_here is not None else []) + \
+                     ([ctx.twin] if (db2 is not None and ctx.twin is not None) else [])   # (identity residual: nobody owns db2)
+            if WRED_DEFER and _defer_begin(owners, _CAPTURE_TABLE_W):
+                # main kernel only, into a workspace of this layer's own; the slab sum joins the pass's one multi launch
+                ws = torch.empty(int(need), device=x.device, dtype=torch.float32)
+                row, nblk = (ctypes.c_longlong * 9)(), ctypes.c_int(0)
+                _launch("conv_wgrad", ctx.flops, "vf_wino_wgrad_main", _ptr(x), _ptr(dy), _ptr(dw), _ptr(db_here), _ptr(db2),
+                        _ptr(ws), ws.numel(), S, Cin, Cout, H, W, m, ctypes.cast(row, ctypes.c_void_p),
+                        ctypes.cast(ctypes.pointer(nblk), ctypes.c_void_p), st, tag=ctx.tag)
+                _PENDING_WRED.append((list(row), nblk.value, (ws, x, dy, dw, db_here, db2)))
+                # AccumulateGrad adopts an incoming gradient only while nobody else references that tensor OBJECT; any
+                # other reference (the entry above; a view's ._base) makes it clone the -- still unfilled -- tensor.  So
+                # autograd gets fresh views (as the GroupNorm sums do with dgb[0] / dgb[1]); db2 reaches the residual conv
+                # through _rowsum_put and is re-viewed there.
+                dw = dw.view_as(dw)
+                if db_here is not None:
+                    db = db_here.view_as(db_here)
+            else:
+                _launch("conv_wgrad", ctx.flops, "vf_wino_wgrad", _ptr(x), _ptr(dy), _ptr(dw), _ptr(db_here), _ptr(db2),
+                        _ptr(ws), ws.numel(), S, Cin, Cout, H, W, m, st, tag=ctx.tag)
         elif ctx.needs_input_grad[1]:
             need = _lib.load().vf_conv_wgrad_ws_floats(S, Cin, Cout, H, W, KS)
             ws = _workspace(x.device, need)
@@ -1142,7 +1244,7 @@ class _Conv1x1CatFn(torch.autograd.Function):
                     ws.numel(), S, Cin, Cout, H, W, st, tag=tag)
         if ctx.has_bias and ctx.needs_input_grad[3]:
             hit = _rowsum_get(dy)                     # the 3x3 conv this output is added to has summed this dY
-            db = hit[2] if hit is not None else None
+            db = hit[2].view_as(hit[2]) if (hit is not None and hit[2] is not None) else None     # (a fresh object: see _fresh)
             if db is None:
                 dvb = hit[1] if hit is not None else None
                 if dvb is None:

@@ -284,7 +284,8 @@ class Trainer:
         self.opt.zero_grad()                           # the capture allocates the gradients in the graph's pool
         g = torch.cuda.CUDAGraph()
         kw = {} if self._pool is None else dict(pool=self._pool)
-        ops.begin_capture(dev, sum(1 for m in self.module.modules() if isinstance(m, torch.nn.GroupNorm)))
+        ops.begin_capture(dev, sum(1 for m in self.module.modules() if isinstance(m, torch.nn.GroupNorm)),
+                          sum(1 for m in self.module.modules() if isinstance(m, torch.nn.Conv2d)))
         failed = None
         try:
             with torch.cuda.graph(g, capture_error_mode="relaxed", **kw):
