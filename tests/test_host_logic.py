@@ -240,3 +240,31 @@ def test_winograd_kernel_choice_is_host_logic():
     finally:
         ops.FORCE_WINOGRAD = ops.FORCE_WINOGRAD44 = False
     assert ops.use_winograd(96, 64, 64, 64, 64, 3, 0, True) and not ops.use_winograd(1, 64, 64, 64, 64, 3, 0, False)
+
+
+def test_deferred_slab_sum_table_is_host_logic():
+    """Round 5: the rows of the one slab-sum launch per backward pass (ops._wred_rows).  Each row is what the main kernel's
+    launcher wrote (9 x int64: five pointers, then int32 pairs); the host only fills the row's `first` field -- the low half
+    of word 8 -- with the running sum of the preceding rows' workgroup counts, and leaves everything else alone."""
+    from view_fusion_amd import ops
+    mk = lambda tag, pad: ([tag + i for i in range(8)] + [pad << 32], )
+    pend = [(mk(100, 0)[0], 65, None), (mk(200, 7)[0], 1280, None), (mk(300, 0)[0], 3, None)]
+    rows, total = ops._wred_rows(pend)
+    assert total == 65 + 1280 + 3
+    assert [r[8] & 0xFFFFFFFF for r in rows] == [0, 65, 65 + 1280]
+    assert [r[8] >> 32 for r in rows] == [0, 7, 0]                    # the upper half (padding) is not touched
+    assert [r[:8] for r in rows] == [p[0][:8] for p in pend]
+    assert pend[1][0][8] == 7 << 32                                  # the registered rows themselves stay as they were
+
+
+def test_attention_kernel_choice_mirrors_the_launcher():
+    """The L = 256 attention forward picks between 8 S workgroups of the 32-query kernel (three per compute unit) and 2 S
+    workgroups of the 128-query kernel by a two-term cost model (attention.hip, vf_attention_fwd); this restates it so that a
+    change of the constants is a conscious one: the training batch S = 96 and the C4 batch S = 48 must take the 32-query
+    kernel, S = 128 (2 S = 256 workgroups: one per compute unit) the 128-query one."""
+    q32_wins = lambda S: 177 * ((S + 31) // 32) + 30 < 660 * ((S + 127) // 128)
+    assert all(q32_wins(S) for S in (17, 32, 48, 64, 96, 144, 160, 192, 224))
+    assert not any(q32_wins(S) for S in (97, 100, 112, 128, 256))
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "view_fusion_amd", "csrc",
+                            "attention.hip")).read()
+    assert "177 * ((S + 31) / 32) + 30 < 660 * ((S + 127) / 128)" in src
