@@ -2,7 +2,7 @@
 #   git stash; python -m view_fusion_amd.build; mkdir -p build/ab; cp view_fusion_amd/lib/libvf_hip.so build/ab/libvf_baseN.so; git stash pop; python -m view_fusion_amd.build
 # (scratch files, removed after the round's measurements; results: profiles/r05_*.md)
 set -x
-cd $GRAFT_REPO_ROOT
+cd "$(dirname "$0")/../.." || exit 1
 python -m pytest tests/test_gpu_kernels.py -q -x -k "wgrad or winograd" -p no:cacheprovider 2>&1 | tail -5
 for i in 1 2; do
 echo "== base"; VF_DEBUG_AB=1 VF_HIP_LIB=$PWD/build/ab/libvf_base.so python tools/wgrad_table.py 2>&1 | grep -v "^\[view" > gpurun_out/r05_wg_base$i.txt; tail -2 gpurun_out/r05_wg_base$i.txt

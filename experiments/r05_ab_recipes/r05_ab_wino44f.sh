@@ -2,7 +2,7 @@
 #   git stash; python -m view_fusion_amd.build; mkdir -p build/ab; cp view_fusion_amd/lib/libvf_hip.so build/ab/libvf_baseN.so; git stash pop; python -m view_fusion_amd.build
 # (scratch files, removed after the round's measurements; results: profiles/r05_*.md)
 set -x
-cd $GRAFT_REPO_ROOT
+cd "$(dirname "$0")/../.." || exit 1
 python -m pytest tests/test_gpu_kernels.py -q -x -k "winograd44 or wino44" -p no:cacheprovider 2>&1 | tail -5
 python -m pytest tests/test_gpu_model.py -q -x -k "extrapolate_real or unet_small_forward" -p no:cacheprovider 2>&1 | tail -3
 echo "== base"; VF_DEBUG_AB=1 VF_HIP_LIB=$PWD/build/ab/libvf_base.so python tools/wino44_table.py 2>&1 | grep -v "^\[view" > gpurun_out/r05_w44_base.txt; tail -1 gpurun_out/r05_w44_base.txt

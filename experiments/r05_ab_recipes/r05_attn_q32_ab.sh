@@ -1,4 +1,4 @@
-# 32-query training attention kernel against the 128-query / key-split ones (VF_ATTN_Q32=0): bash tools/r05_attn_q32_ab.sh
+# 32-query training attention kernel against the 128-query / key-split ones (VF_ATTN_Q32=0): bash experiments/r05_ab_recipes/r05_attn_q32_ab.sh
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 {

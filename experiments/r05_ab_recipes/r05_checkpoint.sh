@@ -1,5 +1,5 @@
 # full GPU suite + the driver's bench command (what the round-end run does) + the other configurations, on one box
-cd $GRAFT_REPO_ROOT
+cd "$(dirname "$0")/../.." || exit 1
 python -m pytest tests -m gpu -q -s --durations=15 -p no:cacheprovider > gpurun_out/r05_gputest_final.log 2>&1; echo rc=$? >> gpurun_out/r05_gputest_final.log
 tail -3 gpurun_out/r05_gputest_final.log
 python bench.py > gpurun_out/r05_bench_final.json 2> gpurun_out/r05_bench_final.err; tail -c 300 gpurun_out/r05_bench_final.json

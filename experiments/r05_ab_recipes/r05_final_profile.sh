@@ -1,4 +1,4 @@
-# Round-5 evidence run on the GPU box (after the code is final):  bash tools/r05_final_profile.sh <commit>
+# Round-5 evidence run on the GPU box (after the code is final):  bash experiments/r05_ab_recipes/r05_final_profile.sh <commit>
 #   1. rocprofv3 --kernel-trace --stats of the bench command            -> gpurun_out/r05_final/kernel_stats.csv
 #   2. FETCH_SIZE / WRITE_SIZE in two separate --pmc passes (--kernel-trace only beside them) -> pmc json
 #   3. SQ counters of the four MFMA-bound shapes of profiles/r04_sq_counters.txt

@@ -1,5 +1,5 @@
 # Evidence run on the final tree (attention kernels of the end of round 5 included): kernel stats of the bench command, then
-# FETCH_SIZE / WRITE_SIZE in two separate --pmc passes.   bash tools/r05_final_profile2.sh <commit>
+# FETCH_SIZE / WRITE_SIZE in two separate --pmc passes.   bash experiments/r05_ab_recipes/r05_final_profile2.sh <commit>
 set -u
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp

@@ -1,5 +1,5 @@
 # sampler A/B: residual conv folded into the block's last 3x3 conv (VF_RES_FOLD), parity first
-cd $GRAFT_REPO_ROOT
+cd "$(dirname "$0")/../.." || exit 1
 python -m pytest tests/test_gpu_kernels.py -q -x -k "folded_residual or conv_small" -p no:cacheprovider 2>&1 | tail -3
 python -m pytest tests/test_gpu_model.py -q -x -k "small_unet_sampler_vs_oracle or generate_chain or c1_small_unet_chain or sampler_drivers" -p no:cacheprovider 2>&1 | tail -3
 for v in 0 1 0 1; do echo "VF_RES_FOLD=$v"; VF_RES_FOLD=$v python tools/bench_sampler.py 2>/dev/null | grep '"graph": true' | python -c "

@@ -1,5 +1,5 @@
 # sampler A/B: GroupNorm without a launch between one-launch convs (VF_GN_LAZY), parity first
-cd $GRAFT_REPO_ROOT
+cd "$(dirname "$0")/../.." || exit 1
 python -m pytest tests/test_gpu_kernels.py -q -x -k "groupnorm_without_a_launch or folded_residual or conv_small" -p no:cacheprovider 2>&1 | tail -15
 python -m pytest tests/test_gpu_model.py -q -x -k "small_unet_sampler_vs_oracle or generate_chain or c1_small_unet_chain or sampler_drivers or unet_small_forward or p_mean_variance or other_geometries" -p no:cacheprovider 2>&1 | tail -15
 for v in 0 1 0 1; do echo "VF_GN_LAZY=$v"; VF_GN_LAZY=$v python tools/bench_sampler.py 2>/dev/null | grep '"graph": true' | python -c "

@@ -1,4 +1,4 @@
-# Sampler kernel stats on the final tree (B = 1, N = 1 and N = 6; HIP-graph replay): bash tools/r05_sampler_profile.sh
+# Sampler kernel stats on the final tree (B = 1, N = 1 and N = 6; HIP-graph replay): bash experiments/r05_ab_recipes/r05_sampler_profile.sh
 set -u
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp

@@ -1,7 +1,7 @@
 # A/B of two builds of the C ABI on one box.  build/ab/libvf_base*.so = the library of the commit BEFORE the change under test:
 #   git stash; python -m view_fusion_amd.build; mkdir -p build/ab; cp view_fusion_amd/lib/libvf_hip.so build/ab/libvf_baseN.so; git stash pop; python -m view_fusion_amd.build
 # (scratch files, removed after the round's measurements; results: profiles/r05_*.md)
-cd $GRAFT_REPO_ROOT
+cd "$(dirname "$0")/../.." || exit 1
 python -m pytest tests/test_gpu_kernels.py -q -x -k "conv_small or folded_residual or groupnorm_without" -p no:cacheprovider 2>&1 | tail -3
 python -m pytest tests/test_gpu_model.py -q -x -k "small_unet_sampler_vs_oracle or generate_chain or c1_small_unet_chain" -p no:cacheprovider 2>&1 | tail -3
 for i in 1 2; do

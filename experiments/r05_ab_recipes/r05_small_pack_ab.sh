@@ -1,4 +1,4 @@
-cd $GRAFT_REPO_ROOT
+cd "$(dirname "$0")/../.." || exit 1
 python -m pytest tests/test_gpu_kernels.py -q -x -k "conv_small or folded_residual or groupnorm_without" -p no:cacheprovider 2>&1 | tail -3
 python -m pytest tests/test_gpu_model.py -q -x -k "small_unet_sampler_vs_oracle or generate_chain or c1_small or weights_are_fresh or unet_small_forward" -p no:cacheprovider 2>&1 | tail -3
 for v in 0 1; do echo "== VF_SMALL_PACK=$v"; VF_SMALL_PACK=$v python tools/small_conv_rounds.py 2>/dev/null; done

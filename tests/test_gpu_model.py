@@ -179,6 +179,53 @@ def test_weight_gradient_slab_sums_are_deferred_into_one_launch(dev):
         assert float((a - 2 * b).abs().max()) <= 1e-6 * float(b.abs().max()) + 1e-12
 
 
+def test_deferred_slab_sums_share_one_arena_across_passes_and_graphs(dev):
+    """Round 6: the deferred layers' slab workspaces are slices of ONE per-device arena refilled from its
+    start by every backward pass -- eager or replayed, whatever the geometry -- and a pending entry keeps neither the
+    layer input nor dY.  Three captured geometries must not add a slab workspace each to the graphs' memory pool."""
+    from view_fusion_amd import ops, train
+    vf = make_vf(SMALL, SCHED_TRAIN, dev, True)
+    tr = train.Trainer(vf, graph=True, lr_warmup=1)
+    g = torch.Generator().manual_seed(3)
+
+    def batch(B, N=2):
+        return dict(y_0=torch.rand(B, 3, 64, 64, generator=g).to(dev), y_cond=torch.rand(B, N, 3, 64, 64, generator=g).to(dev),
+                    angle=(torch.rand(B, 1, generator=g) * 6).to(dev), view_count=torch.full((B,), N))
+
+    seen_entries = []
+    orig = ops._flush_wred
+
+    def spy():
+        seen_entries.extend(ops._PENDING_WRED)
+        orig()
+    ops._flush_wred = spy
+    try:
+        b3 = batch(3)
+        for _ in range(train.Trainer.GRAPH_AFTER + 2):      # eager sightings, capture, one replay
+            tr.step(b3)
+        torch.cuda.synchronize()
+        assert tr.graph_steps >= 1
+        arena0, mem0 = ops.wred_arena_bytes(dev), torch.cuda.memory_allocated(dev)
+        assert arena0 > 0
+        for B in (2, 1):                                     # two smaller geometries: the arena already fits them
+            bb = batch(B)
+            for _ in range(train.Trainer.GRAPH_AFTER + 2):
+                tr.step(bb)
+        torch.cuda.synchronize()
+        assert len(tr._graphs) == 3 and all(e.graph is not None for e in tr._graphs.values())
+        assert ops.wred_arena_bytes(dev) == arena0           # no second arena, no per-graph workspaces
+        grown = torch.cuda.memory_allocated(dev) - mem0
+        # each further graph owns its gradients (136 MB) + activations of its (smaller) geometry; a private set of slab
+        # workspaces would add ~0.25 GB per graph at these sizes on top
+        assert grown < 2.0e9, grown
+    finally:
+        ops._flush_wred = orig
+    assert len(seen_entries) >= 20
+    for row, nblk, keep in seen_entries:
+        assert len(keep) == 4 and keep[0]._base is not None and keep[0].dim() == 1      # (ws = a slice of the arena, dw, db, db2)
+        assert keep[1].dim() == 4 and all(t is None or t.dim() == 1 for t in keep[2:])     # no layer input, no dY
+
+
 def _small_train_step(dev, B=2, N=2, vc=(2, 1), t=(1500, 3)):
     from oracle import unet_ref, view_fusion_ref as vfr
     vf = make_vf(SMALL, SCHED_TRAIN, dev, True)
@@ -316,11 +363,15 @@ def test_gradient_arena_matches_plain_training(dev):
         # captured mode: the failure flag rides the all-reduce, the agreement point steps down to split, which captures
         for graph, env, mode in ((False, {}, "eager"), (True, {}, "captured"),
                                  (True, {"VF_CAPTURE_COLLECTIVES": "0"}, "split"),
-                                 (True, {"VF_TEST_FAIL_CAPTURE": "0:captured"}, "split")):
+                                 (True, {"inject": "0:captured"}, "split")):
+            env = dict(env)
+            train.Trainer.inject_capture_failure = env.pop("inject", None)
+            injected = train.Trainer.inject_capture_failure is not None
             os.environ.update(env)
             try:
                 vf, tr, copied = run(2, graph)           # world=2 only selects the reducer; the group has one rank
             finally:
+                train.Trainer.inject_capture_failure = None
                 for k in env:
                     os.environ.pop(k)
             a = tr.arena
@@ -328,7 +379,7 @@ def test_gradient_arena_matches_plain_training(dev):
             assert copied[1:] == [0] * (STEPS - 1), copied   # zero-copy from the second iteration on (capture included)
             assert all(p.grad.data_ptr() == a.base + 4 * a.off[i] for i, p in enumerate(a.params))
             assert len(a.seg_range) >= 2 and a.seg_range[-1][1] == a.flat.numel()
-            if "VF_TEST_FAIL_CAPTURE" in env:            # it = 4 fails, read at it = 6, sightings 6-7, replay at it = 8
+            if injected:                                 # it = 4 fails, read at it = 6, sightings 6-7, replay at it = 8
                 assert tr.demotions == 1 and tr.graph_steps == 1, (tr.demotions, tr.graph_steps)
             elif graph:                                  # iterations 0-2 eager (layout, two sightings), then replays
                 assert a.capturable == (mode == "captured")

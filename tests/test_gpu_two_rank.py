@@ -61,6 +61,8 @@ def _run(tr, vf, batches, dev):
 
 def _worker(rank, world, port, out, lr, kind, graph, steps, env=None):
     sys.path.insert(0, ROOT)
+    env = dict(env or {})
+    inject = env.pop("inject_capture_failure", None)     # "<rank>:<mode>": a Trainer attribute, not an environment knob
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       VF_REDUCER=kind, **(env or {}))
     import torch.distributed as dist
@@ -70,6 +72,7 @@ def _worker(rank, world, port, out, lr, kind, graph, steps, env=None):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     vf = _model(dev)
     tr = train.Trainer(vf, world=world, lr_warmup=1, graph=graph)
+    tr.inject_capture_failure = inject
     assert (tr.arena is not None) == (kind == "arena")
     tr.it, tr.sched.peak_lr = 0, lr
     copied = []
@@ -136,13 +139,13 @@ def test_capture_failure_on_one_rank_steps_every_rank_down():
     then BOTH step down to the eager mode together; the averaged gradients of every iteration, before, during and
     after, equal single-process gradients on the concatenated batch, and the replicas end bit-identical."""
     STEPS = 9
-    r0, r1 = _spawn(0.0, "arena", True, STEPS, env=dict(VF_TEST_FAIL_CAPTURE="1:split"))
+    r0, r1 = _spawn(0.0, "arena", True, STEPS, env=dict(inject_capture_failure="1:split"))
     # iterations it = 1..9: layout, two eager sightings, capture at it = 4 (rank 1 fails and raises the flag), rank 0
     # replays it = 4, 5; the flag is read at it = 6 (= 2 + 4): everybody eager from there on
     assert r0["graph_steps"] == 2 and r1["graph_steps"] == 0, (r0["graph_steps"], r1["graph_steps"])
     assert r0["mode"] == r1["mode"] == "eager" and r0["demotions"] == r1["demotions"] == 1
     _check_against_global_batch(r0, r1, STEPS, False)
-    r0, r1 = _spawn(1e-4, "arena", True, STEPS, env=dict(VF_TEST_FAIL_CAPTURE="1:split"))
+    r0, r1 = _spawn(1e-4, "arena", True, STEPS, env=dict(inject_capture_failure="1:split"))
     for a, b in zip(r0["params"], r1["params"]):
         assert torch.equal(a, b)
 

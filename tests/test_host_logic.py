@@ -214,6 +214,46 @@ def test_trainer_step_graph_gating_is_host_logic():
     assert tr._graph_key(dict(bt, view_count=[1, 2, 3, 3]), {}) is None          # CPU images
 
 
+def test_multi_rank_agreement_points_are_host_logic():
+    """train.Trainer._agree: the failure flag of the gradient arena is read at iterations every rank
+    computes alike -- 1, 4, 16 after the last change of mode, then every AGREE_EVERY-th -- so a capture that fails late
+    (a new ragged geometry at iteration 1000, a run resumed at it = 100000) is seen within AGREE_EVERY iterations; a
+    raised flag steps the mode down once and restarts the schedule."""
+    class Flag:
+        def __init__(self):
+            self.v, self.reads = 0.0, []
+
+        def item(self):
+            self.reads.append(tr.it)
+            return self.v
+
+        def zero_(self):
+            self.v = 0.0
+
+    class Arena:
+        capturable, flag_value, flat = False, 0.0, None
+
+    tr = train.Trainer(torch.nn.Linear(2, 2), world=1, lr_warmup=1, graph=False)
+    tr.arena, tr._graph_wanted, tr.use_graph = Arena(), True, True
+    tr.arena.flag_acc = f = Flag()
+    base = tr._check_base
+    for tr.it in range(base, base + 300):
+        tr._agree()
+    assert f.reads[:3] == [base + 1, base + 4, base + 16]
+    assert f.reads[3:] == [base + k for k in range(64, 300, 64)]
+    # resumed far into a run: the next read is at most AGREE_EVERY iterations away
+    f.reads.clear()
+    for tr.it in range(100000, 100000 + 2 * train.Trainer.AGREE_EVERY):
+        tr._agree()
+    assert f.reads and f.reads[0] - 100000 < train.Trainer.AGREE_EVERY and len(f.reads) == 2
+    # a raised flag: one demotion (split -> eager), flag cleared, schedule restarts at that iteration
+    f.v = 0.5
+    tr.it = f.reads[-1] + train.Trainer.AGREE_EVERY
+    tr._agree()
+    assert tr.demotions == 1 and tr.mode == "eager" and f.v == 0.0 and tr._check_base == tr.it
+    assert train.Trainer.inject_capture_failure is None and "VF_TEST_FAIL_CAPTURE" not in open(train.__file__).read()
+
+
 def test_winograd_kernel_choice_is_host_logic():
     """ops.wino_kind (round 4): which of the three conv paths a stride-1 3x3 layer takes is decided on the host from the
     library's tile plans and a cost model -- no GPU involved.  At the bench geometry (S = 96) the 64x64 layers and the

@@ -4,10 +4,9 @@ import ctypes, os, subprocess, sys
 import numpy as np
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-so = os.path.join(ROOT, "build", "libvf_attn_stamps.so")
-os.makedirs(os.path.dirname(so), exist_ok=True)
-subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-DVF_ATTN_STAMPS", "-I", os.path.join(ROOT, "include"),
-                os.path.join(ROOT, "view_fusion_amd/csrc/attention.hip"), "-o", so], check=True)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _diag_build import diag_build  # noqa: E402
+so = diag_build("libvf_attn_stamps.so", ["attention.hip"], ["-DVF_ATTN_STAMPS"])
 if len(sys.argv) > 1 and sys.argv[1] == "build":
     sys.exit(0)
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 1

@@ -12,12 +12,9 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-so = os.path.join(ROOT, "build", "libvf_hip_stamps.so")
-if not os.path.exists(so):   # built here (no GPU needed) or on the box
-    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-DVF_CONV_STAMPS", "-I",
-                    os.path.join(ROOT, "include"), os.path.join(ROOT, "view_fusion_amd/csrc/conv.hip"),
-                    os.path.join(ROOT, "view_fusion_amd/csrc/norm.hip"), "-o", so],
-                   check=True)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _diag_build import diag_build  # noqa: E402
+so = diag_build("libvf_hip_stamps.so", ["conv.hip", "norm.hip"], ["-DVF_CONV_STAMPS"])   # built here (no GPU needed) or on the box
 if len(sys.argv) < 5:
     sys.exit(0)
 Cin, Cout, H, KS = (int(v) for v in sys.argv[1:5])

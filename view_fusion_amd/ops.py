@@ -225,6 +225,36 @@ _PENDING_TASK = None      # torch._C._current_graph_task_id() of the backward pa
 # conditions, same flush points, same graph-task bookkeeping as the GroupNorm sums.  VF_WRED_DEFER=0: tuning aid.
 WRED_DEFER = os.environ.get("VF_WRED_DEFER", "1") != "0"
 _PENDING_WRED = []        # [(row: list of 9 int64, workgroups, keep-alive tensors)]
+# The deferred layers' slab workspaces (~18 MiB each, ~1.15 GiB per backward pass at S = 96) are slices of ONE
+# per-device arena that every pass -- eager or replayed, whatever its geometry -- fills from offset 0: passes are
+# ordered on the stream and a pass's slabs are dead once its flush has run.  (Round 5 gave every layer a fresh tensor:
+# inside a captured iteration that pinned 1.15 GiB per graph -- a ragged run holds up to B (N - 1) + 1 graphs.)
+# The arena grows outside captures only (a new, larger tensor; slices already handed out keep the old one alive until
+# their flush, and a graph keeps the arena it was captured with); a captured layer that does not fit runs the
+# non-deferred launch instead.
+_WRED_ARENA = {}          # device -> [arena tensor or None, floats handed out in the running pass]
+
+
+def _wred_ws(device, need):
+    """`need` floats of the slab arena for one layer of the running backward pass, or None (inside a capture, arena
+    too small: the caller launches the non-deferred kernel pair)."""
+    ent = _WRED_ARENA.setdefault(device, [None, 0])
+    n = (int(need) + 63) // 64 * 64
+    cap = 0 if ent[0] is None else ent[0].numel()
+    if ent[1] + n > cap:
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        # (the slices of the old arena stay valid: the pending entries reference them)
+        ent[0] = torch.empty(max(2 * cap, ent[1] + n, 1 << 24), device=device, dtype=torch.float32)
+        ent[1] = 0
+    ws = ent[0][ent[1]:ent[1] + n]
+    ent[1] += n
+    return ws
+
+
+def wred_arena_bytes(device=None):
+    """Bytes of the slab arena(s) currently allocated (tools/long_run.py reports it)."""
+    return sum(4 * e[0].numel() for d, e in _WRED_ARENA.items() if e[0] is not None and (device is None or d == device))
 
 
 _CS_TABLE = {}          # device -> {"rows": last uploaded table, "ring": [[pinned, device table, event, rows], ...], "next": i}
@@ -295,6 +325,8 @@ def _wred_rows(pend):
 def _flush_wred():
     global _PENDING_WRED
     pend, _PENDING_WRED = _PENDING_WRED, []
+    for ent in _WRED_ARENA.values():     # the next pass fills the arena from its start again (stream order)
+        ent[1] = 0
     if not pend:
         return
     if torch.cuda.is_current_stream_capturing():
@@ -451,6 +483,8 @@ def drop_pending_colsums():
     _PENDING_COLSUMS.clear()
     _PENDING_WRED.clear()
     _PENDING_TASK = None
+    for ent in _WRED_ARENA.values():
+        ent[1] = 0
 
 
 def _gn_backward(ctx, dy, addend, addend2=None):
@@ -814,6 +848,9 @@ def pack_all(root, S=None):
             if c is not None and c[0] is not None:
                 object.__setattr__(l, attr, (None, c[1], c[2]))
         object.__setattr__(l, attrs[kind] + "_fresh", True)
+        c = getattr(l.weight, "_vf_small_pack", None)      # the sampler's one-launch 3x3 format: same rule (buffer kept)
+        if c is not None and c[0] is not None:
+            l.weight._vf_small_pack = (None, c[1])
 
 
 # EXPERIMENT, default off: VF_BF16X3=1 routes the forward and dgrad passes of the 1x1 convolutions (maps >= 8x8) through
@@ -1142,14 +1179,16 @@ class _Conv2dFn(torch.autograd.Function):
                     db2 = _gout(ctx.twin, Cout, like=x)
             owners = [ctx.pw] + ([ctx.pb] if db_here is not None else []) + \
                      ([ctx.twin] if (db2 is not None and ctx.twin is not None) else [])   # (identity residual: nobody owns db2)
-            if WRED_DEFER and _defer_begin(owners, _CAPTURE_TABLE_W):
-                # main kernel only, into a workspace of this layer's own; the slab sum joins the pass's one multi launch
-                ws = torch.empty(int(need), device=x.device, dtype=torch.float32)
+            ws_own = _wred_ws(x.device, need) if (WRED_DEFER and _defer_begin(owners, _CAPTURE_TABLE_W)) else None
+            if ws_own is not None:
+                # main kernel only, into this layer's slice of the slab arena; the slab sum joins the pass's one multi launch
+                ws = ws_own
                 row, nblk = (ctypes.c_longlong * 9)(), ctypes.c_int(0)
                 _launch("conv_wgrad", ctx.flops, "vf_wino_wgrad_main", _ptr(x), _ptr(dy), _ptr(dw), _ptr(db_here), _ptr(db2),
                         _ptr(ws), ws.numel(), S, Cin, Cout, H, W, m, ctypes.cast(row, ctypes.c_void_p),
                         ctypes.cast(ctypes.pointer(nblk), ctypes.c_void_p), st, tag=ctx.tag)
-                _PENDING_WRED.append((list(row), nblk.value, (ws, x, dy, dw, db_here, db2)))
+                # (x and dy are not kept: the main kernel has consumed them in stream order; the flush reads ws only)
+                _PENDING_WRED.append((list(row), nblk.value, (ws, dw, db_here, db2)))
                 # AccumulateGrad adopts an incoming gradient only while nobody else references that tensor OBJECT; any
                 # other reference (the entry above; a view's ._base) makes it clone the -- still unfilled -- tensor.  So
                 # autograd gets fresh views (as the GroupNorm sums do with dgb[0] / dgb[1]); db2 reaches the residual conv

@@ -131,6 +131,8 @@ class Trainer:
     another stream into it."""
     GRAPH_AFTER = 2
     GRAPH_MAX = 96
+    AGREE_EVERY = 64            # multi-rank agreement: the failure flag is read at least this often (see _agree)
+    inject_capture_failure = None   # set by tests (class or instance attribute), never read from the environment
 
     def __init__(self, model, world=1, local_rank=0, lr_warmup=2500, decay_it=4000000, bucket_cap_mb=32, graph=None):
         self.module = model
@@ -179,7 +181,7 @@ class Trainer:
         self._graph_epoch = None    # FusedAdam.graph_epoch the kept graphs were captured under (None: none captured)
         self.graph_steps = 0        # iterations that ran as a replay (diagnostics / tests)
         self.world = world
-        self._check_base = self.GRAPH_AFTER     # multi-rank agreement: flag read at _check_base + 1, 4, 16, 64, ...
+        self._check_base = self.GRAPH_AFTER     # multi-rank agreement: flag read at _check_base + 1, 4, 16, then every AGREE_EVERY
         self.demotions = 0
 
     @property
@@ -211,12 +213,16 @@ class Trainer:
 
     def _agree(self):
         """Multi-rank agreement on the launch mode (see the class doc).  Called at the top of every step; reads the
-        arena's accumulated failure flag (one host sync) only at iterations _check_base + 4^j."""
+        arena's accumulated failure flag (one host sync) only at the iteration numbers below."""
         a = self.arena
         if a is None or a.flag_acc is None:
             return
+        # d = 1, 4, 16 after the last change of mode (a capture that fails does so at a geometry's first capture, i.e.
+        # early), then every AGREE_EVERY-th iteration for the rest of the run: a geometry first met at iteration 1000, or a
+        # run whose `it` was restored from a checkpoint, is never more than AGREE_EVERY iterations away from the next
+        # check (one host sync per 64 iterations).  Every rank computes the same iteration numbers.
         d = self.it - self._check_base
-        if d < 1 or (d & (d - 1)) != 0 or (d.bit_length() & 1) == 0:      # d = 1, 4, 16, 64, ...: powers of four
+        if d < 1 or not (d in (1, 4, 16) or d % self.AGREE_EVERY == 0):
             return
         if float(a.flag_acc.item()) == 0.0:        # the same averaged value on every rank
             return
@@ -265,9 +271,9 @@ class Trainer:
         from . import ops
         dev = batch["y_0"].device
         arena = self.arena
-        inj = os.environ.get("VF_TEST_FAIL_CAPTURE")         # tests: "<rank>:<mode>" fails that rank's captures in that mode
+        inj = self.inject_capture_failure    # tests only: "<rank>:<mode>" fails that rank's captures in that mode
         if inj and dist.is_initialized() and inj == f"{dist.get_rank()}:{self.mode}":
-            raise RuntimeError("injected capture failure (VF_TEST_FAIL_CAPTURE)")
+            raise RuntimeError("injected capture failure (Trainer.inject_capture_failure)")
         # With a host-driven transport (gloo) the graph ends with the backward pass; the exchange and the Adam launch
         # follow each replay eagerly.  On RCCL the segment all-reduces and Adam are part of the graph.
         split = arena is not None and not arena.capturable
@@ -375,6 +381,8 @@ class Trainer:
                     try:
                         if not self._capture(e, key, vc, batch, extra):
                             self.use_graph = False
+                            if self.arena is not None:     # this rank stays eager: tell the others (as a failure does)
+                                self.arena.flag_value = 1.0
                     except Exception as err:           # leave the run on the eager path, loudly
                         import sys
                         print(f"[view_fusion_amd] training-step graph capture failed ({type(err).__name__}: {err}); "
