@@ -263,6 +263,30 @@ int vf_adam_multi_dev(const void* desc, int ntensors, long total_blocks, const f
 /* scalars[0..2] = {lr, bc1, bc2}, enqueued on `stream` (values carried as launch arguments) */
 int vf_adam_set_scalars(float* scalars, float lr, float bc1, float bc2, void* stream);
 
+/* ---- gradient exchange next to the path: replaces DistributedDataParallel's bucketed NCCL
+ *      all-reduce + optimizer.step(), experiment.py:104-107, 118-120, 292-293 -- a one-shot all-reduce over IPC-mapped
+ *      peer gradient arenas fused with the Adam update (csrc/xgmi.hip; host side reducer.XgmiArena, VF_REDUCER=xgmi).
+ *      The five memory calls below are the only entry points of the library that allocate / map memory; they run once
+ *      per process, outside any stream. ---- */
+int vf_xgmi_alloc(void** ptr, long bytes);                 /* zero-filled, IPC-exportable device memory */
+int vf_xgmi_free(void* ptr);
+int vf_xgmi_export(void* ptr, void* handle64 /*64 bytes out*/);
+int vf_xgmi_open(const void* handle64, void** ptr);        /* a peer's allocation mapped into this process */
+int vf_xgmi_close(void* ptr);
+/* flag[slot][rank] = epoch in every rank's flag block (unsigned [nslots][world]); peer_flags: HOST array of `world`
+ * device pointers.  Ordered behind everything `stream` has executed before, released at system scope. */
+int vf_xgmi_signal(const void* const* peer_flags, int world, int rank, int slot, unsigned epoch, void* stream);
+/* one wave waits until flag[slot][p] >= epoch for every p and slot in [slot_lo, slot_hi) of this rank's block; gives
+ * up after timeout_us and stores 1 + slot_lo to *status (device unsigned) instead of hanging the queue */
+int vf_xgmi_wait(const void* my_flags, int world, int slot_lo, int slot_hi, unsigned epoch, void* status,
+                 long timeout_us, void* stream);
+/* g = (arena_0 + ... + arena_{W-1}) / W in rank order -> gavg, then vf_adam_multi_dev's update of this rank's own
+ * parameters; desc rows as vf_adam_multi with g = the slot in the LOCAL arena (p == 0: average only);
+ * peer_bases: HOST array of `world` arena base pointers (own rank: my_base) */
+int vf_xgmi_reduce_adam(const void* desc, int ntensors, long total_blocks, const void* const* peer_bases,
+                        const float* my_base, float* gavg_base, int world, const float* scalars, float beta1,
+                        float beta2, float eps, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

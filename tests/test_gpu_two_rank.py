@@ -63,6 +63,7 @@ def _worker(rank, world, port, out, lr, kind, graph, steps, env=None):
     sys.path.insert(0, ROOT)
     env = dict(env or {})
     inject = env.pop("inject_capture_failure", None)     # "<rank>:<mode>": a Trainer attribute, not an environment knob
+    leave_after = int(env.pop("leave_after", 0))         # this many iterations, then rank 1 stops taking part
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       VF_REDUCER=kind, **(env or {}))
     import torch.distributed as dist
@@ -73,15 +74,28 @@ def _worker(rank, world, port, out, lr, kind, graph, steps, env=None):
     vf = _model(dev)
     tr = train.Trainer(vf, world=world, lr_warmup=1, graph=graph)
     tr.inject_capture_failure = inject
-    assert (tr.arena is not None) == (kind == "arena")
+    assert (tr.arena is not None) == (kind in ("arena", "xgmi"))
     tr.it, tr.sched.peak_lr = 0, lr
     copied = []
     grads = []
+    error = None
     for s in range(steps):
-        grads += _run(tr, vf, [_batch(s, rank, ragged=not graph)], dev)
+        if leave_after and rank == 1 and s >= leave_after:
+            break
+        try:
+            grads += _run(tr, vf, [_batch(s, rank, ragged=not graph)], dev)
+        except Exception as e:      # noqa: BLE001
+            error = f"{type(e).__name__}: {e}"
+            break
         copied.append(tr.arena.copied if tr.arena is not None else 0)
+    torch.cuda.synchronize()
+    sd = tr.opt.state_dict()["state"]
     out[rank] = dict(grads=grads, copied=copied, params=[p.detach().cpu().clone() for p in vf.parameters()],
-                     graph_steps=tr.graph_steps, mode=tr.mode, demotions=tr.demotions, info=tr.dist_info())
+                     graph_steps=tr.graph_steps, mode=tr.mode, demotions=tr.demotions, info=tr.dist_info(), error=error,
+                     adam=[(float(v["step"]), v["exp_avg"].cpu(), v["exp_avg_sq"].cpu()) for v in sd.values()] if sd else [])
+    dist.barrier()                  # (a rank's arena stays mapped in its peer until both are done)
+    if hasattr(tr.arena, "close"):
+        tr.arena.close()
     dist.destroy_process_group()
 
 
@@ -148,6 +162,39 @@ def test_capture_failure_on_one_rank_steps_every_rank_down():
     r0, r1 = _spawn(1e-4, "arena", True, STEPS, env=dict(inject_capture_failure="1:split"))
     for a, b in zip(r0["params"], r1["params"]):
         assert torch.equal(a, b)
+
+
+def test_xgmi_reducer_matches_the_arena_bit_for_bit():
+    """SURVEY 8f rank 1 (VF_REDUCER=xgmi): the one-shot all-reduce over IPC-mapped peer arenas fused with Adam
+    (csrc/xgmi.hip), two processes sharing the GPU.  Over six iterations the averaged gradients every rank sees, the
+    parameters and the Adam state (step counts, exp_avg, exp_avg_sq -- torch's layout) equal the gradient arena's
+    (gloo all-reduce + the multi-tensor Adam launch) bit for bit; the replicas equal each other; no gradient is copied
+    from the second iteration on; and with lr = 0 the averaged gradients equal single-process gradients on the
+    concatenated batch."""
+    STEPS = 6
+    a0, a1 = _spawn(1e-4, "arena", False, STEPS)
+    x0, x1 = _spawn(1e-4, "xgmi", False, STEPS)
+    assert x0["error"] is None and x1["error"] is None, (x0["error"], x1["error"])
+    assert x0["info"]["reducer"] == "xgmi" and x0["mode"] == x1["mode"] == "eager"
+    assert x0["copied"][1:] == [0] * (STEPS - 1) and x1["copied"][1:] == [0] * (STEPS - 1), (x0["copied"], x1["copied"])
+    for s in range(STEPS):
+        for ga, g0, g1 in zip(a0["grads"][s], x0["grads"][s], x1["grads"][s]):
+            assert torch.equal(g0, g1) and torch.equal(ga, g0), s
+    for pa, p0, p1 in zip(a0["params"], x0["params"], x1["params"]):
+        assert torch.equal(p0, p1) and torch.equal(pa, p0)
+    assert len(x0["adam"]) == len(a0["adam"]) > 0
+    for (ta, ma, va), (t0, m0, v0) in zip(a0["adam"], x0["adam"]):
+        assert ta == t0 == STEPS and torch.equal(ma, m0) and torch.equal(va, v0)
+    r0, r1 = _spawn(0.0, "xgmi", False, 3)
+    _check_against_global_batch(r0, r1, 3, True)
+
+
+def test_xgmi_reducer_turns_a_missing_peer_into_an_error():
+    """Rank 1 leaves after two iterations: rank 0's device-side waits give up after VF_XGMI_TIMEOUT_S and a later
+    iteration raises VFHipError -- the queue is never left spinning."""
+    r0, r1 = _spawn(1e-4, "xgmi", False, 12, env=dict(VF_XGMI_TIMEOUT_S="0.2", leave_after="2"))
+    assert r1["error"] is None and len(r1["grads"]) == 2
+    assert r0["error"] is not None and "VFHipError" in r0["error"] and "waited" in r0["error"], r0["error"]
 
 
 @pytest.mark.parametrize("kind,graph,STEPS", [("arena", False, 3), ("arena", True, 6), ("ddp", False, 3)])

@@ -95,6 +95,14 @@ SIGNATURES = {
     "vf_conv_small_pack": [_P, _P, _I, _I, _P],
     "vf_adam_multi_dev": [_P, _I, _L, _P, _F, _F, _F, _P],
     "vf_adam_set_scalars": [_P, _F, _F, _F, _P],
+    "vf_xgmi_alloc": [ctypes.POINTER(_P), _L],
+    "vf_xgmi_free": [_P],
+    "vf_xgmi_export": [_P, _P],
+    "vf_xgmi_open": [_P, ctypes.POINTER(_P)],
+    "vf_xgmi_close": [_P],
+    "vf_xgmi_signal": [ctypes.POINTER(_P), _I, _I, _I, ctypes.c_uint, _P],
+    "vf_xgmi_wait": [_P, _I, _I, _I, ctypes.c_uint, _P, _L, _P],
+    "vf_xgmi_reduce_adam": [_P, _I, _L, ctypes.POINTER(_P), _P, _P, _I, _P, _F, _F, _F, _P],
     "vf_psnr": [_P, _P, _P, _I, _I, _P],
     "vf_gather_level": [_P, _P, _P, _P, _I, _P],
     "vf_stack_views": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],

@@ -4,6 +4,7 @@
 // 12 B written per parameter.  Same arithmetic as torch's single-tensor path:
 //   m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; p -= (lr / bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
 #include "common.h"
+#include "adam_update.h"
 
 namespace {
 
@@ -31,12 +32,8 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const AdamDesc* __restr
     const AdamDesc d = desc[lo];
     const long long base = ((long long)blockIdx.x - d.first_block) * ADAM_PER_BLOCK + 4 * threadIdx.x;
     if (base >= d.numel) return;
-    const float step = lr / bc1, rs = 1.0f / sqrtf(bc2);
-    auto upd = [&](float& p, float g, float& m, float& v) {
-        m = b1 * m + (1.0f - b1) * g;
-        v = b2 * v + (1.0f - b2) * g * g;
-        p -= step * m / (sqrtf(v) * rs + eps);
-    };
+    const float step = lr / bc1, rs = 1.0f / sqrtf(bc2), omb1 = 1.0f - b1, omb2 = 1.0f - b2;
+    auto upd = [&](float& p, float g, float& m, float& v) { vf_adam_update(p, g, m, v, b1, b2, omb1, omb2, step, rs, eps); };
     if (base + 4 <= d.numel) {
         float4 p = *reinterpret_cast<float4*>(d.p + base);
         const float4 g = *reinterpret_cast<const float4*>(d.g + base);

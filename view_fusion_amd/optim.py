@@ -29,6 +29,42 @@ class FusedAdam(torch.optim.Optimizer):
         for b in self._plans.get(gi, {}).get("buckets", ()):
             for p in b["params"]:
                 self.state[p]["step"] = torch.tensor(float(b["t"]))
+        ext = getattr(self, "_ext", None)
+        if ext is not None and gi == 0 and ext["epoch"] == self.graph_epoch:
+            for p in ext["params"]:
+                self.state[p]["step"] = torch.tensor(float(ext["t"]))
+
+    # -- an exchange step that applies the update itself (reducer.XgmiArena: all-reduce fused with Adam) -----------
+    def external_begin(self):
+        """One iteration of a reducer that runs this optimizer's update inside its own kernels: state for EVERY
+        parameter (created if missing), one common step count, advanced by one here.  Returns (handle, (lr, 1-b1^t,
+        1-b2^t, b1, b2, eps)); the caller's kernels update p / exp_avg / exp_avg_sq in place (adam.hip's arithmetic), so
+        `state_dict()` stays torch's and a later plain `step()` continues from the same counters."""
+        if len(self.param_groups) != 1:
+            raise _lib.VFHipError("FusedAdam.external_begin: one parameter group")
+        group = self.param_groups[0]
+        ext = getattr(self, "_ext", None)
+        if ext is None or ext["epoch"] != self.graph_epoch:
+            for gi in self._plans:
+                self._flush_steps(gi)
+            steps = set()
+            for p in group["params"]:
+                if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
+                    raise _lib.VFHipError("FusedAdam needs contiguous float32 GPU parameters")
+                st = self.state[p]
+                if not st:
+                    st["step"] = torch.tensor(0.0)
+                    st["exp_avg"] = torch.zeros_like(p)
+                    st["exp_avg_sq"] = torch.zeros_like(p)
+                steps.add(int(float(st["step"])))
+            if len(steps) != 1:
+                raise _lib.VFHipError("FusedAdam.external_begin: the parameters carry different step counts")
+            self._plans = {}                               # (a later plain step() re-reads the counters from the state)
+            ext = self._ext = dict(params=list(group["params"]), t=steps.pop(), epoch=self.graph_epoch)
+        ext["t"] += 1
+        b1, b2 = group["betas"]
+        t = ext["t"]
+        return ext, (float(group["lr"]), 1.0 - b1 ** t, 1.0 - b2 ** t, float(b1), float(b2), float(group["eps"]))
 
     def _plan(self, gi, group):
         """Static part of the descriptor tables {param, grad, exp_avg, exp_avg_sq, numel, first_block}: built once
@@ -39,6 +75,7 @@ class FusedAdam(torch.optim.Optimizer):
         if plan is not None and plan["key"] == key:
             return plan
         self._flush_steps(gi)                          # a changed parameter set must not restart the bias correction
+        self._ext = None                               # (an external reducer's counters have just been flushed)
         self.graph_epoch += 1
         by_step = {}
         for p in params:
@@ -67,7 +104,7 @@ class FusedAdam(torch.optim.Optimizer):
         return plan
 
     def state_dict(self):
-        for gi in self._plans:                         # the per-parameter step counters are kept lazily
+        for gi in set(self._plans) | {0}:              # the per-parameter step counters are kept lazily
             self._flush_steps(gi)
         return super().state_dict()
 

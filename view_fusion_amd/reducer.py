@@ -118,7 +118,7 @@ class GradArena:
             off += self.params[i].numel()
         off = (off + _ALIGN - 1) // _ALIGN * _ALIGN
         self.flag_off = off                                   # the failure flag: one float behind the last slot,
-        self.flat = torch.zeros(off + _ALIGN, device=self.params[0].device, dtype=torch.float32)   # inside the last segment
+        self.flat = self._alloc_flat(off + _ALIGN)            # (the flag lives inside the last segment)
         self.flag_acc = torch.zeros(1, device=self.params[0].device, dtype=torch.float32)
         self.base = self.flat.data_ptr()
         self.seg_of, self.seg_range, k, lo = [0] * n, [], 0, 0
@@ -130,6 +130,12 @@ class GradArena:
                 lo, k = end, k + 1
         self.seg_count = [self.seg_of.count(s) for s in range(len(self.seg_range))]
         self._reset()
+
+    def _alloc_flat(self, n):
+        return torch.zeros(n, device=self.params[0].device, dtype=torch.float32)
+
+    def _after_layout(self):
+        """(subclass hook: the arena exists, the first iteration's gradients have been moved in, nothing is launched yet)"""
 
     def _reset(self):
         self.pending = list(self.seg_count)
@@ -235,6 +241,7 @@ class GradArena:
                     s.copy_(p.grad)
                     p.grad = s
             self.got = got
+            self._after_layout()
         for k, done in enumerate(self.launched):
             if not done:
                 for i, p in enumerate(self.params):
@@ -300,3 +307,222 @@ class GradArena:
             if not done:
                 self._launch(k)
         self._join()
+
+
+# ================================================================================================================
+# VF_REDUCER=xgmi: the hand-written exchange of SURVEY 8f rank 1 -- a one-shot all-reduce over IPC-mapped peer arenas
+# fused with the Adam update (csrc/xgmi.hip).  Default stays the arena over RCCL above.
+# ================================================================================================================
+import ctypes  # noqa: E402
+
+
+class _IpcBuffer:
+    """Device memory a peer process can map (vf_xgmi_alloc / _export / _open).  torch sees it through the CUDA array
+    interface: no copy, and the tensor keeps this object (hence the allocation) alive."""
+
+    def __init__(self, nbytes):
+        from . import _lib
+        ptr = ctypes.c_void_p()
+        _lib.call("vf_xgmi_alloc", ctypes.byref(ptr), int(nbytes))
+        self.ptr, self.nbytes = int(ptr.value), int(nbytes)
+
+    def handle(self):
+        from . import _lib
+        buf = ctypes.create_string_buffer(64)
+        _lib.call("vf_xgmi_export", ctypes.c_void_p(self.ptr), buf)
+        return buf.raw
+
+    def floats(self, n, device):
+        assert 4 * n <= self.nbytes
+        self.__cuda_array_interface__ = dict(shape=(int(n),), typestr="<f4", data=(self.ptr, False), version=2)
+        t = torch.as_tensor(self, device=device)
+        assert t.data_ptr() == self.ptr and t.dtype == torch.float32
+        return t
+
+    def free(self):
+        from . import _lib
+        if self.ptr:
+            _lib.call("vf_xgmi_free", ctypes.c_void_p(self.ptr))
+            self.ptr = 0
+
+
+def _ipc_open(handle):
+    from . import _lib
+    ptr = ctypes.c_void_p()
+    _lib.call("vf_xgmi_open", ctypes.create_string_buffer(handle, 64), ctypes.byref(ptr))
+    return int(ptr.value)
+
+
+class XgmiArena(GradArena):
+    """GradArena whose exchange step is ours too: every rank's arena is mapped into every peer (hipIpc over xGMI on one
+    node); per segment, on a side stream behind the backward pass: signal "my segment is complete" to all peers, wait for
+    theirs, ONE kernel that sums the segment from all W arenas in rank order, writes the average to a local buffer and
+    applies Adam to this rank's parameters (same sums in the same order everywhere: replicas stay bit-identical), signal
+    "done reading".  Replaces the six RCCL all-reduces AND the optimizer launch (`owns_optimizer_step`): Trainer calls
+    begin_step(opt) before the forward pass and skips opt.step().  p.grad shows the averaged gradients after finish(),
+    as with DDP.  Eager launches only (no HIP-graph capture of the iteration in this mode).  A peer that never signals
+    becomes a VFHipError one iteration later (bounded device-side wait), not a hung queue.
+
+    Status: correctness-only.  Tested with two processes sharing one GPU (tests/test_gpu_two_rank.py: gradients and
+    parameters bit-equal to the arena path over six iterations); it has never run across two devices."""
+    owns_optimizer_step = True
+
+    def __init__(self, module, world, segments=6, group=None):
+        super().__init__(module, world, segments=segments, group=group)
+        self.capturable = False
+        self.avg = True                       # (the kernel averages; _join must not scale)
+        self.rank = dist.get_rank(group)
+        self.epoch = 0
+        self.timeout_us = int(float(os.environ.get("VF_XGMI_TIMEOUT_S", "20")) * 1e6)
+        self.comm = torch.cuda.Stream(device=self.params[0].device, priority=-1)
+        self._mem = self._flagmem = None
+        self._opened = []
+        self._tables = None                   # (optimizer epoch, [(device rows, n, blocks)] per segment)
+        self._hyper = None
+        self._status_host = None
+        self._status_ev = None
+
+    # -- memory -------------------------------------------------------------------------------------------------
+    def _alloc_flat(self, n):
+        self._mem = _IpcBuffer(4 * n)
+        return self._mem.floats(n, self.params[0].device)
+
+    def _lay_out(self):
+        super()._lay_out()
+        dev, W, nseg = self.flat.device, self.world, len(self.seg_range)
+        self._flagmem = _IpcBuffer(max(256, 4 * 2 * nseg * W))      # unsigned [ready k | done k][rank]
+        handles = [None] * W
+        dist.all_gather_object(handles, (self._mem.handle(), self._flagmem.handle()), group=self.group)
+        bases, flags = [], []
+        for r, (ha, hf) in enumerate(handles):
+            if r == self.rank:
+                bases.append(self._mem.ptr)
+                flags.append(self._flagmem.ptr)
+            else:
+                a, f = _ipc_open(ha), _ipc_open(hf)
+                self._opened += [a, f]
+                bases.append(a)
+                flags.append(f)
+        self._bases = (ctypes.c_void_p * W)(*bases)
+        self._flags = (ctypes.c_void_p * W)(*flags)
+        self.gavg = torch.zeros_like(self.flat)                      # the averaged gradients (local)
+        self._gviews = [self.gavg[o:o + p.numel()].view(p.shape) for p, o in zip(self.params, self.off)]
+        self.status = torch.zeros(1, device=dev, dtype=torch.int32)
+        self._status_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self._scal = torch.zeros(3, device=dev, dtype=torch.float32)
+        self._events = [torch.cuda.Event() for _ in range(nseg + 1)]
+        dist.barrier(group=self.group)                               # every rank has mapped every rank
+
+    def close(self):
+        """Unmap the peers and free the arena (end of the run; every rank after a barrier)."""
+        from . import _lib
+        torch.cuda.synchronize()
+        for ptr in self._opened:
+            _lib.call("vf_xgmi_close", ctypes.c_void_p(ptr))
+        self._opened = []
+        self.flat = self._gviews = None
+        for p in self.params:
+            p.grad = None
+
+    # -- per iteration ------------------------------------------------------------------------------------------
+    def begin_step(self, opt):
+        """Before the forward pass: advance Adam's step count, put {lr, 1-b1^t, 1-b2^t} where the fused kernels read
+        them and make sure every peer has finished reading last iteration's gradients out of this rank's arena."""
+        self._check_status()
+        ext, hyper = opt.external_begin()
+        self._opt, self._ext, self._hyper = opt, ext, hyper
+        self.epoch += 1
+        if self.flat is not None:
+            self._prologue()
+
+    def _after_layout(self):
+        self._prologue()
+
+    def _prologue(self):
+        from . import _lib
+        lr, bc1, bc2 = self._hyper[:3]
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        _lib.call("vf_adam_set_scalars", ctypes.c_void_p(self._scal.data_ptr()), lr, bc1, bc2, st)
+        nseg = len(self.seg_range)
+        if self._signalled_before:
+            # peers' "done reading" flags of the last exchange: in practice long set (their reduce kernels ran before
+            # their own next forward pass)
+            _lib.call("vf_xgmi_wait", ctypes.c_void_p(self._flagmem.ptr), self.world, nseg, 2 * nseg,
+                      ctypes.c_uint(self._signalled_before), ctypes.c_void_p(self.status.data_ptr()), self.timeout_us, st)
+
+    _signalled_before = 0        # epoch of the last exchange this rank took part in
+
+    def _segment_tables(self):
+        opt = self._opt
+        if self._tables is not None and self._tables[0] == (opt.graph_epoch, id(opt)):
+            return self._tables[1]
+        dev = self.flat.device
+        tabs = []
+        for k in range(len(self.seg_range)):
+            rows, first = [], 0
+            for i in sorted((i for i in range(len(self.params)) if self.seg_of[i] == k), key=lambda i: self.off[i]):
+                p = self.params[i]
+                st = opt.state[p]
+                rows.append([p.data_ptr(), self.base + 4 * self.off[i], st["exp_avg"].data_ptr(),
+                             st["exp_avg_sq"].data_ptr(), p.numel(), first])
+                first += (p.numel() + 1023) // 1024
+            if k == len(self.seg_range) - 1:                          # the failure flag: averaged, no update
+                rows.append([0, self.base + 4 * self.flag_off, 0, 0, 1, first])
+                first += 1
+            tabs.append((torch.tensor(rows, dtype=torch.int64).to(dev), len(rows), first))
+        self._tables = ((opt.graph_epoch, id(opt)), tabs)
+        return tabs
+
+    def _launch(self, k):
+        from . import _lib, ops
+        ops.flush_colsums()
+        assert k == self.next_seg, (k, self.next_seg)
+        nseg = len(self.seg_range)
+        if k == nseg - 1:
+            self.flat[self.flag_off:self.flag_off + 1].fill_(self.flag_value)
+        tab, n, blocks = self._segment_tables()[k]
+        ev = self._events[k]
+        ev.record(torch.cuda.current_stream())          # the segment's producers (and the table upload) are enqueued
+        self.comm.wait_event(ev)
+        st = ctypes.c_void_p(self.comm.cuda_stream)
+        e = ctypes.c_uint(self.epoch & 0xFFFFFFFF)
+        _, _, _, b1, b2, eps = self._hyper
+        _lib.call("vf_xgmi_signal", self._flags, self.world, self.rank, k, e, st)
+        _lib.call("vf_xgmi_wait", ctypes.c_void_p(self._flagmem.ptr), self.world, k, k + 1, e,
+                  ctypes.c_void_p(self.status.data_ptr()), self.timeout_us, st)
+        _lib.call("vf_xgmi_reduce_adam", ctypes.c_void_p(tab.data_ptr()), n, blocks, self._bases,
+                  ctypes.c_void_p(self.base), ctypes.c_void_p(self.gavg.data_ptr()), self.world,
+                  ctypes.c_void_p(self._scal.data_ptr()), float(b1), float(b2), float(eps), st)
+        _lib.call("vf_xgmi_signal", self._flags, self.world, self.rank, nseg + k, e, st)
+        self.works.append(k)
+        self.launched[k] = True
+        self.next_seg = k + 1
+
+    def _join(self):
+        if self.works:
+            ev = self._events[-1]
+            ev.record(self.comm)
+            main = torch.cuda.current_stream()
+            main.wait_event(ev)
+            self.flag_acc.add_(self.gavg[self.flag_off:self.flag_off + 1])
+            for p, g in zip(self.params, self._gviews):               # the averaged gradients, as DDP leaves them
+                p.grad = g
+            torch.autograd.graph.increment_version(self.params)       # updated through raw pointers
+            self._signalled_before = self.epoch & 0xFFFFFFFF
+            if self._status_ev is None:                               # read by a later begin_step, without blocking
+                self._status_host.copy_(self.status, non_blocking=True)
+                self._status_ev = torch.cuda.Event()
+                self._status_ev.record(main)
+        self.works = []
+        self._reset()
+
+    def _check_status(self):
+        if self._status_ev is None or not self._status_ev.query():
+            return
+        self._status_ev = None
+        code = int(self._status_host.item())
+        if code:
+            from . import _lib
+            raise _lib.VFHipError(f"xgmi reducer: rank {self.rank} waited {self.timeout_us / 1e6:.0f} s for a peer's flag "
+                                  f"(slot {code - 1}) -- a rank died or left the iteration; the step that followed used "
+                                  "incomplete gradients")

@@ -138,9 +138,12 @@ class Trainer:
         self.module = model
         self.model = model
         self.arena = None
-        if world > 1 and os.environ.get("VF_REDUCER", "arena") != "ddp":
+        kind = os.environ.get("VF_REDUCER", "arena")
+        if world > 1 and kind != "ddp":
             try:
-                self.arena = reducer.ACTIVE = reducer.GradArena(model, world)
+                # "xgmi": the hand-written one-shot all-reduce over IPC-mapped peer arenas fused with Adam (correctness-
+                # only so far: it has run with two processes on one GPU, never across devices); default: RCCL
+                self.arena = reducer.ACTIVE = (reducer.XgmiArena if kind == "xgmi" else reducer.GradArena)(model, world)
             except (RuntimeError, dist.DistBackendError) as e:    # first collective of the job (parameter broadcast)
                 import traceback
                 traceback.print_exc()    # (anything else -- a programming error in the hook set-up -- propagates as is)
@@ -148,7 +151,8 @@ class Trainer:
                 raise SystemExit(
                     f"[view_fusion_amd] gradient-arena set-up failed at world={world}: {type(e).__name__}: {e}\n"
                     "  -> relaunch (a fresh process group, not a re-exec) with VF_REDUCER=ddp to use torch's "
-                    "DistributedDataParallel for the gradient exchange; see tools/scale_run.md") from e
+                    "DistributedDataParallel for the gradient exchange (VF_REDUCER=xgmi: first back to the default, "
+                    "the arena over RCCL); see tools/scale_run.md") from e
         elif world > 1:
             kw = dict(broadcast_buffers=False, gradient_as_bucket_view=True, bucket_cap_mb=bucket_cap_mb)
             if next(model.parameters()).is_cuda:
@@ -172,7 +176,8 @@ class Trainer:
         if graph is None:
             graph = os.environ.get("VF_STEP_GRAPH", "1") == "1"
         # (with torch DDP the iteration stays eager: its reducer is driven by autograd hooks on the host)
-        self.use_graph = bool(graph) and params[0].is_cuda and (world == 1 or self.arena is not None)
+        self.use_graph = bool(graph) and params[0].is_cuda and (world == 1 or self.arena is not None) and \
+            not getattr(self.arena, "owns_optimizer_step", False)     # (the xgmi reducer: eager launches only)
         self._graph_wanted = self.use_graph     # what the run was configured for (a local capture failure clears use_graph)
         self._graphs = {}           # geometry key -> _StepGraph
         self._pool = None           # the graphs' shared private memory pool
@@ -195,7 +200,7 @@ class Trainer:
 
     def dist_info(self):
         """What a multi-rank run looks like from this rank (bench.py prints it)."""
-        info = dict(world_size=self.world, reducer="none" if self.world == 1 else ("arena" if self.arena else "ddp"),
+        info = dict(world_size=self.world, reducer="none" if self.world == 1 else (("xgmi" if getattr(self.arena, "owns_optimizer_step", False) else "arena") if self.arena else "ddp"),
                     launch_mode=self.mode, graph_steps=self.graph_steps, mode_demotions=self.demotions)
         if dist.is_available() and dist.is_initialized():
             info.update(world_size=dist.get_world_size(), rank=dist.get_rank(), backend=dist.get_backend())
@@ -397,12 +402,16 @@ class Trainer:
                 e.seen += 1
         self._last_graph = None
         self.opt.zero_grad()
+        fused = self.arena is not None and getattr(self.arena, "owns_optimizer_step", False)
+        if fused:                         # the exchange kernels apply Adam themselves (reducer.XgmiArena)
+            self.arena.begin_step(self.opt)
         loss = self.model(y_0=batch["y_0"], y_cond=batch["y_cond"], view_count=batch["view_count"],
                           angle=batch["angle"], **extra)
         loss.backward()
         if self.arena is not None:
             self.arena.finish()
-        self.opt.step()
+        if not fused:
+            self.opt.step()
         # detached: a caller that keeps the returned loss should not keep this iteration's autograd graph (its saved
         # activations: several GB at B=16) alive with it
         return loss.detach()
