@@ -250,10 +250,10 @@ def roofline(trainer, batch, S, ms_step, steps=3):
     iterations after the timed region.  The headline `frac` is the EXECUTED fp32-MFMA fraction of the dominant
     kernel, wino_conv_kernel: its launches' algorithmic direct-convolution FLOPs / 3 (the nested Winograd F(2,3)xF(4,3)
     multiplies 24 values per 2x4 outputs x 9 taps = 72 direct ones) / its own event time / 157.3 TF."""
-    ops.KERNEL_LOG = []
+    ops.st.KERNEL_LOG = []
     trainer.step(batch)              # untimed: the first eager iteration after graph replays (re-made gradient tensors,
     torch.cuda.synchronize()         # descriptor uploads) runs its first kernels 1-5 % slower than the following ones
-    ops.KERNEL_LOG = []
+    ops.st.KERNEL_LOG = []
     # the instrumented iterations run EAGERLY (a kernel log forces it) with two events around every launcher: their
     # own GPU time, bracketed by one more event pair per iteration, is what the family table must sum to -- not the
     # graph-replay step time of the headline (different launch regime: eager launches carry gaps)
@@ -266,7 +266,7 @@ def roofline(trainer, batch, S, ms_step, steps=3):
         step_ev.append((e0, e1))
     torch.cuda.synchronize()
     eager_ms = sum(a.elapsed_time(b) for a, b in step_ev) / steps
-    log, ops.KERNEL_LOG = ops.KERNEL_LOG, None
+    log, ops.st.KERNEL_LOG = ops.st.KERNEL_LOG, None
     agg = {}
     for kind, flops, e0, e1, _tag, name, nbytes in log:
         fam = _family(kind, name)
@@ -459,7 +459,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             # VF_BF16X3=1 (experiment, default off): the 1x1 convolutions' forward / dgrad products run as bf16x3 split
             # products on the bf16 matrix path -- such a line is NOT the fp32-MFMA headline and says so here
-            "dtype": "f32" if not ops.BF16X3 else "f32 (1x1 conv fwd+dgrad: bf16x3 split products on the bf16 MFMA path)",
+            "dtype": "f32" if not ops.st.BF16X3 else "f32 (1x1 conv fwd+dgrad: bf16x3 split products on the bf16 MFMA path)",
             "data": "synthetic",
             "config": {"workload": "small UNet 64x64 (33.9M params), B=%d/GPU N=%d (S=%d views/GPU), training "
                                    "iteration fwd+bwd+Adam, linear T=2000 schedule%s" % (args.batch, args.views, S,

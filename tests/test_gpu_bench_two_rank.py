@@ -23,7 +23,7 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("reducer", ["arena", "ddp"])
+@pytest.mark.parametrize("reducer", ["arena", "ddp", "xgmi"])
 def test_bench_two_ranks_on_one_gpu(reducer):
     env = dict(os.environ, VF_DIST_BACKEND="gloo", VF_SHARE_GPU="1", VF_REDUCER=reducer, HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):

@@ -181,9 +181,9 @@ def test_conv_small_sampler_kernel(dev, Cin, Cout, Hin, KS, mode, S):
     ref = F.conv2d(inp, layer.weight.double(), layer.bias.double(), stride=2 if mode == "down2" else 1, padding=KS // 2)
     ref = ref + vb.double()[:, :, None, None] + res.double()
     layer = layer.to(dev)
-    ops.KERNEL_LOG = []
-    saved = ops.SMALL_CONV_MAX_WGS, ops.SMALL_CONV_MAX_CIN3, ops.SMALL_CONV_MAX_S3
-    ops.SMALL_CONV_MAX_WGS, ops.SMALL_CONV_MAX_CIN3, ops.SMALL_CONV_MAX_S3 = (1 << 30, 1 << 30), 1 << 30, 1 << 30
+    ops.st.KERNEL_LOG = []
+    saved = ops.st.SMALL_CONV_MAX_WGS, ops.st.SMALL_CONV_MAX_CIN3, ops.st.SMALL_CONV_MAX_S3
+    ops.st.SMALL_CONV_MAX_WGS, ops.st.SMALL_CONV_MAX_CIN3, ops.st.SMALL_CONV_MAX_S3 = (1 << 30, 1 << 30), 1 << 30, 1 << 30
     try:
         assert ops.use_small_conv(S, Cin, Cout, Hout, Hout, KS, ops._MODES[mode])
         with torch.no_grad():
@@ -191,12 +191,12 @@ def test_conv_small_sampler_kernel(dev, Cin, Cout, Hin, KS, mode, S):
             y0 = ops.conv2d(x.to(dev), layer, mode=mode)
         torch.cuda.synchronize()
         # (3x3: the general entry with the packed weight copy, made once per weight version; 1x1: the plain entry)
-        names = [e[5] for e in ops.KERNEL_LOG if e[5] != "vf_conv_small_pack"]
+        names = [e[5] for e in ops.st.KERNEL_LOG if e[5] != "vf_conv_small_pack"]
         assert names == (["vf_conv_small_gn"] * 2 if KS == 3 else ["vf_conv_small"] * 2), names
-        assert sum(e[5] == "vf_conv_small_pack" for e in ops.KERNEL_LOG) == (1 if KS == 3 else 0)
+        assert sum(e[5] == "vf_conv_small_pack" for e in ops.st.KERNEL_LOG) == (1 if KS == 3 else 0)
     finally:
-        ops.KERNEL_LOG = None
-        ops.SMALL_CONV_MAX_WGS, ops.SMALL_CONV_MAX_CIN3, ops.SMALL_CONV_MAX_S3 = saved
+        ops.st.KERNEL_LOG = None
+        ops.st.SMALL_CONV_MAX_WGS, ops.st.SMALL_CONV_MAX_CIN3, ops.st.SMALL_CONV_MAX_S3 = saved
     assert rel(y, ref) < 2e-6
     assert rel(y0, ref - vb.double()[:, :, None, None] - res.double()) < 2e-6
 
@@ -223,19 +223,19 @@ def test_conv_small_with_folded_residual_conv(dev, C, H, rC1, rC2, S):
     ref = (F.conv2d(a2.double(), conv.weight.double(), conv.bias.double(), padding=1) + vb.double()[:, :, None, None]
            + F.conv2d(xin.double(), resc.weight.double(), resc.bias.double()))
     conv, resc = conv.to(dev), resc.to(dev)
-    saved = ops.SMALL_CONV_MAX_WGS, ops.SMALL_CONV_MAX_CIN3, ops.SMALL_CONV_MAX_S3
-    ops.SMALL_CONV_MAX_WGS, ops.SMALL_CONV_MAX_CIN3, ops.SMALL_CONV_MAX_S3 = (1 << 30, 1 << 30), 1 << 30, 1 << 30
-    ops.KERNEL_LOG = []
+    saved = ops.st.SMALL_CONV_MAX_WGS, ops.st.SMALL_CONV_MAX_CIN3, ops.st.SMALL_CONV_MAX_S3
+    ops.st.SMALL_CONV_MAX_WGS, ops.st.SMALL_CONV_MAX_CIN3, ops.st.SMALL_CONV_MAX_S3 = (1 << 30, 1 << 30), 1 << 30, 1 << 30
+    ops.st.KERNEL_LOG = []
     try:
         with torch.no_grad():
             fold = (resc, x1.to(dev), None if x2 is None else x2.to(dev))
             y = ops.conv2d(a2.to(dev), conv, view_bias=vb.to(dev), res_fold=fold)
             y_nb = ops.conv2d(a2.to(dev), conv, res_fold=fold)
         torch.cuda.synchronize()
-        assert [e[5] for e in ops.KERNEL_LOG if e[5] != "vf_conv_small_pack"] == ["vf_conv_small_gn"] * 2   # (general entry: packed weights + fold)
+        assert [e[5] for e in ops.st.KERNEL_LOG if e[5] != "vf_conv_small_pack"] == ["vf_conv_small_gn"] * 2   # (general entry: packed weights + fold)
     finally:
-        ops.KERNEL_LOG = None
-        ops.SMALL_CONV_MAX_WGS, ops.SMALL_CONV_MAX_CIN3, ops.SMALL_CONV_MAX_S3 = saved
+        ops.st.KERNEL_LOG = None
+        ops.st.SMALL_CONV_MAX_WGS, ops.st.SMALL_CONV_MAX_CIN3, ops.st.SMALL_CONV_MAX_S3 = saved
     assert rel(y, ref) < 2e-6
     assert rel(y_nb, ref - vb.double()[:, :, None, None]) < 2e-6
 
@@ -244,11 +244,14 @@ def test_conv_small_with_folded_residual_conv(dev, C, H, rC1, rC2, S):
 @pytest.mark.parametrize("C0,C1,C2,H,KS2", [(64, 64, 64, 64, 3), (128, 128, 64, 32, 3), (192, 192, 576, 16, 1),
                                             (64, 192, 192, 16, 3), (96, 320, 100, 8, 1), (32, 32, 40, 4, 3)])
 def test_conv_small_groupnorm_without_a_launch(dev, C0, C1, C2, H, KS2, S):
-    """Round 5: conv -> GroupNorm(32)+Swish -> conv with NO GroupNorm launch (vf_conv_small_gn): the first conv's
-    epilogue accumulates per-(view, channel) integer sums of its output, the second conv normalises while staging --
-    against fp64 of the reference's Block chain (unet.py:207-218); the sums themselves against fp64 to 2^-24-unit
-    fixed-point accuracy; bit-reproducible across launches (integer atomics)."""
-    from view_fusion_amd import ops
+    """conv -> GroupNorm(32)+Swish -> conv with NO GroupNorm launch (the optional statistics operands of
+    vf_conv_small_gn): the first conv's epilogue accumulates per-(view, channel) integer sums of its output, the second
+    conv normalises while staging -- against fp64 of the reference's Block chain (unet.py:207-218); the sums themselves
+    against fp64 to 2^-24-unit fixed-point accuracy; bit-reproducible across launches (integer atomics).  The sampler
+    does not take this route (round 5 measured it 4 % slower than a GroupNorm launch, profiles/r05_sampler.md; round 6
+    removed the host path): the test drives the C ABI directly."""
+    import ctypes
+    from view_fusion_amd import _lib, ops
     conv1, conv2 = torch.nn.Conv2d(C0, C1, 3, padding=1), torch.nn.Conv2d(C1, C2, KS2, padding=KS2 // 2)
     gn = torch.nn.GroupNorm(32, C1)
     with torch.no_grad():
@@ -266,24 +269,34 @@ def test_conv_small_groupnorm_without_a_launch(dev, C0, C1, C2, H, KS2, S):
         n_ref = n_ref * torch.sigmoid(n_ref)
     y_ref = F.conv2d(n_ref, conv2.weight.double(), conv2.bias.double(), padding=KS2 // 2)
     conv1, conv2, gn = conv1.to(dev), conv2.to(dev), gn.to(dev)
-    saved = ops.SMALL_CONV_MAX_WGS, ops.SMALL_CONV_MAX_CIN3, ops.SMALL_CONV_MAX_S3
-    ops.SMALL_CONV_MAX_WGS, ops.SMALL_CONV_MAX_CIN3, ops.SMALL_CONV_MAX_S3 = (1 << 30, 1 << 30), 1 << 30, 1 << 30
-    ops.STATS = ops.StatsArena(dev, S)
-    ops.KERNEL_LOG = []
-    lazy_default, ops.GN_LAZY = ops.GN_LAZY, True        # (gated experiment, off by default: profiles/r05_sampler.md)
-    try:
-        with torch.no_grad():
-            assert ops.can_apply_gn_on_load(S, conv1, H, H) and ops.can_apply_gn_on_load(S, conv2, H, H)
-            outs = []
-            for _ in range(2):
-                h, st = ops.conv2d(x.to(dev), conv1, view_bias=vb.to(dev), want_stats=True)
-                y = ops.conv2d(ops.LazyGN(h, st, gn, 32, silu), conv2)
-                outs.append((h.clone(), st.clone(), y.clone()))
-        torch.cuda.synchronize()
-        assert [e[5] for e in ops.KERNEL_LOG if e[5] != "vf_conv_small_pack"] == ["vf_conv_small_gn"] * 4
-    finally:
-        ops.KERNEL_LOG, ops.STATS, ops.GN_LAZY = None, None, lazy_default
-        ops.SMALL_CONV_MAX_WGS, ops.SMALL_CONV_MAX_CIN3, ops.SMALL_CONV_MAX_S3 = saved
+    xd, vbd = x.to(dev), vb.to(dev)
+    P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    st_raw = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def packed(conv):
+        if conv.weight.shape[2] != 3 or conv.weight.shape[1] % 32:
+            return None
+        wp = torch.empty(_lib.load().vf_conv_small_pack_floats(conv.weight.shape[0], conv.weight.shape[1]), device=dev)
+        _lib.call("vf_conv_small_pack", P(conv.weight.detach()), P(wp), conv.weight.shape[0], conv.weight.shape[1], st_raw)
+        return wp
+
+    def launch(xin, conv, view_bias, in_stats, out_stats):
+        Cout, Cin, KS, _ = conv.weight.shape
+        y = torch.empty(S, Cout, H, H, device=dev)
+        wp = packed(conv)
+        _lib.call("vf_conv_small_gn", P(xin), None, 0, P(conv.weight.detach()), P(conv.bias.detach()), P(view_bias), None, P(y), S,
+                  Cin, Cout, H, H, KS, P(in_stats), P(gn.weight.detach()) if in_stats is not None else None,
+                  P(gn.bias.detach()) if in_stats is not None else None, 32 if in_stats is not None else 0, 1e-5, int(silu),
+                  P(out_stats), None, None, 0, 0, None, None, P(wp), 0, st_raw)
+        return y
+
+    outs = []
+    for _ in range(2):
+        st = torch.zeros(S * C1 * 2, dtype=torch.int64, device=dev)
+        h = launch(xd, conv1, vbd, None, st)
+        y = launch(h, conv2, None, st, None)
+        outs.append((h.clone(), st.clone(), y.clone()))
+    torch.cuda.synchronize()
     (h, st, y), (h2, st2, y2) = outs
     assert torch.equal(st, st2) and torch.equal(y, y2)                # order-independent sums: bit-reproducible
     assert rel(h, h_ref) < 2e-6
@@ -321,15 +334,15 @@ def test_winograd_fixup_evaluates_the_groupnorm(dev, Cin, Cout, H, mode, S):
     with torch.no_grad():
         if not (ops.wino_kind(S, Cin, Cout, H, H, 3, m, False) == 1 and lib.vf_wino_conv_gn_fusable(S, Cin, Cout, H, H, m, 32)):
             pytest.skip("this shape does not take the fused fix-up at this S under the natural policy")
-        ops.KERNEL_LOG = []
+        ops.st.KERNEL_LOG = []
         try:
             y, a = ops.conv2d_gn(x.to(dev), layer, gn, 32, True, view_bias=vb.to(dev), residual=res.to(dev), mode=mode,
                                  want_y=True)
             y2, a2 = ops.conv2d_gn(x.to(dev), layer, gn, 32, True, view_bias=vb.to(dev), residual=res.to(dev), mode=mode)
             torch.cuda.synchronize()
-            assert [e[5] for e in ops.KERNEL_LOG if e[5] != "vf_wino_pack_weights"] == ["vf_wino_conv_fwd_gn"] * 2
+            assert [e[5] for e in ops.st.KERNEL_LOG if e[5] != "vf_wino_pack_weights"] == ["vf_wino_conv_fwd_gn"] * 2
         finally:
-            ops.KERNEL_LOG = None
+            ops.st.KERNEL_LOG = None
     assert y2 is None and torch.equal(a, a2)
     assert rel(y, y_ref) < 2e-5 and rel(a, a_ref) < 2e-5, (rel(y, y_ref), rel(a, a_ref))
 
@@ -375,11 +388,11 @@ def test_conv_winograd_path(dev, Cin, Cout, Hin, mode):
     """Fused Winograd F(2x2,3x3) forward, dgrad and (plain stride-1 layers with >= 32 channels) wgrad,
     forced on, vs CPU conv2d."""
     from view_fusion_amd import ops
-    ops.FORCE_WINOGRAD = True
+    ops.st.FORCE_WINOGRAD = True
     try:
         test_conv_fwd_bwd(dev, Cin, Cout, Hin, 3, mode, 3)
     finally:
-        ops.FORCE_WINOGRAD = False
+        ops.st.FORCE_WINOGRAD = False
 
 
 @pytest.mark.parametrize("Cin,Cout,Hin,mode,S", [
@@ -395,11 +408,11 @@ def test_conv_winograd44_path(dev, Cin, Cout, Hin, mode, S):
     (32x32 / 64x64 outputs), vs CPU conv2d.  rel = max|a - b| / max|b| < 3e-5 (the 4-point transform on both axes:
     measured 4-9e-6; the nested kernel is held to 2e-5)."""
     from view_fusion_amd import ops
-    ops.FORCE_WINOGRAD44 = True
+    ops.st.FORCE_WINOGRAD44 = True
     try:
         test_conv_fwd_bwd(dev, Cin, Cout, Hin, 3, mode, S, tol=3e-5)
     finally:
-        ops.FORCE_WINOGRAD44 = False
+        ops.st.FORCE_WINOGRAD44 = False
 
 
 @pytest.mark.parametrize("Cin,Cout,Hin,mode,S", [(320, 320, 8, "same", 6), (192, 320, 8, "same", 9), (64, 96, 4, "up2", 5),
@@ -407,11 +420,11 @@ def test_conv_winograd44_path(dev, Cin, Cout, Hin, mode, S):
 def test_conv_winograd_small_maps(dev, Cin, Cout, Hin, mode, S):
     """8x8 maps pack four views into one 64-tile workgroup (ragged last group); all tiles K-split."""
     from view_fusion_amd import ops
-    ops.FORCE_WINOGRAD = True
+    ops.st.FORCE_WINOGRAD = True
     try:
         test_conv_fwd_bwd(dev, Cin, Cout, Hin, 3, mode, S)
     finally:
-        ops.FORCE_WINOGRAD = False
+        ops.st.FORCE_WINOGRAD = False
 
 
 @pytest.mark.parametrize("C,H", [(64, 64), (128, 32), (192, 16), (320, 16), (96, 32), (320, 8), (640, 8), (96, 8)])
@@ -424,12 +437,12 @@ def test_group_norm_backward_rowsum(dev, C, H):
     gamma, beta = (1 + 0.1 * rnd(C, seed=3)).to(dev), (0.1 * rnd(C, seed=4)).to(dev)
     xg = x.to(dev).requires_grad_(True)
     y = ops.group_norm(xg, gamma, beta, 32, silu=True)
-    seen, real_put = [], ops._rowsum_put
-    ops._rowsum_put = lambda t, rs, cs: (seen.append((t, rs)), real_put(t, rs, cs))[1]
+    seen, real_put = [], ops.norm._rowsum_put
+    ops.norm._rowsum_put = lambda t, rs, cs: (seen.append((t, rs)), real_put(t, rs, cs))[1]
     try:
         y.backward(gy.to(dev))
     finally:
-        ops._rowsum_put = real_put
+        ops.norm._rowsum_put = real_put
     (t, rowsum), = seen                           # the dx tensor the kernel wrote, and its closed-form sums
     assert torch.equal(t, xg.grad) and t._vf_sums[0] == t._version and t._vf_sums[1] is rowsum
     ref = t.double().sum((2, 3))
@@ -444,7 +457,7 @@ def test_group_norm_backward_rowsum(dev, C, H):
     _lib.call = lambda name, *a: (names.append(name), real_call(name, *a))[1]
     try:
         for fusion in (True, False):
-            ops.ROWSUM_FUSION = fusion
+            ops.st.ROWSUM_FUSION = fusion
             layer.zero_grad(); vb.grad = None
             del names[:]
             h = ops.conv2d(x.to(dev), layer, view_bias=vb)
@@ -454,7 +467,7 @@ def test_group_norm_backward_rowsum(dev, C, H):
             assert (("vf_rowsum" in names) or ("vf_bias_grad" in names)) == (not fusion), names
     finally:
         _lib.call = real_call
-        ops.ROWSUM_FUSION = True
+        ops.st.ROWSUM_FUSION = True
     for a, b in zip(*grads):
         assert (a - b).abs().max().item() < 1e-5 * max(1.0, b.abs().max().item()) + 2e-6 * scale
 

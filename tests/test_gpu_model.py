@@ -125,11 +125,11 @@ def test_small_train_step_vs_oracle(dev, winograd):
     eligible layers, as the S=96 training step uses them."""
     from oracle import unet_ref, view_fusion_ref as vfr
     from view_fusion_amd import ops
-    ops.FORCE_WINOGRAD = winograd
+    ops.st.FORCE_WINOGRAD = winograd
     try:
         _small_train_step(dev)
     finally:
-        ops.FORCE_WINOGRAD = False
+        ops.st.FORCE_WINOGRAD = False
 
 
 def test_small_train_step_natural_policy(dev):
@@ -157,13 +157,13 @@ def test_weight_gradient_slab_sums_are_deferred_into_one_launch(dev):
         if zero:
             for p in params:
                 p.grad = None
-        ops.WRED_DEFER, ops.KERNEL_LOG = defer, []
+        ops.st.WRED_DEFER, ops.st.KERNEL_LOG = defer, []
         try:
             vf(**kw).backward()
             torch.cuda.synchronize()
-            return [e[5] for e in ops.KERNEL_LOG], [p.grad.detach().clone() for p in params]
+            return [e[5] for e in ops.st.KERNEL_LOG], [p.grad.detach().clone() for p in params]
         finally:
-            ops.WRED_DEFER, ops.KERNEL_LOG = True, None
+            ops.st.WRED_DEFER, ops.st.KERNEL_LOG = True, None
 
     names, g_def = run(True)
     n_main = names.count("vf_wino_wgrad_main")
@@ -193,12 +193,12 @@ def test_deferred_slab_sums_share_one_arena_across_passes_and_graphs(dev):
                     angle=(torch.rand(B, 1, generator=g) * 6).to(dev), view_count=torch.full((B,), N))
 
     seen_entries = []
-    orig = ops._flush_wred
+    orig = ops.deferred._flush_wred
 
     def spy():
-        seen_entries.extend(ops._PENDING_WRED)
+        seen_entries.extend(ops.st._PENDING_WRED)
         orig()
-    ops._flush_wred = spy
+    ops.deferred._flush_wred = spy
     try:
         b3 = batch(3)
         for _ in range(train.Trainer.GRAPH_AFTER + 2):      # eager sightings, capture, one replay
@@ -219,7 +219,7 @@ def test_deferred_slab_sums_share_one_arena_across_passes_and_graphs(dev):
         # workspaces would add ~0.25 GB per graph at these sizes on top
         assert grown < 2.0e9, grown
     finally:
-        ops._flush_wred = orig
+        ops.deferred._flush_wred = orig
     assert len(seen_entries) >= 20
     for row, nblk, keep in seen_entries:
         assert len(keep) == 4 and keep[0]._base is not None and keep[0].dim() == 1      # (ws = a slice of the arena, dw, db, db2)
@@ -531,15 +531,15 @@ def test_small_unet_sampler_vs_oracle(dev, N, use_graph):
 
 
 def _kernel_names(fn):
-    """C-ABI entry points a call goes through (ops.KERNEL_LOG), in launch order."""
+    """C-ABI entry points a call goes through (ops.st.KERNEL_LOG), in launch order."""
     from view_fusion_amd import ops
-    ops.KERNEL_LOG = []
+    ops.st.KERNEL_LOG = []
     try:
         fn()
         torch.cuda.synchronize()
-        return [e[5] for e in ops.KERNEL_LOG]
+        return [e[5] for e in ops.st.KERNEL_LOG]
     finally:
-        ops.KERNEL_LOG = None
+        ops.st.KERNEL_LOG = None
 
 
 def test_small_unet_sampler_b16_vs_oracle(dev):

@@ -272,13 +272,13 @@ def test_winograd_kernel_choice_is_host_logic():
     import torch
     with torch.no_grad():                                   # default `train` = whether autograd records
         assert ops.wino_kind(96, 64, 64, 64, 64, 3, 0) == ops.wino_kind(96, 64, 64, 64, 64, 3, 0, False)
-    ops.FORCE_WINOGRAD = True
+    ops.st.FORCE_WINOGRAD = True
     try:
         assert k(2, 64, 64, 64) == 1 and k(96, 64, 64, 64) == 1
-        ops.FORCE_WINOGRAD44 = True
+        ops.st.FORCE_WINOGRAD44 = True
         assert k(2, 64, 64, 64) == 2 and k(2, 192, 192, 16) == 1          # (no F(4x4) kernel for 16x16 maps)
     finally:
-        ops.FORCE_WINOGRAD = ops.FORCE_WINOGRAD44 = False
+        ops.st.FORCE_WINOGRAD = ops.st.FORCE_WINOGRAD44 = False
     assert ops.use_winograd(96, 64, 64, 64, 64, 3, 0, True) and not ops.use_winograd(1, 64, 64, 64, 64, 3, 0, False)
 
 

@@ -17,12 +17,12 @@ B = int(_s.argv[1]) if len(_s.argv) > 1 else 16
 batch = train.synthetic_batch(B, 6, 64, dev)
 for _ in range(2):
     tr.step(batch)
-ops.KERNEL_LOG = []
+ops.st.KERNEL_LOG = []
 steps = 2
 for _ in range(steps):
     tr.step(batch)
 torch.cuda.synchronize()
-log, ops.KERNEL_LOG = ops.KERNEL_LOG, None
+log, ops.st.KERNEL_LOG = ops.st.KERNEL_LOG, None
 agg = {}
 for kind, flops, e0, e1, tag, name, _nb in log:
     if tag is None:

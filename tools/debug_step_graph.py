@@ -29,7 +29,7 @@ tr.opt.zero_grad()
 adam = tr.opt.graph_begin()
 scal = torch.zeros(3, device=dev)
 g = torch.cuda.CUDAGraph()
-ops.COLSUM_DEFER = os.environ.get("DEFER", "1") == "1"
+ops.st.COLSUM_DEFER = os.environ.get("DEFER", "1") == "1"
 ops.begin_capture(torch.device(dev), 128)
 with torch.cuda.graph(g, capture_error_mode="relaxed"):
     if stage == "fwd":

@@ -22,11 +22,11 @@ for (H, C) in ((16, 192), (8, 320)):
             out.backward(gy, retain_graph=True)
         for _ in range(3):
             bwd()
-        ops.KERNEL_LOG = []
+        ops.st.KERNEL_LOG = []
         bwd()
         torch.cuda.synchronize()
-        names = [e[5] for e in ops.KERNEL_LOG]
-        ops.KERNEL_LOG = None
+        names = [e[5] for e in ops.st.KERNEL_LOG]
+        ops.st.KERNEL_LOG = None
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         n = 30
         e0.record()

@@ -21,15 +21,15 @@ Ho = H // 2 if mode == "down2" else (H * 2 if mode == "up2" else H)
 gy = torch.rand(S, Cout, Ho, Ho, device=dev)
 res = torch.rand(S, Cout, Ho, Ho, device=dev)
 fl = 2.0 * S * Cout * Cin * KS * KS * Ho * Ho
-ops.KERNEL_LOG = []
+ops.st.KERNEL_LOG = []
 for it in range(reps + 2):
     if it == 2:
-        ops.KERNEL_LOG.clear()
+        ops.st.KERNEL_LOG.clear()
     y = ops.conv2d(x, layer, residual=res, mode=mode)
     y.backward(gy)
 torch.cuda.synchronize()
 agg = {}
-for kind, flops, e0, e1, tag, _name in ops.KERNEL_LOG:
+for kind, flops, e0, e1, tag, _name in ops.st.KERNEL_LOG:
     a = agg.setdefault(kind, [0.0, 0]); a[0] += e0.elapsed_time(e1) * 1e-3; a[1] += 1
 print(" ".join(f"{k}: {v[0] / v[1] * 1e6:.1f}us {fl / (v[0] / v[1]) / 1e12:.1f}TF" for k, v in agg.items()),
       f"| Cin={Cin} Cout={Cout} H={H} KS={KS} {mode} ablate={os.environ.get('VF_CONV_ABLATE', '0')}")

@@ -11,7 +11,7 @@ deterministic_fill_(net.state_dict())
 net = net.to(dev).eval()
 for label, f24, f44 in (("natural policy", False, False), ("every eligible layer on the nested F(2,3)xF(4,3) kernel", True, False),
                         ("64x64 / 32x32 layers on the F(4x4,3x3) kernel, nested below", True, True)):
-    ops.FORCE_WINOGRAD, ops.FORCE_WINOGRAD44 = f24, f44
+    ops.st.FORCE_WINOGRAD, ops.st.FORCE_WINOGRAD44 = f24, f44
     with torch.no_grad():
         y = net(torch.from_numpy(g['x']).to(dev), torch.from_numpy(g['angle']).to(dev), torch.from_numpy(g['level']).to(dev))
     ref = g['y'] if 'y' in g else g['out']

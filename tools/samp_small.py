@@ -7,7 +7,7 @@ model = train.build_model(device="cuda:0", phase="test")
 for B, N in ((1, 1), (1, 2), (1, 6)):
     row = []
     for small, cin3, s3 in ((False, 0, 0), (True, 256, 1), (True, 320, 1), (True, 384, 1), (True, 320, 2), (True, 1 << 30, 1)):
-        ops.SMALL_CONV, ops.SMALL_CONV_MAX_CIN3, ops.SMALL_CONV_MAX_S3 = small, cin3, s3
+        ops.st.SMALL_CONV, ops.st.SMALL_CONV_MAX_CIN3, ops.st.SMALL_CONV_MAX_S3 = small, cin3, s3
         r = sampling_bench.time_sampler(B, N, steps=200, use_graph=True, model=model)
         row.append(f"{'off' if not small else (cin3, s3)}: {r['ms_per_step']:.3f}")
     print(f"B={B} N={N}  " + "  ".join(row), flush=True)

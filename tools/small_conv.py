@@ -16,7 +16,7 @@ shapes = [(64, 64, 64, 3), (128, 128, 32, 3), (192, 192, 16, 3), (384, 192, 16, 
 row = []
 with torch.no_grad():
   for small in (False, True):
-    ops.SMALL_CONV, ops.SMALL_CONV_MAX_WGS, ops.SMALL_CONV_MAX_CIN3, ops.SMALL_CONV_MAX_S3 = small, (1 << 30, 1 << 30), 1 << 30, 1 << 30
+    ops.st.SMALL_CONV, ops.st.SMALL_CONV_MAX_WGS, ops.st.SMALL_CONV_MAX_CIN3, ops.st.SMALL_CONV_MAX_S3 = small, (1 << 30, 1 << 30), 1 << 30, 1 << 30
     row.append("| small" if small else "| split-K")
     for Cin, Cout, H, KS in shapes:
           layer = torch.nn.Conv2d(Cin, Cout, KS, padding=KS // 2).to(dev)

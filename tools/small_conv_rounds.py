@@ -16,7 +16,7 @@ def t_us(fn, n=100):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); g.replay(); e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
-ops.SMALL_CONV_MAX_WGS, ops.SMALL_CONV_MAX_CIN3, ops.SMALL_CONV_MAX_S3 = (1 << 30, 1 << 30), 1 << 30, 1 << 30
+ops.st.SMALL_CONV_MAX_WGS, ops.st.SMALL_CONV_MAX_CIN3, ops.st.SMALL_CONV_MAX_S3 = (1 << 30, 1 << 30), 1 << 30, 1 << 30
 with torch.no_grad():
     for H, Cout in ((32, 128), (16, 192), (64, 64)):
         for Cin in (32, 64, 128, 256, 512):

@@ -249,7 +249,7 @@ class Trainer:
     # -- whole-step HIP graph ---------------------------------------------------------------------------------------
     def _graph_key(self, batch, extra):
         from . import ops
-        if not self.use_graph or ops.KERNEL_LOG is not None or (self.arena is not None and self.arena.flat is None):
+        if not self.use_graph or ops.st.KERNEL_LOG is not None or (self.arena is not None and self.arena.flat is None):
             return None
         if any(k not in ("t", "u", "noise") for k in extra):       # injected draws are graph inputs, nothing else is
             return None

@@ -54,13 +54,10 @@ class _ResBlock(nn.Module):
 
     def _forward_inference(self, x, e, skip, a_in, next_gn):
         """No-grad path (the sampler): the same arithmetic with as few launches as the sizes allow.
-        a_in: GroupNorm1(x) if the producer of x already dealt with it -- a tensor (evaluated by the producer's split-K
-        reduce launch, ops.conv2d_gn) or an ops.LazyGN (the producer left channel sums; this block's first conv
-        normalises on load).  next_gn = (GroupNorm holder, silu, consumer conv) of the consumer of this block's output,
-        or None.  -> (y, next_a | None), next_a again a tensor or a LazyGN.
-        Between two one-launch convs (ops.can_apply_gn_on_load) a GroupNorm costs no launch at all (round 5): the
-        producing conv accumulates integer channel sums in its epilogue, the consuming conv applies mean / rstd / affine /
-        Swish while it stages its input; the residual 1x1 conv rides in the block's last conv as extra K."""
+        a_in: GroupNorm1(x) if the producer of x already evaluated it (in its split-K reduce / Winograd fix-up launch,
+        ops.conv2d_gn), else None.  next_gn = (GroupNorm holder, silu) of the consumer of this block's output, or None.
+        -> (y, GroupNorm_next(y) | None).  The residual 1x1 conv rides in the block's last conv as extra K where that
+        conv runs the one-launch kernel (ops.can_fold_residual)."""
         from . import ops
         b1, b2 = self.block1["block"], self.block2["block"]
         conv1, conv2 = b1["3"], b2["3"]
@@ -70,43 +67,21 @@ class _ResBlock(nn.Module):
             C1, C = x.shape[1], x.shape[1] + skip.shape[1]
             if not (isinstance(self.res_conv, nn.Conv2d) and ops.cat_fusable(C1, C, x.shape[2] * x.shape[3], self.groups)):
                 x, skip = ops.concat_channels(x, skip), None
-        # The residual 1x1 conv is needed by the block's LAST conv only.  Where that conv runs the one-launch kernel it
-        # takes the 1x1 conv along as extra K (one graph node less); elsewhere the 1x1 conv is a launch of its own --
-        # optionally a side branch of the captured step (ops.side_branch: measured slower, off by default).
         fold = (self.res_conv, x, skip) if ops.can_fold_residual(S, Cout, H, W, self.res_conv) else None
-        br, res = None, None
+        res = None
         if skip is not None:
             if fold is None:
-                with ops.side_branch() as br:
-                    res = ops.conv1x1_cat(x, skip, self.res_conv)
+                res = ops.conv1x1_cat(x, skip, self.res_conv)
             a, _, _ = ops.group_norm_cat_skip(x, skip, b1["0"].weight, b1["0"].bias, self.groups, silu=True)
         else:
             if isinstance(self.res_conv, nn.Identity):
                 res = x
             elif fold is None:
-                with ops.side_branch() as br:
-                    res = ops.conv2d(x, self.res_conv)
-            if isinstance(a_in, ops.LazyGN) and not ops.can_apply_gn_on_load(S, conv1, H, W):
-                a_in = a_in.materialize()
+                res = ops.conv2d(x, self.res_conv)
             a = a_in if a_in is not None else ops.group_norm(x, b1["0"].weight, b1["0"].bias, self.groups, silu=True)
-        # conv1 -> GroupNorm2 -> conv2: no launch for the norm when both convs are one-launch convs
-        if ops.can_apply_gn_on_load(S, conv1, H, W) and ops.can_apply_gn_on_load(S, conv2, H, W):
-            h, hst = ops.conv2d(a, conv1, view_bias=e, want_stats=True)
-            a2 = ops.LazyGN(h, hst, b2["0"], self.groups, True) if hst is not None else \
-                ops.group_norm(h, b2["0"].weight, b2["0"].bias, self.groups, True)
-        else:
-            if isinstance(a, ops.LazyGN):
-                a = a.materialize()
-            _, a2 = ops.conv2d_gn(a, conv1, b2["0"], self.groups, True, view_bias=e)
-        if br is not None:
-            br.join(res)
+        _, a2 = ops.conv2d_gn(a, conv1, b2["0"], self.groups, True, view_bias=e)
         if next_gn is None:
             return ops.conv2d(a2, conv2, residual=res, res_fold=fold), None
-        if ops.can_apply_gn_on_load(S, conv2, H, W) and ops.can_apply_gn_on_load(S, next_gn[2], H, W):
-            y, yst = ops.conv2d(a2, conv2, residual=res, res_fold=fold, want_stats=True)
-            if yst is not None:
-                return y, ops.LazyGN(y, yst, next_gn[0], self.groups, next_gn[1])
-            return y, ops.group_norm(y, next_gn[0].weight, next_gn[0].bias, self.groups, next_gn[1])
         return ops.conv2d_gn(a2, conv2, next_gn[0], self.groups, next_gn[1], residual=res, want_y=True, res_fold=fold)
 
     def forward(self, x, e, skip=None, tap=False, draws=None):
@@ -146,26 +121,16 @@ class _SelfAttention(nn.Module):
         self.out = nn.Conv2d(ch, ch, 1)
         self.groups = groups
 
-    def forward(self, x, n=None, next_gn=None):
-        """n: GroupNorm(x) when the producer of x has already dealt with it (inference: a tensor or an ops.LazyGN).
-        next_gn (inference): (GroupNorm holder, silu, consumer conv) of the consumer of the output -> returns
-        (y, LazyGN | None) instead of y."""
+    def forward(self, x, n=None):
+        """n: GroupNorm(x) when the producer of x has already evaluated it (inference)."""
         from . import ops
         if n is None:
             n, xs = ops.group_norm_skip(x, self.norm.weight, self.norm.bias, self.groups, silu=False)
         else:
             xs = x
-        S, _, H, W = x.shape
-        if isinstance(n, ops.LazyGN) and not ops.can_apply_gn_on_load(S, self.qkv, H, W):
-            n = n.materialize()
         qkv = ops.conv2d(n, self.qkv)                                               # (S,3C,H,W)
         o = ops.attention(qkv)                                                      # (S,C,H,W)
-        if next_gn is None:
-            return ops.conv2d(o, self.out, residual=xs)
-        if ops.can_apply_gn_on_load(S, self.out, H, W) and ops.can_apply_gn_on_load(S, next_gn[2], H, W):
-            y, yst = ops.conv2d(o, self.out, residual=xs, want_stats=True)
-            return y, (ops.LazyGN(y, yst, next_gn[0], self.groups, next_gn[1]) if yst is not None else None)
-        return ops.conv2d(o, self.out, residual=xs), None
+        return ops.conv2d(o, self.out, residual=xs)
 
 
 class _ResAttnBlock(nn.Module):
@@ -179,10 +144,8 @@ class _ResAttnBlock(nn.Module):
     def forward_inference(self, x, e, skip=None, a_in=None, next_gn=None):
         """No-grad path: -> (y, GroupNorm_next(y) | None); see _ResBlock._forward_inference."""
         if self.with_attn:
-            y, n = self.res_block._forward_inference(x, e, skip, a_in, (self.attn.norm, False, self.attn.qkv))
-            if next_gn is None:
-                return self.attn(y, n), None
-            return self.attn(y, n, next_gn)
+            y, n = self.res_block._forward_inference(x, e, skip, a_in, (self.attn.norm, False))
+            return self.attn(y, n), None
         return self.res_block._forward_inference(x, e, skip, a_in, next_gn)
 
     def forward(self, x, e, skip=None, tap=False, draws=None):
@@ -302,55 +265,40 @@ class UNet(nn.Module):
     def _has_dropout(self):
         return any(isinstance(m, _ResBlock) and m.dropout > 0 for m in self.modules())
 
-    def _forward_inference(self, x, es, embed_branch=None):
+    def _forward_inference(self, x, es):
         """The no-grad forward (sampler): same dataflow as below without the autograd handles; a residual block whose
         output goes straight into another residual block's first GroupNorm (or into the final one) lets its last conv
-        evaluate that GroupNorm too.  embed_branch = (ops.side_branch, its tensors): the time-embedding launches, to be
-        joined in front of the first residual block."""
+        evaluate that GroupNorm too."""
         from . import ops
 
         def gn1_of(layer):            # first GroupNorm of a residual block that consumes its input un-concatenated
             if not isinstance(layer, _ResAttnBlock):
                 return None
-            b1 = layer.res_block.block1["block"]
-            return (b1["0"], True, b1["3"])
+            return (layer.res_block.block1["block"]["0"], True)
 
-        def tensor_of(a):             # a GroupNorm result somebody has to read as a tensor
-            return a.materialize() if isinstance(a, ops.LazyGN) else a
-
-        ops.STATS = ops.StatsArena(x.device, x.shape[0]) if ops.GN_LAZY and x.is_cuda else None
-        try:
-            feats, a_next = [], None
-            downs = list(self.downs)
-            for i, layer in enumerate(downs):
-                if isinstance(layer, _ResAttnBlock):
-                    if embed_branch is not None:      # the time-embedding chain ran beside the stem conv: join it here
-                        embed_branch[0].join(*embed_branch[1])
-                        embed_branch = None
-                    nxt = downs[i + 1] if i + 1 < len(downs) else self.mid[0]
-                    x, a_next = layer.forward_inference(x, next(es), a_in=a_next, next_gn=gn1_of(nxt))
-                elif isinstance(layer, _Resample):
-                    x, a_next = layer(x), None
-                else:
-                    x, a_next = ops.conv2d(x, layer), None
-                feats.append(x)
-            x, a_next = self.mid[0].forward_inference(x, next(es), a_in=a_next, next_gn=gn1_of(self.mid[1]))
-            x, a_next = self.mid[1].forward_inference(x, next(es), a_in=a_next, next_gn=None)
-            ups = list(self.ups)
-            fc = self.final_conv["block"]
-            for i, layer in enumerate(ups):
-                if isinstance(layer, _ResAttnBlock):
-                    last = i + 1 == len(ups)
-                    x, a_next = layer.forward_inference(x, next(es), skip=feats.pop(),
-                                                        next_gn=(fc["0"], True, fc["3"]) if last else None)
-                else:
-                    x, a_next = layer(x), None
-            a = a_next if a_next is not None else ops.group_norm(x, fc["0"].weight, fc["0"].bias, self.norm_groups, silu=True)
-            if isinstance(a, ops.LazyGN) and not ops.can_apply_gn_on_load(x.shape[0], fc["3"], x.shape[2], x.shape[3]):
-                a = tensor_of(a)
-            return ops.conv2d(a, fc["3"])
-        finally:
-            ops.STATS = None
+        feats, a_next = [], None
+        downs = list(self.downs)
+        for i, layer in enumerate(downs):
+            if isinstance(layer, _ResAttnBlock):
+                nxt = downs[i + 1] if i + 1 < len(downs) else self.mid[0]
+                x, a_next = layer.forward_inference(x, next(es), a_in=a_next, next_gn=gn1_of(nxt))
+            elif isinstance(layer, _Resample):
+                x, a_next = layer(x), None
+            else:
+                x, a_next = ops.conv2d(x, layer), None
+            feats.append(x)
+        x, a_next = self.mid[0].forward_inference(x, next(es), a_in=a_next, next_gn=gn1_of(self.mid[1]))
+        x, a_next = self.mid[1].forward_inference(x, next(es), a_in=a_next, next_gn=None)
+        ups = list(self.ups)
+        fc = self.final_conv["block"]
+        for i, layer in enumerate(ups):
+            if isinstance(layer, _ResAttnBlock):
+                last = i + 1 == len(ups)
+                x, a_next = layer.forward_inference(x, next(es), skip=feats.pop(), next_gn=(fc["0"], True) if last else None)
+            else:
+                x, a_next = layer(x), None
+        a = a_next if a_next is not None else ops.group_norm(x, fc["0"].weight, fc["0"].bias, self.norm_groups, silu=True)
+        return ops.conv2d(a, fc["3"])
 
     def forward(self, x, angle, time, dropout_u=None):
         """x (S,Cin,H,W), angle (S,1), time = noise level (S,1)  ->  (S,Cout,H,W).
@@ -371,9 +319,7 @@ class UNet(nn.Module):
             return ops.time_affine_all(emb, self._affine_layers())
 
         if inference:                                   # (Dropout active: the general path below applies it)
-            with ops.side_branch() as br:               # five small launches beside the stem conv (captured step)
-                es = list(embed())
-            return self._forward_inference(x, iter(es), (br, es))
+            return self._forward_inference(x, iter(embed()))
         es = iter(embed())
 
         # feats[i] feeds the next encoder layer AND the decoder: where that next layer is a residual block or a
