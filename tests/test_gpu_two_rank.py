@@ -64,6 +64,7 @@ def _worker(rank, world, port, out, lr, kind, graph, steps, env=None):
     env = dict(env or {})
     inject = env.pop("inject_capture_failure", None)     # "<rank>:<mode>": a Trainer attribute, not an environment knob
     leave_after = int(env.pop("leave_after", 0))         # this many iterations, then rank 1 stops taking part
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC (read when the HIP runtime initialises)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       VF_REDUCER=kind, **(env or {}))
     import torch.distributed as dist
