@@ -105,40 +105,40 @@ class _Conv2dFn(torch.autograd.Function):
         S, Cin, Hi, Wi = x.shape
         _, Cout, H, W = dy.shape
         KS, m = ctx.KS, ctx.m
-        st = _stream()
+        strm = _stream()
         dx = dw = db = dvb = dres = None
         if ctx.needs_input_grad[0] and ctx.wino:      # Winograd dgrad (dy and dx have the conv's output size)
             dfull = torch.empty(S, Cin, H, W, device=x.device, dtype=torch.float32)
             ws, nws = _wino_ws(x.device, S, Cout, Cin, H, W, ctx.wino)
             _launch("conv_dgrad", ctx.flops, _WINO_ABI[ctx.wino][3], _ptr(dy), _ptr(ctx.wb), None, None, None,
-                    _ptr(dfull), _ptr(ws), nws, S, Cout, Cin, H, W, 0, st, tag=ctx.tag,
+                    _ptr(dfull), _ptr(ws), nws, S, Cout, Cin, H, W, 0, strm, tag=ctx.tag,
                     nbytes=4.0 * (dy.numel() + dfull.numel() + ctx.pw.numel()))
             if m == 2:                                 # upsample + conv: 2x2 sum-pool back to the source size
                 dx = torch.empty_like(x)
-                _call("vf_sumpool2", _ptr(dfull), _ptr(dx), dx.numel(), Wi, st)
+                _call("vf_sumpool2", _ptr(dfull), _ptr(dx), dx.numel(), Wi, strm)
             else:
                 dx = dfull
         elif ctx.needs_input_grad[0] and ctx.b3:
             dx = torch.empty_like(x)
             _launch("conv_dgrad", ctx.flops, "vf_conv1x1_bf16x3", _ptr(dy), None, 0, ctypes.c_void_p(ctx.wb.data_ptr()), None,
-                    None, None, _ptr(dx), None, 0, S, Cout, Cin, H * W, st, tag=ctx.tag)
+                    None, None, _ptr(dx), None, 0, S, Cout, Cin, H * W, strm, tag=ctx.tag)
         elif ctx.needs_input_grad[0]:
             if m == 0:
                 dx = torch.empty_like(x)
                 ws, nws = _conv_ws(x.device, S, Cout, Cin, H, W, KS)
                 _launch("conv_dgrad", ctx.flops, "vf_conv_fwd", _ptr(dy), _ptr(ctx.wb), None, None, None, _ptr(dx),
-                        _ptr(ws), nws, S, Cout, Cin, H, W, KS, 0, st, tag=ctx.tag)
+                        _ptr(ws), nws, S, Cout, Cin, H, W, KS, 0, strm, tag=ctx.tag)
             elif m == 1:      # stride-2 conv: sub-pixel transposed conv (each output parity gets its own taps)
                 dx = torch.empty_like(x)
                 _launch("conv_dgrad", ctx.flops, "vf_conv_fwd", _ptr(dy), _ptr(ctx.wb), None, None, _ptr(dtap), _ptr(dx),
-                        None, 0, S, Cout, Cin, H, W, KS, 4, st, tag=ctx.tag)
+                        None, 0, S, Cout, Cin, H, W, KS, 4, strm, tag=ctx.tag)
                 dtap = None
             else:             # upsample + conv: dgrad at the upsampled size, then 2x2 sum-pool
                 dup = torch.empty(S, Cin, H, W, device=x.device, dtype=torch.float32)
                 _launch("conv_dgrad", ctx.flops, "vf_conv_fwd", _ptr(dy), _ptr(ctx.wb), None, None, None, _ptr(dup),
-                        None, 0, S, Cout, Cin, H, W, KS, 0, st, tag=ctx.tag)
+                        None, 0, S, Cout, Cin, H, W, KS, 0, strm, tag=ctx.tag)
                 dx = torch.empty_like(x)
-                _call("vf_sumpool2", _ptr(dup), _ptr(dx), dx.numel(), Wi, st)
+                _call("vf_sumpool2", _ptr(dup), _ptr(dx), dx.numel(), Wi, strm)
         hb, hv, hr = ctx.has
         want_b, want_v = hb and ctx.needs_input_grad[2], hv and ctx.needs_input_grad[3]
         arena = reducer.ACTIVE is not None
@@ -166,7 +166,7 @@ class _Conv2dFn(torch.autograd.Function):
                 row, nblk = (ctypes.c_longlong * 9)(), ctypes.c_int(0)
                 _launch("conv_wgrad", ctx.flops, "vf_wino_wgrad_main", _ptr(x), _ptr(dy), _ptr(dw), _ptr(db_here), _ptr(db2),
                         _ptr(ws), ws.numel(), S, Cin, Cout, H, W, m, ctypes.cast(row, ctypes.c_void_p),
-                        ctypes.cast(ctypes.pointer(nblk), ctypes.c_void_p), st, tag=ctx.tag)
+                        ctypes.cast(ctypes.pointer(nblk), ctypes.c_void_p), strm, tag=ctx.tag)
                 # (x and dy are not kept: the main kernel has consumed them in stream order; the flush reads ws only)
                 st._PENDING_WRED.append((list(row), nblk.value, (ws, dw, db_here, db2)))
                 # AccumulateGrad adopts an incoming gradient only while nobody else references that tensor OBJECT; any
@@ -178,26 +178,26 @@ class _Conv2dFn(torch.autograd.Function):
                     db = db_here.view_as(db_here)
             else:
                 _launch("conv_wgrad", ctx.flops, "vf_wino_wgrad", _ptr(x), _ptr(dy), _ptr(dw), _ptr(db_here), _ptr(db2),
-                        _ptr(ws), ws.numel(), S, Cin, Cout, H, W, m, st, tag=ctx.tag)
+                        _ptr(ws), ws.numel(), S, Cin, Cout, H, W, m, strm, tag=ctx.tag)
         elif ctx.needs_input_grad[1]:
             need = _lib.load().vf_conv_wgrad_ws_floats(S, Cin, Cout, H, W, KS)
             ws = _workspace(x.device, need)
             dw = _gout(ctx.pw, Cout, Cin, KS, KS, like=x)
             _launch("conv_wgrad", ctx.flops, "vf_conv_wgrad", _ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), ws.numel(), S,
-                    Cin, Cout, H, W, KS, m, st, tag=ctx.tag)
+                    Cin, Cout, H, W, KS, m, strm, tag=ctx.tag)
         if want_b or want_v:
             if (want_v and dvb is None) or (want_b and db is None and dvb is None):
                 if Cout >= 192:                  # one launch, one workgroup per channel (enough channels to fill the chip)
                     db_new = _gout(ctx.pb, Cout, like=x) if (want_b and db is None) else None
                     dvb = torch.empty(S, Cout, device=x.device, dtype=torch.float32) if want_v else None
-                    _call("vf_bias_grad", _ptr(dy), _ptr(db_new), _ptr(dvb), S, Cout, H * W, st)
+                    _call("vf_bias_grad", _ptr(dy), _ptr(db_new), _ptr(dvb), S, Cout, H * W, strm)
                     db = db_new if db_new is not None else db
                 else:                            # few channels: wave-per-row partial sums, then the column sum
                     dvb = torch.empty(S, Cout, device=x.device, dtype=torch.float32)
-                    _call("vf_rowsum", _ptr(dy), _ptr(dvb), S * Cout, H * W, st)
+                    _call("vf_rowsum", _ptr(dy), _ptr(dvb), S * Cout, H * W, strm)
             if want_b and db is None:
                 db = _gout(ctx.pb, Cout, like=x)
-                _call("vf_colsum", _ptr(dvb), _ptr(db), 1, S, Cout, st)
+                _call("vf_colsum", _ptr(dvb), _ptr(db), 1, S, Cout, strm)
             if hr and want_b:                    # the residual branch (1x1 conv) receives this very dY
                 # a tensor living in the gradient arena is all-reduced in place as soon as its segment is complete:
                 # it must never be handed to a second layer (which gets db2, or re-derives db from the row sums)
@@ -245,22 +245,22 @@ class _Conv1x1CatFn(torch.autograd.Function):
         dy = _c(dy)
         S, C1, H, W = x1.shape
         Cin, Cout = ctx.dims
-        st = _stream()
+        strm = _stream()
         flops, tag = 2.0 * S * Cout * Cin * H * W, (Cin, Cout, H, 1, 0)
         dx1 = dx2 = dw = db = None
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
             dx1, dx2 = torch.empty_like(x1), torch.empty_like(x2)
             if ctx.b3:
                 _launch("conv_dgrad", flops, "vf_conv1x1_bf16x3", _ptr(dy), None, 0, ctypes.c_void_p(ctx.wb.data_ptr()), None,
-                        None, None, _ptr(dx1), _ptr(dx2), C1, S, Cout, Cin, H * W, st, tag=tag)
+                        None, None, _ptr(dx1), _ptr(dx2), C1, S, Cout, Cin, H * W, strm, tag=tag)
             else:
                 _launch("conv_dgrad", flops, "vf_conv1x1_cat_dgrad", _ptr(dy), _ptr(ctx.wb), _ptr(dx1), _ptr(dx2), C1, S,
-                        Cin, Cout, H, W, st, tag=tag)
+                        Cin, Cout, H, W, strm, tag=tag)
         if ctx.needs_input_grad[2]:
             ws = _workspace(x1.device, _lib.load().vf_conv_wgrad_ws_floats(S, Cin, Cout, H, W, 1))
             dw = _gout(ctx.pw, Cout, Cin, 1, 1, like=x1)
             _launch("conv_wgrad", flops, "vf_conv1x1_cat_wgrad", _ptr(x1), _ptr(x2), C1, _ptr(dy), _ptr(dw), _ptr(ws),
-                    ws.numel(), S, Cin, Cout, H, W, st, tag=tag)
+                    ws.numel(), S, Cin, Cout, H, W, strm, tag=tag)
         if ctx.has_bias and ctx.needs_input_grad[3]:
             hit = _rowsum_get(dy)                     # the 3x3 conv this output is added to has summed this dY
             db = hit[2].view_as(hit[2]) if (hit is not None and hit[2] is not None) else None     # (a fresh object: see _fresh)
@@ -268,9 +268,9 @@ class _Conv1x1CatFn(torch.autograd.Function):
                 dvb = hit[1] if hit is not None else None
                 if dvb is None:
                     dvb = torch.empty(S, Cout, device=x1.device, dtype=torch.float32)
-                    _call("vf_rowsum", _ptr(dy), _ptr(dvb), S * Cout, H * W, st)
+                    _call("vf_rowsum", _ptr(dy), _ptr(dvb), S * Cout, H * W, strm)
                 db = _gout(ctx.pb, Cout, like=x1)
-                _call("vf_colsum", _ptr(dvb), _ptr(db), 1, S, Cout, st)
+                _call("vf_colsum", _ptr(dvb), _ptr(db), 1, S, Cout, strm)
         return dx1, dx2, dw, db, None, None
 
 
