@@ -129,6 +129,14 @@ int vf_conv1x1_bf16x3(const float* x, const float* x2, int C1in, const void* w3,
 long vf_conv_wgrad_ws_floats(int S, int Cin, int Cout, int H, int W, int KS);
 int vf_conv_wgrad(const float* x, const float* dy, float* dw_oihw, float* ws, long ws_floats, int S, int Cin,
                   int Cout, int H, int W, int KS, int mode, void* stream);
+/* vf_conv_wgrad / vf_conv1x1_cat_wgrad without their follow-up launch (round 6): the main kernel only; desc9 (HOST memory,
+ * 9 x int64) receives the row vf_wino44_reduce_multi needs for this layer, *nblocks its workgroup count; ws must stay
+ * untouched until that launch (hosts that can postpone the weight gradients to the end of the backward pass). */
+int vf_conv_wgrad_main(const float* x, const float* dy, float* dw_oihw, float* ws, long ws_floats, int S, int Cin,
+                       int Cout, int H, int W, int KS, int mode, long long* desc9, int* nblocks, void* stream);
+int vf_conv1x1_cat_wgrad_main(const float* x1, const float* x2, int C1, const float* dy, float* dw_oihw, float* ws,
+                              long ws_floats, int S, int Cin, int Cout, int H, int W, long long* desc9, int* nblocks,
+                              void* stream);
 int vf_sumpool2(const float* x, float* y, long n_out, int Wo, void* stream);
 
 /* fused Winograd F(2x2,3x3) path for stride-1 3x3 convs on 8x8 / 16x16 / 32x32 / 64x64 maps (forward and

@@ -169,12 +169,17 @@ def test_weight_gradient_slab_sums_are_deferred_into_one_launch(dev):
     n_main = names.count("vf_wino_wgrad_main")
     assert n_main >= 20 and names.count("vf_wino44_reduce_multi") == 1 and "vf_wino_wgrad" not in names, \
         (n_main, names.count("vf_wino44_reduce_multi"), names.count("vf_wino_wgrad"))
+    # round 6: the direct / 1x1 weight gradients' slab sums ride in the same launch
+    n_gen = names.count("vf_conv_wgrad_main") + names.count("vf_conv1x1_cat_wgrad_main")
+    assert n_gen >= 20 and "vf_conv_wgrad" not in names and "vf_conv1x1_cat_wgrad" not in names, n_gen
     names, g_now = run(False)
     assert names.count("vf_wino_wgrad") == n_main and "vf_wino_wgrad_main" not in names
+    assert names.count("vf_conv_wgrad") + names.count("vf_conv1x1_cat_wgrad") == n_gen and "vf_conv_wgrad_main" not in names
     for a, b in zip(g_def, g_now):
         assert torch.equal(a, b)
     names, g_acc = run(True, zero=False)                  # second pass on top of the existing gradients
     assert "vf_wino_wgrad_main" not in names and names.count("vf_wino_wgrad") == n_main
+    assert "vf_conv_wgrad_main" not in names and "vf_conv1x1_cat_wgrad_main" not in names
     for a, b in zip(g_acc, g_now):
         assert float((a - 2 * b).abs().max()) <= 1e-6 * float(b.abs().max()) + 1e-12
 

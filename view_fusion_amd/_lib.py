@@ -70,6 +70,8 @@ SIGNATURES = {
     "vf_wino_wgrad": [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P],
     "vf_wino_wgrad_main": [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P, _P, _P],
     "vf_wino44_reduce_multi": [_P, _I, _I, _P],
+    "vf_conv_wgrad_main": [_P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P],
+    "vf_conv1x1_cat_wgrad_main": [_P, _P, _I, _P, _P, _P, _L, _I, _I, _I, _I, _I, _P, _P, _P],
     "vf_sumpool2": [_P, _P, _L, _I, _P],
     "vf_time_affine_fwd": [_P, _I, _P, _P, _I, _I, _I, _P],
     "vf_time_affine_ws_floats": [_I, _I],

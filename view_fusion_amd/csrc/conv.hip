@@ -21,6 +21,8 @@
 //
 // Bound: fp32 matrix rate (157.3 TF), not HBM: AI of these layers is 144-960 flop/B.
 #include "common.h"
+#include "wgrad_reduce.h"
+#include <cstring>
 #include "conv1x1.h"
 #include <cstdlib>
 
@@ -629,39 +631,13 @@ __global__ __launch_bounds__(256, BIG ? 1 : 2) void conv_wgrad_kernel(WgradArgs 
     }
 }
 
-// dw[co][ci][tap] = sum_slab ws[slab][tap][co][ci]
-// block = 64 consecutive (tap,co,ci) outputs x 4 slab groups (fixed 4-way split + fixed tree:
-// deterministic), so that small weight tensors still spread over the chip.
+// dw[co][ci][tap] = sum_slab ws[slab][tap][co][ci]: wgrad_reduce_body (wgrad_reduce.h), one launch per layer here; a host
+// that can postpone the weight gradients runs the *_main entry points instead and sums every layer's slabs with ONE
+// vf_wino44_reduce_multi launch at the end of the backward pass (round 6: 38 launches of ~6 us per training iteration gone).
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
                                                            int nslab, int NT, int Cout, int Cin, int CoutP,
                                                            int CinQ) {
-    __shared__ float red[4][64];
-    const int ox = threadIdx.x & 63, sy = threadIdx.x >> 6;
-    const int idx = blockIdx.x * 64 + ox;                     // over (tap, co, ci), ci fastest
-    const int total = NT * Cout * Cin;
-    float acc = 0.f;
-    int ci = 0, co = 0, tap = 0;
-    if (idx < total) {
-        ci = idx % Cin;
-        const int t = idx / Cin;
-        co = t % Cout;
-        tap = t / Cout;
-        const size_t stride = (size_t)NT * CoutP * CinQ;
-        const float* p = ws + ((size_t)tap * CoutP + co) * CinQ + ci;
-        float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // 8 slabs in flight per thread, fixed order
-        for (int s = sy; s < nslab; s += 32) {
-            float t[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) t[j] = p[(size_t)min(s + 4 * j, nslab - 1) * stride];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) a8[j] += s + 4 * j < nslab ? t[j] : 0.f;
-        }
-        acc = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
-    }
-    red[sy][ox] = acc;
-    __syncthreads();
-    if (sy == 0 && idx < total)
-        dw[((size_t)co * Cin + ci) * NT + tap] = (red[0][ox] + red[1][ox]) + (red[2][ox] + red[3][ox]);
+    wgrad_reduce_body(ws, dw, nslab, NT, Cout, Cin, CoutP, CinQ, (int)blockIdx.x);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -1100,7 +1076,7 @@ int launch_conv(const ConvArgs& a, hipStream_t st, long ws_floats) {
 }
 
 template <int KS, int LOGW, int MODE>
-int launch_wgrad(WgradArgs a, float* dw, size_t ws_floats, hipStream_t st) {
+int launch_wgrad(WgradArgs a, float* dw, size_t ws_floats, hipStream_t st, long long* desc = nullptr, int* nblocks = nullptr) {
     using G = Geo<KS, LOGW, MODE, 128>;
     constexpr int NT = KS * KS;
     constexpr bool BIG = MODE != 1;                  // stride-2 patches do not fit the big tile
@@ -1118,6 +1094,10 @@ int launch_wgrad(WgradArgs a, float* dw, size_t ws_floats, hipStream_t st) {
     z = (a.ntiles + a.tiles_per_slice - 1) / a.tiles_per_slice;
     hipLaunchKernelGGL((conv_wgrad_kernel<KS, LOGW, MODE, BIG>), dim3(nco, nci, z), dim3(256), 0, st, a);
     const int total = NT * a.Cout * a.Cin;
+    if (desc) {                                       // the slab sum joins the caller's deferred multi launch
+        *nblocks = wgrad_reduce_row(desc, a.ws, dw, z, NT, a.Cout, a.Cin, a.CoutP, a.CinQ);
+        VF_RETURN_LAST_ERROR();
+    }
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 63) / 64), dim3(256), 0, st, a.ws, dw, z, NT,
                        a.Cout, a.Cin, a.CoutP, a.CinQ);
     VF_RETURN_LAST_ERROR();
@@ -1299,7 +1279,9 @@ long vf_conv_wgrad_ws_floats(int S, int Cin, int Cout, int H, int W, int KS) {
 // dw[Cout][Cin][KS][KS] = sum_{s,p} dy[s][co][p] * x_as_seen_by_the_conv[s][ci][p (+) tap]
 // (H, W = OUTPUT size = dy size; mode as in vf_conv_fwd, 0..2).
 static int conv_wgrad_impl(const float* x, const float* x2, int C1, const float* dy, float* dw, float* ws,
-                           long ws_floats, int S, int Cin, int Cout, int H, int W, int KS, int mode, void* stream) {
+                           long ws_floats, int S, int Cin, int Cout, int H, int W, int KS, int mode, void* stream,
+                           long long* desc = nullptr, int* nblocks = nullptr) {
+    if (desc) *nblocks = 0;
     if (S <= 0) return 0;
     const int lw = ilog2_exact(W);
     if (H != W || lw < 3 || lw > 7 || (KS != 1 && KS != 3)) return (int)hipErrorInvalidValue;
@@ -1327,6 +1309,10 @@ static int conv_wgrad_impl(const float* x, const float* x2, int C1, const float*
         else if (tn == 128) hipLaunchKernelGGL((conv1x1_wgrad_kernel<64, 128>), grid, dim3(256), 0, st1, g);
         else hipLaunchKernelGGL((conv1x1_wgrad_kernel<64, 64>), grid, dim3(256), 0, st1, g);
         const int total = Cout * Cin;
+        if (desc) {
+            *nblocks = wgrad_reduce_row(desc, ws, dw, z, 1, Cout, Cin, g.CoutP, g.CinQ);
+            VF_RETURN_LAST_ERROR();
+        }
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 63) / 64), dim3(256), 0, st1, ws, dw, z, 1, Cout, Cin,
                            g.CoutP, g.CinQ);
         VF_RETURN_LAST_ERROR();
@@ -1337,7 +1323,7 @@ static int conv_wgrad_impl(const float* x, const float* x2, int C1, const float*
     a.CinQ = round_up(Cin, 32);
     hipStream_t st = (hipStream_t)stream;
 #define VF_CASE(KS_, LW_, M_) \
-    if (KS == KS_ && lw == LW_ && mode == M_) return launch_wgrad<KS_, LW_, M_>(a, dw, (size_t)ws_floats, st);
+    if (KS == KS_ && lw == LW_ && mode == M_) return launch_wgrad<KS_, LW_, M_>(a, dw, (size_t)ws_floats, st, desc, nblocks);
     VF_CASE(3, 3, 0) VF_CASE(3, 4, 0) VF_CASE(3, 5, 0) VF_CASE(3, 6, 0) VF_CASE(3, 7, 0)
     VF_CASE(3, 3, 1) VF_CASE(3, 4, 1) VF_CASE(3, 5, 1) VF_CASE(3, 6, 1)
     VF_CASE(3, 4, 2) VF_CASE(3, 5, 2) VF_CASE(3, 6, 2) VF_CASE(3, 7, 2)
@@ -1353,6 +1339,22 @@ int vf_conv_wgrad(const float* x, const float* dy, float* dw, float* ws, long ws
 int vf_conv1x1_cat_wgrad(const float* x1, const float* x2, int C1, const float* dy, float* dw, float* ws,
                          long ws_floats, int S, int Cin, int Cout, int H, int W, void* stream) {
     return conv_wgrad_impl(x1, x2, C1, dy, dw, ws, ws_floats, S, Cin, Cout, H, W, 1, 0, stream);
+}
+
+// vf_conv_wgrad / vf_conv1x1_cat_wgrad without their follow-up launch: the main kernel only; desc9 (HOST memory, 9 x int64)
+// receives the row that vf_wino44_reduce_multi needs for this layer, *nblocks its workgroup count.  ws must stay untouched
+// until that launch.
+int vf_conv_wgrad_main(const float* x, const float* dy, float* dw, float* ws, long ws_floats, int S, int Cin, int Cout,
+                       int H, int W, int KS, int mode, long long* desc9, int* nblocks, void* stream) {
+    if (!desc9 || !nblocks) return (int)hipErrorInvalidValue;
+    return conv_wgrad_impl(x, nullptr, Cin, dy, dw, ws, ws_floats, S, Cin, Cout, H, W, KS, mode, stream, desc9, nblocks);
+}
+
+int vf_conv1x1_cat_wgrad_main(const float* x1, const float* x2, int C1, const float* dy, float* dw, float* ws,
+                              long ws_floats, int S, int Cin, int Cout, int H, int W, long long* desc9, int* nblocks,
+                              void* stream) {
+    if (!desc9 || !nblocks) return (int)hipErrorInvalidValue;
+    return conv_wgrad_impl(x1, x2, C1, dy, dw, ws, ws_floats, S, Cin, Cout, H, W, 1, 0, stream, desc9, nblocks);
 }
 
 int vf_sumpool2(const float* x, float* y, long n_out, int Wo, void* stream) {

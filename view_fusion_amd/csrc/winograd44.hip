@@ -27,6 +27,7 @@
 // of the 36-slice dU.  wino44_reduce_kernel sums the slabs in a fixed order (no float atomics) and writes dW (one
 // follow-up launch instead of the F(2x2) kernel's two).
 #include "common.h"
+#include "wgrad_reduce.h"
 #include <cstring>
 
 namespace {
@@ -694,15 +695,7 @@ __global__ __launch_bounds__(256) void wino44_reduce_kernel(const float* __restr
 // workspace alive and sum all of them here -- 65 follow-up launches of ~7 us per training iteration become one (or one
 // per all-reduce segment) that runs at the chip's streaming rate.  Row = what wino44_reduce_kernel takes + the row's first
 // workgroup in this launch (9 x 8 bytes).
-struct W44Red {
-    const float* ws;
-    float* dw;
-    const float* bsum;
-    float* db;
-    float* db2;
-    int Cout, Cin, CoutP, CinQ, nslab, nmain, first, pad;
-};
-static_assert(sizeof(W44Red) == 72, "descriptor row = 9 x int64");
+// (W44Red: wgrad_reduce.h -- round 6: rows with nt != 0 are direct / 1x1 weight gradients, summed by wgrad_reduce_body)
 
 __global__ __launch_bounds__(256) void wino44_reduce_multi_kernel(const W44Red* __restrict__ tab, int nrows) {
     __shared__ int row_s;
@@ -716,6 +709,10 @@ __global__ __launch_bounds__(256) void wino44_reduce_multi_kernel(const W44Red* 
     }
     __syncthreads();
     const W44Red d = tab[row_s];
+    if (d.nt != 0) {                                  // (uniform over the workgroup)
+        wgrad_reduce_body(d.ws, d.dw, d.nslab, d.nt, d.Cout, d.Cin, d.CoutP, d.CinQ, (int)blockIdx.x - d.first);
+        return;
+    }
     wino44_reduce_body(d.ws, d.dw, d.Cout, d.Cin, d.CoutP, d.CinQ, d.nslab, d.bsum, d.db, d.db2, d.nmain,
                        (int)blockIdx.x - d.first);
 }
@@ -743,7 +740,7 @@ int launch_wino44_wgrad(W44Args a, float* dw, float* db, float* db2, size_t ws_f
     if (desc) {
         W44Red r;
         r.ws = a.ws; r.dw = dw; r.bsum = a.bsum; r.db = db; r.db2 = db2;
-        r.Cout = a.Cout; r.Cin = a.Cin; r.CoutP = a.CoutP; r.CinQ = a.CinQ; r.nslab = z; r.nmain = nmain; r.first = 0; r.pad = 0;
+        r.Cout = a.Cout; r.Cin = a.Cin; r.CoutP = a.CoutP; r.CinQ = a.CinQ; r.nslab = z; r.nmain = nmain; r.first = 0; r.nt = 0;
         memcpy(desc, &r, sizeof(r));
         *nblocks = nmain + nbias;
         VF_RETURN_LAST_ERROR();

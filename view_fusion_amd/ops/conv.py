@@ -181,10 +181,21 @@ class _Conv2dFn(torch.autograd.Function):
                         _ptr(ws), ws.numel(), S, Cin, Cout, H, W, m, strm, tag=ctx.tag)
         elif ctx.needs_input_grad[1]:
             need = _lib.load().vf_conv_wgrad_ws_floats(S, Cin, Cout, H, W, KS)
-            ws = _workspace(x.device, need)
             dw = _gout(ctx.pw, Cout, Cin, KS, KS, like=x)
-            _launch("conv_wgrad", ctx.flops, "vf_conv_wgrad", _ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), ws.numel(), S,
-                    Cin, Cout, H, W, KS, m, strm, tag=ctx.tag)
+            # (round 6) the direct / 1x1 kernels' slab sums join the pass's deferred multi launch too
+            ws_own = _wred_ws(x.device, need) if (st.WRED_DEFER and st.WRED_DEFER_GENERIC
+                                                 and _defer_begin([ctx.pw], st._CAPTURE_TABLE_W)) else None
+            if ws_own is not None:
+                row, nblk = (ctypes.c_longlong * 9)(), ctypes.c_int(0)
+                _launch("conv_wgrad", ctx.flops, "vf_conv_wgrad_main", _ptr(x), _ptr(dy), _ptr(dw), _ptr(ws_own), ws_own.numel(),
+                        S, Cin, Cout, H, W, KS, m, ctypes.cast(row, ctypes.c_void_p),
+                        ctypes.cast(ctypes.pointer(nblk), ctypes.c_void_p), strm, tag=ctx.tag)
+                st._PENDING_WRED.append((list(row), nblk.value, (ws_own, dw, None, None)))
+                dw = dw.view_as(dw)                   # (a fresh object for autograd: see the Winograd branch above)
+            else:
+                ws = _workspace(x.device, need)
+                _launch("conv_wgrad", ctx.flops, "vf_conv_wgrad", _ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), ws.numel(), S,
+                        Cin, Cout, H, W, KS, m, strm, tag=ctx.tag)
         if want_b or want_v:
             if (want_v and dvb is None) or (want_b and db is None and dvb is None):
                 if Cout >= 192:                  # one launch, one workgroup per channel (enough channels to fill the chip)
@@ -257,10 +268,21 @@ class _Conv1x1CatFn(torch.autograd.Function):
                 _launch("conv_dgrad", flops, "vf_conv1x1_cat_dgrad", _ptr(dy), _ptr(ctx.wb), _ptr(dx1), _ptr(dx2), C1, S,
                         Cin, Cout, H, W, strm, tag=tag)
         if ctx.needs_input_grad[2]:
-            ws = _workspace(x1.device, _lib.load().vf_conv_wgrad_ws_floats(S, Cin, Cout, H, W, 1))
+            need = _lib.load().vf_conv_wgrad_ws_floats(S, Cin, Cout, H, W, 1)
             dw = _gout(ctx.pw, Cout, Cin, 1, 1, like=x1)
-            _launch("conv_wgrad", flops, "vf_conv1x1_cat_wgrad", _ptr(x1), _ptr(x2), C1, _ptr(dy), _ptr(dw), _ptr(ws),
-                    ws.numel(), S, Cin, Cout, H, W, strm, tag=tag)
+            ws_own = _wred_ws(x1.device, need) if (st.WRED_DEFER and st.WRED_DEFER_GENERIC
+                                                  and _defer_begin([ctx.pw], st._CAPTURE_TABLE_W)) else None
+            if ws_own is not None:                    # slab sum deferred to the pass's one multi launch (see _Conv2dFn)
+                row, nblk = (ctypes.c_longlong * 9)(), ctypes.c_int(0)
+                _launch("conv_wgrad", flops, "vf_conv1x1_cat_wgrad_main", _ptr(x1), _ptr(x2), C1, _ptr(dy), _ptr(dw),
+                        _ptr(ws_own), ws_own.numel(), S, Cin, Cout, H, W, ctypes.cast(row, ctypes.c_void_p),
+                        ctypes.cast(ctypes.pointer(nblk), ctypes.c_void_p), strm, tag=tag)
+                st._PENDING_WRED.append((list(row), nblk.value, (ws_own, dw, None, None)))
+                dw = dw.view_as(dw)
+            else:
+                ws = _workspace(x1.device, need)
+                _launch("conv_wgrad", flops, "vf_conv1x1_cat_wgrad", _ptr(x1), _ptr(x2), C1, _ptr(dy), _ptr(dw), _ptr(ws),
+                        ws.numel(), S, Cin, Cout, H, W, strm, tag=tag)
         if ctx.has_bias and ctx.needs_input_grad[3]:
             hit = _rowsum_get(dy)                     # the 3x3 conv this output is added to has summed this dY
             db = hit[2].view_as(hit[2]) if (hit is not None and hit[2] is not None) else None     # (a fresh object: see _fresh)

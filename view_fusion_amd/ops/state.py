@@ -38,6 +38,7 @@ class State:
         self.ROWSUM_FUSION = True
         self.COLSUM_DEFER = True
         self.WRED_DEFER = os.environ.get("VF_WRED_DEFER", "1") != "0"
+        self.WRED_DEFER_GENERIC = os.environ.get("VF_WRED_DEFER_GENERIC", "1") != "0"   # the direct / 1x1 kernels' slabs too (round 6)
         self._PENDING_COLSUMS = []
         self._PENDING_TASK = None      # torch._C._current_graph_task_id() of the backward pass the pending entries belong to
         self._PENDING_WRED = []        # [(row: list of 9 int64, workgroups, keep-alive tensors)]
