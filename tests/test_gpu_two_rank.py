@@ -108,11 +108,11 @@ def _free_port():
     return p
 
 
-def _spawn(lr, kind="arena", graph=False, steps=3, env=None):
+def _spawn(lr, kind="arena", graph=False, steps=3, env=None, world=2):
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_worker, args=(2, _free_port(), out, lr, kind, graph, steps, env), nprocs=2, join=True)
-    return out[0], out[1]
+    mp.spawn(_worker, args=(world, _free_port(), out, lr, kind, graph, steps, env), nprocs=world, join=True)
+    return tuple(out[r] for r in range(world))
 
 
 def _check_against_global_batch(r0, r1, STEPS, ragged):
@@ -188,6 +188,33 @@ def test_xgmi_reducer_matches_the_arena_bit_for_bit():
         assert ta == t0 == STEPS and torch.equal(ma, m0) and torch.equal(va, v0)
     r0, r1 = _spawn(0.0, "xgmi", False, 3)
     _check_against_global_batch(r0, r1, 3, True)
+
+
+def test_xgmi_reducer_three_ranks():
+    """World 3 (three processes on the one GPU): the flag blocks, peer tables and the rank-order sum at a world that is
+    neither 2 nor a power of two.  Replicas bit-identical after four updating iterations; with lr = 0 every rank's averaged
+    gradients equal single-process gradients on the concatenated batch of all three shards."""
+    from view_fusion_amd import train
+    STEPS = 4
+    rs = _spawn(1e-4, "xgmi", False, STEPS, world=3)
+    assert all(r["error"] is None for r in rs) and rs[0]["info"]["world_size"] == 3
+    for a, b, c in zip(rs[0]["params"], rs[1]["params"], rs[2]["params"]):
+        assert torch.equal(a, b) and torch.equal(a, c)
+    rs = _spawn(0.0, "xgmi", False, 2, world=3)
+    dev = torch.device("cuda:0")
+    vf = _model(dev)
+    tr = train.Trainer(vf, world=1, lr_warmup=1, graph=False)
+    tr.it, tr.sched.peak_lr = 0, 0.0
+    glob = []
+    for s in range(2):
+        shards = [_batch(s, r, True) for r in range(3)]
+        glob.append({k: torch.cat([sh[k] for sh in shards]) for k in shards[0]})
+    ref = _run(tr, vf, glob, dev)
+    for s in range(2):
+        for g0, g1, g2, gr in zip(rs[0]["grads"][s], rs[1]["grads"][s], rs[2]["grads"][s], ref[s]):
+            assert torch.equal(g0, g1) and torch.equal(g0, g2)
+            err = float((g0.double() - gr.double()).norm())
+            assert err <= 2e-5 * float(gr.double().norm()) + 1e-7 * gr.numel() ** 0.5, (s, err)
 
 
 def test_xgmi_reducer_turns_a_missing_peer_into_an_error():
