@@ -366,9 +366,12 @@ def test_gradient_arena_matches_plain_training(dev):
         # eager | captured (collectives inside the graph: the default for a group of one) | split on RCCL (what a real
         # multi-rank run defaults to: forward + backward replayed, collectives + Adam eager) | a capture that fails in
         # captured mode: the failure flag rides the all-reduce, the agreement point steps down to split, which captures
+        # | the hand-written exchange (VF_REDUCER=xgmi) over the same RCCL-initialised group of one: its own rank is the
+        # only "peer", the fused kernels average over one arena and apply Adam -- same parameters, bit for bit
         for graph, env, mode in ((False, {}, "eager"), (True, {}, "captured"),
                                  (True, {"VF_CAPTURE_COLLECTIVES": "0"}, "split"),
-                                 (True, {"inject": "0:captured"}, "split")):
+                                 (True, {"inject": "0:captured"}, "split"),
+                                 (True, {"VF_REDUCER": "xgmi"}, "eager")):
             env = dict(env)
             train.Trainer.inject_capture_failure = env.pop("inject", None)
             injected = train.Trainer.inject_capture_failure is not None
@@ -382,9 +385,15 @@ def test_gradient_arena_matches_plain_training(dev):
             a = tr.arena
             assert a is not None and reducer.ACTIVE is a and tr.mode == mode, (tr.mode, mode)
             assert copied[1:] == [0] * (STEPS - 1), copied   # zero-copy from the second iteration on (capture included)
-            assert all(p.grad.data_ptr() == a.base + 4 * a.off[i] for i, p in enumerate(a.params))
+            xg = env.get("VF_REDUCER") == "xgmi"
+            if xg:                                       # p.grad = the averaged-gradient buffer, same layout as the arena
+                assert all(p.grad.data_ptr() == a.gavg.data_ptr() + 4 * a.off[i] for i, p in enumerate(a.params))
+            else:
+                assert all(p.grad.data_ptr() == a.base + 4 * a.off[i] for i, p in enumerate(a.params))
             assert len(a.seg_range) >= 2 and a.seg_range[-1][1] == a.flat.numel()
-            if injected:                                 # it = 4 fails, read at it = 6, sightings 6-7, replay at it = 8
+            if xg:
+                assert tr.graph_steps == 0 and tr.dist_info()["reducer"] == "xgmi"
+            elif injected:                                 # it = 4 fails, read at it = 6, sightings 6-7, replay at it = 8
                 assert tr.demotions == 1 and tr.graph_steps == 1, (tr.demotions, tr.graph_steps)
             elif graph:                                  # iterations 0-2 eager (layout, two sightings), then replays
                 assert a.capturable == (mode == "captured")
