@@ -6,7 +6,9 @@
  *   - raw DEVICE pointers to contiguous fp32 NCHW tensors, explicit sizes, explicit stream
  *     (`hipStream_t` passed as void*); no torch types;
  *   - every call only ENQUEUES work: no allocation, no synchronisation, no retained
- *     pointers, re-entrant, HIP-graph capturable; workspaces are passed in by the caller;
+ *     pointers, re-entrant, HIP-graph capturable; workspaces are passed in by the caller
+ *     (the one exception: the five vf_xgmi_* MEMORY calls at the end of this file, which allocate / export / map the
+ *     IPC-shared gradient arena once per process, outside any stream);
  *   - return value is a hipError_t as int (0 = success; hipErrorInvalidValue for an
  *     unsupported shape -- there is no fallback path).
  */

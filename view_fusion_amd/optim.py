@@ -193,7 +193,7 @@ class FusedAdam(torch.optim.Optimizer):
                 ops._launch("adam", 0.0, "vf_adam_multi", ctypes.c_void_p(b["dev"][f].data_ptr()), len(grads), b["blocks"],
                             float(group["lr"]), float(b1), float(b2), float(group["eps"]), 1.0 - b1 ** t, 1.0 - b2 ** t,
                             raw, nbytes=28.0 * b["numel"])   # 4 reads + 3 writes
-                # the kernel writes through raw pointers: tell autograd (and the packed-weight caches of ops.py,
+                # the kernel writes through raw pointers: tell autograd (and the packed-weight caches of ops/packing.py,
                 # which are keyed on the version counter) that the parameters changed
                 torch.autograd.graph.increment_version(b["params"])
         return loss
