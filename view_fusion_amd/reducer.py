@@ -345,6 +345,12 @@ class _IpcBuffer:
             _lib.call("vf_xgmi_free", ctypes.c_void_p(self.ptr))
             self.ptr = 0
 
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:           # noqa: BLE001  (interpreter shutdown: the driver reclaims the memory with the process)
+            pass
+
 
 def _ipc_open(handle):
     from . import _lib
@@ -414,15 +420,22 @@ class XgmiArena(GradArena):
         dist.barrier(group=self.group)                               # every rank has mapped every rank
 
     def close(self):
-        """Unmap the peers and free the arena (end of the run; every rank after a barrier)."""
+        """End of the run, called by EVERY rank: unmap the peers' memory, wait until every rank has done so (nobody may
+        free memory a peer still has mapped), then free this rank's arena and flag block."""
         from . import _lib
         torch.cuda.synchronize()
         for ptr in self._opened:
             _lib.call("vf_xgmi_close", ctypes.c_void_p(ptr))
         self._opened = []
-        self.flat = self._gviews = None
         for p in self.params:
             p.grad = None
+        self.flat = self._gviews = self.gavg = None
+        if self._mem is not None:
+            dist.barrier(group=self.group)
+            self._flagmem.free()
+            # (the arena tensor may still be referenced by a caller's gradient views: its memory is returned to the driver
+            # only when torch drops the last tensor over it -- _IpcBuffer.__del__)
+            self._mem = self._flagmem = None
 
     # -- per iteration ------------------------------------------------------------------------------------------
     def begin_step(self, opt):
